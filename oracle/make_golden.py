@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported read-only from
+/root/reference) in the build container.  Test infrastructure only; never runs on the GPU box.
+
+    python -m oracle.make_golden            # from the repo root; rewrites tests/golden/
+
+What travels to the repo is data only: seeded inputs and the reference's outputs.  Model weights
+are not stored - they are regenerated from ``egohmr_amd.synthetic.make_state_dict(seed)`` and
+pushed into the reference through ``load_state_dict``.
+
+Shims injected before importing the reference: ``smplx`` (absent pip
+package; ``smplx.create`` returns an nn.Module around the oracle LBS of oracle/smpl.py, so LBS is
+NOT pinned by these fixtures), ``coap`` (absent; ``attach_coap`` attaches the build's proxy loss),
+``torch.utils.model_zoo.load_url`` (no network), ``data/smpl_mean_params.npz`` in a temp cwd, a
+SimpleNamespace cfg for the yacs keys the path reads.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+import tempfile
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from egohmr_amd import synthetic as syn  # noqa: E402
+from oracle.collision import proxy_collision_loss  # noqa: E402
+from oracle.smpl import SMPLOracle  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------- shims
+
+class _ShimSMPL(nn.Module):
+    """nn.Module facade with smplx buffer names around the oracle LBS."""
+
+    def __init__(self, asset):
+        super().__init__()
+        self._oracle = SMPLOracle(asset)
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+            self.register_buffer(k, torch.as_tensor(asset[k]))
+        self.faces = asset["faces"]
+
+    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, return_full_pose=False,
+                pose2rot=True, **kw):
+        o = self._oracle(betas=betas, body_pose=body_pose, global_orient=global_orient,
+                         return_full_pose=return_full_pose, pose2rot=pose2rot)
+        return SimpleNamespace(vertices=o.vertices, joints=o.joints, full_pose=o.full_pose, betas=betas,
+                               body_pose=body_pose, global_orient=global_orient)
+
+
+class _ShimCoap(nn.Module):
+    def collision_loss(self, points, smpl_output, ret_collision_mask=None):
+        return proxy_collision_loss(points, smpl_output.vertices)
+
+
+def install_shims(asset):
+    smplx = types.ModuleType("smplx")
+    smplx.create = lambda *a, **k: _ShimSMPL(asset)
+    smplx_utils = types.ModuleType("smplx.utils")
+
+    class SMPLOutput:  # default-constructible with assignable attributes (egohmr.py:393-404)
+        pass
+
+    smplx_utils.SMPLOutput = SMPLOutput
+    smplx.utils = smplx_utils
+    sys.modules["smplx"] = smplx
+    sys.modules["smplx.utils"] = smplx_utils
+    coap = types.ModuleType("coap")
+
+    def attach_coap(model, pretrained=True, device=None):
+        model.coap = _ShimCoap()
+        return model
+
+    coap.attach_coap = attach_coap
+    sys.modules["coap"] = coap
+    import torch.utils.model_zoo as mz
+    mz.load_url = lambda *a, **k: {}
+    sys.path.insert(0, REF)
+
+
+def ref_cfg():
+    return SimpleNamespace(MODEL=SimpleNamespace(BACKBONE=SimpleNamespace(NUM_LAYERS=50, OUT_CHANNELS=2048)),
+                           CAM=SimpleNamespace(FX_NORM_COEFF=1500.0), EXTRA=SimpleNamespace(FOCAL_LENGTH=5000.0),
+                           TRAIN=SimpleNamespace(LR=1e-4, WEIGHT_DECAY=1e-4))
+
+
+@contextlib.contextmanager
+def explicit_noise(stack: torch.Tensor):
+    """Feed th.randn / th.randn_like from ``stack`` rows in call order (gaussian_diffusion.py:478,331,547)."""
+    it = iter(stack)
+    o_randn, o_like = torch.randn, torch.randn_like
+    torch.randn = lambda *a, **k: next(it).clone()
+    torch.randn_like = lambda x, **k: next(it).clone()
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+
+
+def to_torch_batch(b):
+    out = {}
+    for k, v in b.items():
+        out[k] = to_torch_batch(v) if isinstance(v, dict) else torch.from_numpy(np.asarray(v))
+    return out
+
+
+def build_reference_model(sd_np, asset, mean, std, diffuse_fuse=True):
+    from models.egohmr.egohmr import EgoHMR
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data"))
+    np.savez(os.path.join(tmp, "data", "smpl_mean_params.npz"), shape=np.zeros(10, np.float32))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        model = EgoHMR(cfg=ref_cfg(), device="cpu", body_rep_mean=torch.from_numpy(mean), body_rep_std=torch.from_numpy(std),
+                       with_focal_length=True, with_bbox_info=True, with_cam_center=True, scene_feat_dim=512,
+                       scene_type="cube", scene_cano=True, cond_mask_prob=0.0, only_mask_img_cond=True,
+                       pelvis_vis_loosen=True, diffuse_fuse=diffuse_fuse)
+    finally:
+        os.chdir(cwd)
+    ref_keys = {k: tuple(v.shape) for k, v in model.state_dict().items()
+                if not k.startswith(("smpl.", "smpl_male.", "smpl_female."))}
+    mine = {k: tuple(v.shape) for k, v in sd_np.items()}
+    assert ref_keys == mine, (sorted(set(ref_keys) ^ set(mine))[:10], [k for k in ref_keys if k in mine and ref_keys[k] != mine[k]][:10])
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=False)
+    assert not unexpected and all(k.startswith("smpl") for k in missing), (missing, unexpected)
+    model.eval()
+    return model
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------- goldens
+
+def g1_schedules():
+    from diffusion.model_util import create_gaussian_diffusion
+    arrs = {}
+    for n, rs in [(50, ""), (50, "ddim5"), (50, "ddim10"), (100, ""), (100, "ddim10"), (100, "ddim50"),
+                  (1000, ""), (1000, "ddim10"), (1000, "ddim50")]:
+        d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+        tag = f"n{n}_{rs or 'ddpm'}"
+        for f in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            arrs[f"{tag}__{f}"] = getattr(d, f)
+        arrs[f"{tag}__timestep_map"] = np.array(d.timestep_map, dtype=np.int64)
+    save("g1_schedules", **arrs)
+
+
+def g2_g3_geometry():
+    from utils.geometry import aa_to_rotmat, rot6d_to_rotmat, rotmat_to_rot6d
+    from utils.konia_transform import rotation_matrix_to_angle_axis
+    g = np.random.Generator(np.random.PCG64(11))
+    x = g.normal(size=(4096, 6)).astype(np.float32)
+    x[:64, 1::2] = x[:64, 0::2] * 1.5 + g.normal(scale=1e-4, size=(64, 3)).astype(np.float32)   # a1 ~ parallel a2
+    x[64:128, 0::2] *= 1e-6                                                                         # |a1| -> 0
+    x[128:160] = 0.0                                                                                # fully degenerate
+    xt = torch.from_numpy(x)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        R_diff = rot6d_to_rotmat(xt, "diffusion").numpy()
+        R_pro = rot6d_to_rotmat(xt, "prohmr").numpy()
+    r6 = rotmat_to_rot6d(torch.from_numpy(R_diff), "diffusion").numpy()
+    aa = g.normal(size=(1024, 3)).astype(np.float32)
+    aa[:32] *= 1e-5
+    aa[32:64] = aa[32:64] / np.linalg.norm(aa[32:64], axis=1, keepdims=True) * (np.pi - 1e-4)
+    R_aa = aa_to_rotmat(torch.from_numpy(aa)).numpy()
+    save("g2_rot6d", x=x, R_diffusion=R_diff, R_prohmr=R_pro, rot6d_back=r6, aa=aa, R_from_aa=R_aa)
+    # G3: rotmat -> axis-angle on valid rotations (incl. theta -> 0, theta -> pi, trace <= 0 branches)
+    Rv = np.concatenate([R_aa, R_diff[160:1184]], axis=0)
+    aa_back = rotation_matrix_to_angle_axis(torch.from_numpy(Rv)).numpy()
+    save("g3_rotmat_to_aa", R=Rv, aa=aa_back)
+
+
+def g4_gcn():
+    from models.egohmr.modulated_gcn.modulated_gcn import ModulatedGCN
+    from models.egohmr.modulated_gcn.modulated_gcn_conv import ModulatedGraphConv
+    from oracle.model import smpl_adjacency
+    adj = smpl_adjacency()
+    man = [(n.replace("diffusion_model.", ""), s) for n, s in syn.egohmr_manifest(hid_dim=64, num_blocks=1, with_backbone=False)
+           if n.startswith("diffusion_model.")]
+    man = [(n, (2, 32, s[2]) if n == "gconv_input.0.gconv.W" else s) for n, s in man]
+    sd = syn.make_state_dict(seed=4, manifest=man)
+    net = ModulatedGCN(adj=adj, in_dim=32, out_dim=6, hid_dim=64, num_layers=1, p_dropout=0.0)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net.eval()
+    g = np.random.Generator(np.random.PCG64(12))
+    x = g.normal(size=(3, 24, 32)).astype(np.float32)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x)).numpy()
+    arrs = {"w__" + k: v for k, v in sd.items()}
+    save("g4_gcn_tiny", x=x, y=y, adj=adj.numpy(), **arrs)
+    # one full-width hidden conv [8*24,1024] -> 1024, weights from seed (not stored)
+    man = [("gconv.W", (2, 1024, 1024)), ("gconv.M", (24, 1024)), ("gconv.adj2", (24, 24)), ("gconv.bias", (1024,))]
+    sd = syn.make_state_dict(seed=5, manifest=man)
+    conv = ModulatedGraphConv(1024, 1024, adj)
+    conv.load_state_dict({k.replace("gconv.", ""): torch.from_numpy(v) for k, v in sd.items()})
+    x = g.normal(size=(8, 24, 1024)).astype(np.float32)
+    with torch.no_grad():
+        y = conv(torch.from_numpy(x)).numpy()
+    save("g4_gconv_1024", x=x, y=y, weight_seed=5)
+
+
+def g5_g6_small_modules(model, sd):
+    t = torch.tensor([0, 1, 10, 49, 99, 999])
+    with torch.no_grad():
+        e = model.embed_timestep(t).squeeze(0).numpy()
+    save("g5_timestep_embed", t=t.numpy(), emb=e, weight_seed=0)
+    g = np.random.Generator(np.random.PCG64(13))
+    p = g.uniform(-1, 1, size=(2, 257, 3)).astype(np.float32)
+    with torch.no_grad():
+        c = model.scene_enc(torch.from_numpy(p)).numpy()
+    save("g6_pointnet", pts=p, feat=c, weight_seed=0)
+    img = g.normal(size=(2, 3, 224, 224)).astype(np.float32)
+    with torch.no_grad():
+        f = model.backbone(torch.from_numpy(img)).numpy()
+    save("g6_resnet50", img_seed=13, feat=f, weight_seed=0)
+    return img
+
+
+def g7_single_steps():
+    from diffusion.model_util import create_gaussian_diffusion
+
+    class Dummy:
+        def __init__(self, x0):
+            self.x0 = x0
+
+        def __call__(self, batch, t):
+            self.t_seen = t.clone()
+            return {"pred_x_start": self.x0}
+
+    g = np.random.Generator(np.random.PCG64(14))
+    arrs = {}
+    for n, rs, idx in [(50, "", 49), (50, "", 7), (50, "", 0), (100, "ddim10", 9), (100, "ddim10", 3), (100, "ddim10", 0)]:
+        d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+        x = torch.from_numpy(g.normal(size=(3, 144)).astype(np.float32))
+        x0 = torch.from_numpy(g.normal(size=(3, 144)).astype(np.float32))
+        eps = torch.from_numpy(g.normal(size=(1, 3, 144)).astype(np.float32))
+        t = torch.tensor([idx] * 3)
+        m = Dummy(x0)
+        with explicit_noise(eps):
+            o = (d.ddim_sample if rs else d.p_sample)(m, {}, x, t, clip_denoised=False)
+        tag = f"n{n}_{rs or 'ddpm'}_i{idx}"
+        arrs.update({f"{tag}__x": x.numpy(), f"{tag}__x0": x0.numpy(), f"{tag}__eps": eps[0].numpy(),
+                     f"{tag}__sample": o["sample"].numpy(), f"{tag}__t_model": m.t_seen.numpy()})
+    save("g7_single_steps", **arrs)
+
+
+def _pack_out(o, prefix=""):
+    return {
+        prefix + "pred_x_start": o["pred_x_start"].numpy(),
+        prefix + "betas": o["pred_smpl_params"]["betas"].numpy(),
+        prefix + "global_orient": o["pred_smpl_params"]["global_orient"].numpy(),
+        prefix + "body_pose": o["pred_smpl_params"]["body_pose"].numpy(),
+        prefix + "pred_pose_6d": o["pred_pose_6d"].numpy(),
+        prefix + "verts_head": o["pred_vertices"][:, :64].numpy(),
+        prefix + "verts_sum": o["pred_vertices"].double().sum(dim=1).numpy(),
+        prefix + "joints": o["pred_keypoints_3d"].numpy(),
+        prefix + "joints_full": o["pred_keypoints_3d_full"].numpy(),
+        prefix + "kp2d_full": o["pred_keypoints_2d_full"].numpy(),
+    }
+
+
+def g10_forward(model_fuse, model_nofuse):
+    B = 3
+    b = syn.make_batch(B, num_scene_points=512, seed=21)
+    b["orig_keypoints_2d"][0, :, 2] = 1.0          # all visible
+    b["orig_keypoints_2d"][1, :, 2] = 0.0          # none visible (pelvis forced, egohmr.py:187)
+    x_t = syn.make_noise_stack(0, B, seed=21)[0]
+    arrs = {"x_t": x_t, "t": np.array([37, 37, 37])}
+    for tag, m in (("fuse__", model_fuse), ("nofuse__", model_nofuse)):
+        tb = to_torch_batch(b)
+        tb["x_t"] = torch.from_numpy(x_t)
+        with torch.no_grad():
+            o = m(tb, torch.tensor([37] * B))
+        arrs.update(_pack_out(o, tag))
+        arrs[tag + "vis_mask_smpl"] = tb["vis_mask_smpl"].numpy()
+    save("g10_forward", batch_seed=21, num_scene_points=512, **arrs)
+
+
+def g8_g9_end_to_end(model):
+    from diffusion.model_util import create_gaussian_diffusion
+    # G8: BASELINE config 1 - B=4, DDIM-5 of 50, N=4096
+    for name, n, rs, B, N, guided, w in [("g8_e2e_ddim5", 50, "ddim5", 4, 4096, False, 0.0),
+                                         ("g9_e2e_ddpm50", 50, "", 2, 1024, False, 0.0),
+                                         ("g9_e2e_ddpm50_guided", 50, "", 2, 1024, True, 2.0)]:
+        d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+        b = to_torch_batch(syn.make_batch(B, num_scene_points=N, seed=31))
+        if guided:  # put the scene floor through the body so the proxy has something to push against
+            b["scene_pcd_verts_full"][:, : N // 3, 1] = b["smpl_params"]["transl"][:, None, 1] - 0.6
+        T = d.num_timesteps
+        noise = torch.from_numpy(syn.make_noise_stack(T, B, seed=31))
+        xs = []
+        orig = d.p_mean_variance
+
+        def spy(mm, bb, x, t, **kw):
+            xs.append(x.clone().numpy())
+            return orig(mm, bb, x, t, **kw)
+
+        d.p_mean_variance = spy
+        with explicit_noise(noise), torch.no_grad():
+            o = d.val_losses(model=model, batch=b, shape=[B, 144], progress=False, clip_denoised=False, cur_epoch=0,
+                             timestep_respacing=rs, cond_fn_with_grad=guided, cond_grad_weight=w, compute_loss=False)
+        save(name, batch_seed=31, noise_seed=31, B=B, N=N, n=n, respacing=rs, guided=guided, cond_grad_weight=w,
+             x_t_trace=np.stack(xs), **_pack_out(o))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    asset = syn.make_smpl_asset(0)
+    install_shims(asset)
+    print("reference-driven goldens ->", OUT)
+    g1_schedules()
+    g2_g3_geometry()
+    g4_gcn()
+    g7_single_steps()
+    sd = syn.make_state_dict(0)
+    mean, std = syn.make_body_rep_stats(0)
+    model = build_reference_model(sd, asset, mean, std, diffuse_fuse=True)
+    model_nofuse = build_reference_model(sd, asset, mean, std, diffuse_fuse=False)
+    g5_g6_small_modules(model, sd)
+    g10_forward(model, model_nofuse)
+    g8_g9_end_to_end(model)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def synth_weights():
+    from egohmr_amd import synthetic as syn
+    return syn.make_state_dict(0)
+
+
+@pytest.fixture(scope="session")
+def smpl_asset():
+    from egohmr_amd import synthetic as syn
+    return syn.make_smpl_asset(0)

@@ -1,0 +1,166 @@
+"""CPU: the oracle restatement against golden vectors produced by the reference itself
+(oracle/make_golden.py).  Pins schedule, geometry, GCN, embedders, encoders, single sampler steps,
+EgoHMR.forward and the end-to-end DDIM/DDPM loops (guided plumbing included)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egohmr_amd import synthetic as syn
+from oracle import geometry as geo
+from oracle import model as om
+from oracle import sampler, schedule
+from oracle.collision import proxy_collision_loss
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _tt(b):
+    return {k: (_tt(v) if isinstance(v, dict) else torch.from_numpy(np.asarray(v))) for k, v in b.items()}
+
+
+@pytest.mark.parametrize("n,rs", [(50, ""), (50, "ddim5"), (50, "ddim10"), (100, ""), (100, "ddim10"), (100, "ddim50"),
+                                  (1000, ""), (1000, "ddim10"), (1000, "ddim50")])
+def test_g1_schedule_tables(golden_dir, n, rs):
+    g = _load(golden_dir, "g1_schedules")
+    t = schedule.make_tables(n, rs)
+    tag = f"n{n}_{rs or 'ddpm'}"
+    for f in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+              "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_array_equal(getattr(t, f), g[f"{tag}__{f}"], err_msg=f)   # float64, bit-exact
+    assert t.timestep_map == list(g[f"{tag}__timestep_map"])
+
+
+def test_bad_respacing_raises():
+    with pytest.raises(ValueError):
+        schedule.make_tables(50, "ddim49")
+
+
+def test_g2_rot6d(golden_dir):
+    g = _load(golden_dir, "g2_rot6d")
+    x = torch.from_numpy(g["x"])
+    np.testing.assert_allclose(geo.rot6d_to_rotmat(x, "diffusion").numpy(), g["R_diffusion"], atol=2e-6)
+    np.testing.assert_allclose(geo.rot6d_to_rotmat(x, "prohmr").numpy(), g["R_prohmr"], atol=2e-6)
+    np.testing.assert_array_equal(geo.rotmat_to_rot6d(torch.from_numpy(g["R_diffusion"])).numpy(), g["rot6d_back"])
+    np.testing.assert_allclose(geo.aa_to_rotmat(torch.from_numpy(g["aa"])).numpy(), g["R_from_aa"], atol=1e-6)
+
+
+def test_g3_rotmat_to_angle_axis(golden_dir):
+    g = _load(golden_dir, "g3_rotmat_to_aa")
+    np.testing.assert_allclose(geo.rotation_matrix_to_angle_axis(torch.from_numpy(g["R"])).numpy(), g["aa"], atol=1e-5)
+
+
+def test_g4_gcn(golden_dir):
+    g = _load(golden_dir, "g4_gcn_tiny")
+    sd = {"diffusion_model." + k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w__")}
+    y = om.modulated_gcn(sd, torch.from_numpy(g["x"]), torch.from_numpy(g["adj"]), num_blocks=1)
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=1e-5)
+    np.testing.assert_allclose(om.smpl_adjacency().numpy(), g["adj"], atol=0)
+    g = _load(golden_dir, "g4_gconv_1024")
+    man = [("gconv.W", (2, 1024, 1024)), ("gconv.M", (24, 1024)), ("gconv.adj2", (24, 24)), ("gconv.bias", (1024,))]
+    sd = {k: torch.from_numpy(v) for k, v in syn.make_state_dict(seed=int(g["weight_seed"]), manifest=man).items()}
+    y = om.modulated_graph_conv(sd, "gconv", torch.from_numpy(g["x"]), om.smpl_adjacency())
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=2e-5)
+
+
+def test_g5_g6_embedders_encoders(golden_dir, synth_weights):
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth_weights.items()}
+    g = _load(golden_dir, "g5_timestep_embed")
+    np.testing.assert_allclose(om.timestep_embedding(sd, torch.from_numpy(g["t"])).numpy(), g["emb"], atol=1e-6)
+    g = _load(golden_dir, "g6_pointnet")
+    np.testing.assert_allclose(om.resnet_pointnet(sd, torch.from_numpy(g["pts"])).numpy(), g["feat"], atol=1e-5)
+    g = _load(golden_dir, "g6_resnet50")
+    rng = np.random.Generator(np.random.PCG64(int(g["img_seed"])))
+    rng.uniform(-1, 1, size=(2, 257, 3))          # same stream position as the generator script
+    img = rng.normal(size=(2, 3, 224, 224)).astype(np.float32)
+    np.testing.assert_allclose(om.resnet50(sd, torch.from_numpy(img)).numpy(), g["feat"], atol=2e-5)
+
+
+def test_g7_single_steps(golden_dir):
+    g = _load(golden_dir, "g7_single_steps")
+
+    class Dummy:
+        def __init__(self, x0):
+            self.x0 = x0
+
+        def validation_setup(self):
+            pass
+
+        def __call__(self, batch, t):
+            self.t = t
+            return {"pred_x_start": self.x0}
+
+    for n, rs, idx in [(50, "", 49), (50, "", 7), (50, "", 0), (100, "ddim10", 9), (100, "ddim10", 3), (100, "ddim10", 0)]:
+        tag = f"n{n}_{rs or 'ddpm'}_i{idx}"
+        full = schedule.make_tables(n, rs)
+        # run exactly one step: tables truncated so that the loop's single index is ``idx``
+        one = schedule.Tables(**{k: (v[idx:idx + 1] if isinstance(v, np.ndarray) else [v[idx]]) for k, v in full.__dict__.items()})
+        x, x0, eps = (torch.from_numpy(g[f"{tag}__{k}"]) for k in ("x", "x0", "eps"))
+        m = Dummy(x0)
+        noise = torch.stack([x, eps])
+        fn = sampler.ddim_sample_loop if rs else sampler.p_sample_loop
+        if idx == 0:
+            o = fn(m, {}, one, noise)
+        else:  # loop treats its last index as t == 0 -> emulate "not last" by a 2-entry table whose 2nd step we take
+            two = schedule.Tables(**{k: (np.concatenate([v[:1], v[idx:idx + 1]]) if isinstance(v, np.ndarray) else [v[0], v[idx]])
+                                     for k, v in full.__dict__.items()})
+            tr = []
+            fn(m, {}, two, torch.stack([x, eps, eps]), trace=tr)
+            o = {"sample": tr[0][0]}
+        np.testing.assert_allclose(o["sample"].numpy(), g[f"{tag}__sample"], atol=1e-6, err_msg=tag)
+
+
+def _model(synth_weights, smpl_asset, **kw):
+    mean, std = syn.make_body_rep_stats(0)
+    return om.EgoHMROracle(synth_weights, smpl_asset, mean, std, **kw)
+
+
+def _check_out(o, g, prefix="", atol=2e-5):
+    np.testing.assert_allclose(o["pred_x_start"].numpy(), g[prefix + "pred_x_start"], atol=atol)
+    np.testing.assert_allclose(o["pred_smpl_params"]["betas"].numpy(), g[prefix + "betas"], atol=atol)
+    np.testing.assert_allclose(o["pred_smpl_params"]["global_orient"].numpy(), g[prefix + "global_orient"], atol=atol)
+    np.testing.assert_allclose(o["pred_smpl_params"]["body_pose"].numpy(), g[prefix + "body_pose"], atol=atol)
+    np.testing.assert_allclose(o["pred_vertices"][:, :64].numpy(), g[prefix + "verts_head"], atol=atol)
+    np.testing.assert_allclose(o["pred_vertices"].double().sum(1).numpy(), g[prefix + "verts_sum"], atol=2e-2)
+    np.testing.assert_allclose(o["pred_keypoints_3d"].numpy(), g[prefix + "joints"], atol=atol)
+    np.testing.assert_allclose(o["pred_keypoints_3d_full"].numpy(), g[prefix + "joints_full"], atol=atol)
+    np.testing.assert_allclose(o["pred_keypoints_2d_full"].numpy(), g[prefix + "kp2d_full"], atol=atol)
+
+
+def test_g10_forward(golden_dir, synth_weights, smpl_asset):
+    g = _load(golden_dir, "g10_forward")
+    b = syn.make_batch(3, num_scene_points=int(g["num_scene_points"]), seed=int(g["batch_seed"]))
+    b["orig_keypoints_2d"][0, :, 2] = 1.0
+    b["orig_keypoints_2d"][1, :, 2] = 0.0
+    for tag, fuse in (("fuse__", True), ("nofuse__", False)):
+        m = _model(synth_weights, smpl_asset, diffuse_fuse=fuse)
+        tb = _tt(b)
+        tb["x_t"] = torch.from_numpy(g["x_t"])
+        o = m(tb, torch.from_numpy(g["t"]))
+        _check_out(o, g, tag)
+        np.testing.assert_array_equal(tb["vis_mask_smpl"].numpy(), g[tag + "vis_mask_smpl"])
+
+
+@pytest.mark.parametrize("name", ["g8_e2e_ddim5", "g9_e2e_ddpm50", "g9_e2e_ddpm50_guided"])
+@pytest.mark.parametrize("faithful", [True, False])
+def test_g8_g9_end_to_end(golden_dir, synth_weights, smpl_asset, name, faithful):
+    if faithful and name != "g8_e2e_ddim5":
+        pytest.skip("reference-faithful mode (encoders every step) checked on the short loop only")
+    g = _load(golden_dir, name)
+    B, N, n, rs = int(g["B"]), int(g["N"]), int(g["n"]), str(g["respacing"])
+    guided = bool(g["guided"])
+    b = _tt(syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"])))
+    if guided:
+        b["scene_pcd_verts_full"][:, : N // 3, 1] = b["smpl_params"]["transl"][:, None, 1] - 0.6
+    tab = schedule.make_tables(n, rs)
+    noise = torch.from_numpy(syn.make_noise_stack(tab.num_timesteps, B, seed=int(g["noise_seed"])))
+    m = _model(synth_weights, smpl_asset, faithful=faithful, collision_loss=proxy_collision_loss)
+    tr = []
+    o = sampler.val_losses(m, b, tab, noise, rs, cond_fn_with_grad=guided, cond_grad_weight=float(g["cond_grad_weight"]), trace=tr)
+    xs = np.stack([noise[0].numpy()] + [t[0].numpy() for t in tr[:-1]])
+    np.testing.assert_allclose(xs, g["x_t_trace"], atol=2e-5)
+    _check_out(o, g)

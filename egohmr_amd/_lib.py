@@ -1,0 +1,150 @@
+"""ctypes binding of libegohmr_hip.so (C ABI: include/egohmr_hip.h).
+
+The library is the product: there is no eager / CPU fallback.  If it is missing or cannot be
+loaded this module raises - loudly - at first use.
+
+``import torch`` happens before the dlopen on purpose: PyTorch-ROCm ships its own
+``libamdhip64.so`` (SONAME libamdhip64.so.7, same as /opt/rocm's) and the dynamic loader then
+binds our library to that already-loaded runtime, so device pointers / streams handed over
+from torch tensors are valid inside the kernels' launches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+SOURCES = ["gcn.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+
+
+class EgoHMRHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+           *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise EgoHMRHipError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+class GConvParams(C.Structure):
+    """ehm_gconv_params"""
+    _fields_ = [("W", C.c_void_p), ("M", C.c_void_p), ("adj2", C.c_void_p), ("bias", C.c_void_p),
+                ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p),
+                ("in_dim", C.c_int), ("out_dim", C.c_int)]
+
+
+class StepCoefs(C.Structure):
+    """ehm_step_coefs"""
+    _fields_ = [(n, C.c_float) for n in ("coef1", "coef2", "log_variance", "variance", "sqrt_recip_ac", "sqrt_recipm1_ac",
+                                         "sqrt_ac_prev", "dir_coef", "sigma", "nonzero", "grad_scale")]
+
+
+class SampleDesc(C.Structure):
+    """ehm_sample_desc"""
+    _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/egohmr_hip.h declares
+PROTOTYPES = {
+    "ehm_last_error": (C.c_char_p, []),
+    "ehm_target_arch": (C.c_char_p, []),
+    "ehm_rot6d_to_rotmat": (_I, [_P, _P, _L, _I, _P]),
+    "ehm_rot6d_to_rotmat_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
+    "ehm_smpl_create": (_I, [C.POINTER(_P), _P, _P, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P]),
+    "ehm_smpl_destroy": (None, [_P]),
+    "ehm_smpl_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "ehm_smpl_forward_rot6d": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "ehm_gcn_create": (_I, [C.POINTER(_P), _P, C.POINTER(GConvParams), C.POINTER(GConvParams), _I, C.POINTER(GConvParams), _I, _P]),
+    "ehm_gcn_destroy": (None, [_P]),
+    "ehm_gcn_row_tile": (_I, []),
+    "ehm_gcn_input_layer": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "ehm_gcn_hidden_layer": (_I, [_P, _I, _P, _P, _P, _L, _P]),
+    "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "ehm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _P]),
+    "ehm_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P]),
+    "ehm_collision_proxy": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ehm_smpl_backward_rot6d": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "ehm_guidance_grad_finish": (_I, [_P, _P, _P, _I, _F, _P]),
+    "ehm_sample_workspace_bytes": (_L, [C.POINTER(SampleDesc), _I, _I]),
+    "ehm_sample_loop": (_I, [_P, _P, C.POINTER(SampleDesc), C.POINTER(StepCoefs)] + [_P] * 18 + [_L, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Raises EgoHMRHipError when it is absent - never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EgoHMRHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  egohmr_amd has no CPU/eager fallback.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise EgoHMRHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise EgoHMRHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        if handle.ehm_target_arch() != b"gfx950":
+            raise EgoHMRHipError("libegohmr_hip.so was not built for gfx950")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ehm_last_error()
+        raise EgoHMRHipError(f"{what or 'libegohmr_hip'} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous float32/uint8 CUDA(HIP) tensor (0 for None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EgoHMRHipError("egohmr_amd kernels need tensors on a HIP device (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise EgoHMRHipError("tensor handed to the C ABI must be contiguous")
+    return t.data_ptr()
+
+
+def f32(t, device=None):
+    """contiguous float32 view/copy on the device."""
+    t = t.detach()
+    if device is not None and t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

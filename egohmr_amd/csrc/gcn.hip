@@ -1,0 +1,493 @@
+// Modulated-GCN denoiser for gfx950 (MI355X): the per-step part of
+//   ModulatedGCN.forward           models/egohmr/modulated_gcn/modulated_gcn.py:99-116
+//   _GraphConv / _ResGraphConv     modulated_gcn.py:21-28, :38-42
+//   ModulatedGraphConv.forward     models/egohmr/modulated_gcn/modulated_gcn_conv.py:39-50
+// of the reference, as called from EgoHMR.forward (models/egohmr/egohmr.py:236-254).
+//
+// Design (not a translation - the reference is ~12 eager torch ops per conv):
+//   * one kernel per hid->hid conv: f32 MFMA GEMM  [rows,K] x [K, W0|W1]  with the whole
+//     "M (.) h -> 24x24 adjacency mix -> +bias -> BatchNorm(eval) -> ReLU -> (+residual)" epilogue done
+//     IN REGISTERS.  The MFMA row->body/joint map is chosen so that after the K loop every lane owns
+//     all 24 joints of two bodies for one output channel (v_mfma_f32_32x32x2_f32 C layout:
+//     col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); the adjacency mix is then 24x24
+//     scalar-broadcast FMAs per body with no LDS / cross-lane traffic.
+//   * weights are re-packed once ([n_tile][W0 cols | W1 cols][K], K contiguous) so both MFMA operands
+//     are "row = m or n, contiguous k" and stream through LDS with 16-byte global_load_lds DMA,
+//     double buffered, one barrier per 32-wide K tile; LDS images are XOR-swizzled on the SOURCE
+//     address so the ds_read_b128 fragment reads are bank-conflict free.
+//   * BatchNorm is folded into per-channel scale/shift, the adjacency is symmetrised once.
+#include "common.h"
+#include "egohmr_hip.h"
+
+namespace {
+
+constexpr int BM = 192;   // rows per block = 8 bodies x 24 joints
+constexpr int BNH = 64;   // output channels per block (x2: W0 and W1 branch)
+constexpr int BK = 32;    // K tile (128 B per row)
+constexpr int A_TILE = BM * BK;        // floats
+constexpr int B_TILE = 2 * BNH * BK;   // floats
+constexpr int STAGE = A_TILE + B_TILE; // 10240 floats = 40 KiB
+
+struct LayerDev {
+  float* Wp;     // [N/64][128][K]   packed W0|W1 columns, K contiguous
+  float* D;      // [24][N]  A[j][j] * M[j][n] * scale[n]
+  float* M1;     // [24][N]  M[j][n] * scale[n]
+  float* shift;  // [N]      (bias - mean) * scale + beta      (bias when no BN)
+  float* Aoff;   // [24][24] symmetrised adjacency, zero diagonal
+  int K, N;
+  int relu;
+};
+
+struct OutDev {
+  float* Wt;    // [12][K]  rows 0-5: W0 columns, rows 6-11: W1 columns
+  float* M;     // [24][6]
+  float* A;     // [24][24] symmetrised adjacency (diagonal kept)
+  float* bias;  // [6]
+  int K;
+};
+
+// ------------------------------------------------------------------------------------------------
+// parameter packing (runs once per model)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_w_kernel(const float* __restrict__ W, float* __restrict__ Wp, int K, int N) {
+  // W [2][K][N] -> Wp[nt][u*64 + c][k] = W[u][k][nt*64 + c]; 32x32 LDS transpose tiles
+  __shared__ float tile[32][33];
+  int u = blockIdx.z;
+  int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int r = ty; r < 32; r += 8) {
+    int k = k0 + r, n = n0 + tx;
+    tile[r][tx] = (k < K && n < N) ? W[((size_t)u * K + k) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int n = n0 + r, k = k0 + tx;
+    if (n < N && k < K) {
+      int nt = n >> 6, c = n & 63;
+      Wp[((size_t)nt * 128 + u * 64 + c) * K + k] = tile[tx][r];
+    }
+  }
+}
+
+__global__ void pack_epilogue_kernel(const float* __restrict__ adj, ehm_gconv_params p, float* D, float* M1, float* shift,
+                                     float* Aoff) {
+  int N = p.out_dim;
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < kJ * kJ) {
+    int i = threadIdx.x / kJ, j = threadIdx.x % kJ;
+    float aij = adj[i * kJ + j] + p.adj2[i * kJ + j];
+    float aji = adj[j * kJ + i] + p.adj2[j * kJ + i];
+    Aoff[i * kJ + j] = (i == j) ? 0.f : (aji + aij) / 2;   // (adj.T + adj)/2, modulated_gcn_conv.py:44
+  }
+  if (n >= N) return;
+  float scale = 1.f, sh = p.bias ? p.bias[n] : 0.f;
+  if (p.bn_weight) {
+    scale = p.bn_weight[n] / sqrtf(p.bn_var[n] + 1e-5f);   // BatchNorm1d eval, eps = 1e-5
+    sh = (sh - p.bn_mean[n]) * scale + p.bn_bias[n];
+  }
+  shift[n] = sh;
+  for (int j = 0; j < kJ; ++j) {
+    const float ajj = adj[j * kJ + j] + p.adj2[j * kJ + j];   // diagonal of (A.T + A)/2
+    float m = p.M[j * N + n];
+    D[j * N + n] = ajj * m * scale;
+    M1[j * N + n] = m * scale;
+  }
+}
+
+__global__ void pack_out_kernel(const float* __restrict__ adj, ehm_gconv_params p, float* Wt, float* M, float* A, float* bias) {
+  int K = p.in_dim;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 12 * K) {
+    int r = t / K, k = t % K;
+    int u = r / 6, c = r % 6;
+    Wt[t] = p.W[((size_t)u * K + k) * 6 + c];
+  }
+  if (t < kJ * kJ) {
+    int i = t / kJ, j = t % kJ;
+    A[t] = ((adj[j * kJ + i] + p.adj2[j * kJ + i]) + (adj[i * kJ + j] + p.adj2[i * kJ + j])) / 2;
+  }
+  if (t < kJ * 6) M[t] = p.M[t];
+  if (t < 6) bias[t] = p.bias ? p.bias[t] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared epilogue: one lane = one output channel n of one body; h0/h1 = the 24 joints' W0/W1 responses
+// ------------------------------------------------------------------------------------------------
+// d0[j] = D[j][n]*h0[j] + shift[n] (diagonal branch, bias and BatchNorm folded), g1[j] = M1[j][n]*h1[j];
+// res[j] = residual input (already loaded, zeros when unused).
+__device__ __forceinline__ void gcn_mix_store(const float (&d0)[kJ], const float (&g1)[kJ], const float (&res)[kJ], int n, int N,
+                                              size_t row0, const float* __restrict__ Aoff, float* __restrict__ Y, bool relu) {
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) {
+    float s = d0[j];
+#pragma unroll
+    for (int jp = 0; jp < kJ; ++jp) s = fmaf(Aoff[j * kJ + jp], g1[jp], s);  // Aoff: wave-uniform -> scalar loads
+    if (relu) s = fmaxf(s, 0.f);
+    Y[(row0 + j) * (size_t)N + n] = s + res[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hid -> hid conv: f32 MFMA GEMM + in-register epilogue
+// ------------------------------------------------------------------------------------------------
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+template <bool RES>
+__global__ __launch_bounds__(256, 2) void gcn_hidden_kernel(const float* __restrict__ X, LayerDev L,
+                                                             const float* __restrict__ Res, float* __restrict__ Y,
+                                                             int m_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];  // 80 KiB: 2 blocks per CU
+
+  const int K = L.K, N = L.N;
+  const int n_tiles = N / BNH;
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of (m_tile, all n_tiles)
+  int bid = blockIdx.x;
+  const int total = m_tiles * n_tiles;
+  int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
+  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
+  const size_t m0 = (size_t)m_tile * BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- global -> LDS DMA addressing (global_load_lds: LDS dest = wave-uniform base + lane*16 B) ----
+  // a wave instruction fills 8 rows x 128 B; physical (row r, chunk c) holds logical chunk c ^ ((r>>1)&7)
+  const int ld_r = lane >> 3, ld_c = lane & 7;
+  const float* gA[6];
+  const float* gB[4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int r = 8 * (wave + 4 * i) + ld_r;
+    gA[i] = X + (m0 + r) * K + ((ld_c ^ ((r >> 1) & 7)) << 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = 8 * (wave + 4 * i) + ld_r;
+    gB[i] = L.Wp + ((size_t)n_tile * 128 + r) * K + ((ld_c ^ ((r >> 1) & 7)) << 2);
+  }
+  auto stage = [&](int buf, int kt) {
+    float* base = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(gA[i] + kt * BK), (AS3 void*)(base + (wave + 4 * i) * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(gB[i] + kt * BK),
+                                       (AS3 void*)(base + A_TILE + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+
+  // ---- MFMA fragment addressing ----
+  // MFMA row i of row-tile t  <->  LDS row 48*((i>>2)&1) + 16t + (i&3) + 4*(i>>3)  (+96*wm)
+  // => lane half h = lane>>5 ends up with accumulator index q = 16t + reg  <->  body 2h + q/24, joint q%24
+  const int mi = lane & 31, h = lane >> 5;
+  const int rA = 96 * wm + 48 * ((mi >> 2) & 1) + (mi & 3) + 4 * (mi >> 3);
+  const int rB = 32 * wn + mi;
+  const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
+
+  f32x16 acc0[3], acc1[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[t][r] = 0.f; acc1[t][r] = 0.f; }
+  }
+
+  const int KT = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt landed for every wave; everyone is done reading the other buffer
+    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
+    const float* As = lds + (kt & 1) * STAGE;
+    const float* Bs = As + A_TILE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cA = ((2 * kk + h) ^ keyA) << 2, cB = ((2 * kk + h) ^ keyB) << 2;
+      f32x4 a[3], b[2];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) a[t] = *(const f32x4*)(As + (rA + 16 * t) * BK + cA);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) b[u] = *(const f32x4*)(Bs + (rB + 64 * u) * BK + cB);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          acc0[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[0][s], acc0[t], 0, 0, 0);
+          acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[1][s], acc1[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane = channel n, two bodies (beta = 0,1) of 24 joints each in registers ----
+  // Hand-staged so the register allocator never sees more than acc (96) + two 24-wide load batches:
+  // sched_barrier keeps hipcc from hoisting all ~100 global loads to the top and spilling the accumulators.
+  const int n = n_tile * BNH + 32 * wn + mi;
+  const size_t rowb = m0 + 96 * wm + 48 * h;
+  float res0[kJ], res1[kJ];
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) res0[j] = RES ? Res[(rowb + j) * (size_t)N + n] : 0.f;
+  {
+    float dj[kJ], mj[kJ];
+    const float sh = L.shift[n];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) { dj[j] = L.D[j * N + n]; mj[j] = L.M1[j * N + n]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {   // fold modulation / BatchNorm scale into the accumulators in place
+#pragma unroll
+      for (int beta = 0; beta < 2; ++beta) {
+        const int q = 24 * beta + j;
+        acc0[q >> 4][q & 15] = fmaf(dj[j], acc0[q >> 4][q & 15], sh);
+        acc1[q >> 4][q & 15] *= mj[j];
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) res1[j] = RES ? Res[(rowb + 24 + j) * (size_t)N + n] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float d0[kJ], g1[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) { d0[j] = acc0[j >> 4][j & 15]; g1[j] = acc1[j >> 4][j & 15]; }
+    gcn_mix_store(d0, g1, res0, n, N, rowb, L.Aoff, Y, L.relu != 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float d0[kJ], g1[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) { d0[j] = acc0[(24 + j) >> 4][(24 + j) & 15]; g1[j] = acc1[(24 + j) >> 4][(24 + j) & 15]; }
+    gcn_mix_store(d0, g1, res1, n, N, rowb + 24, L.Aoff, Y, L.relu != 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// input conv with the step-invariant projections hoisted (see ehm_gcn_input_layer in the header)
+// one wave = one virtual body x 64 channels; 4 waves per block = 4 channel groups
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict__ h_img, const float* __restrict__ h_oth,
+                                                        const uint8_t* __restrict__ vis, const float* __restrict__ x,
+                                                        const float* __restrict__ Wx, const float* __restrict__ tvec,
+                                                        LayerDev L, float* __restrict__ Y, int B, int passes) {
+  const int N = L.N;
+  const int vb = blockIdx.x;           // virtual body = p*B + b
+  const int p = vb / B, b = vb % B;
+  const int n = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+  if (n >= N) return;
+  float base[2], img[2], wx[2][6];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    base[k] = h_oth[((size_t)b * 2 + k) * N + n] + tvec[k * N + n];
+    img[k] = (p == 0) ? h_img[((size_t)b * 2 + k) * N + n] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) wx[k][c] = Wx[(k * 6 + c) * N + n];
+  }
+  const float* xb = x + (size_t)b * kPoseDim;   // wave-uniform -> scalar loads
+  const uint8_t* vb_ = vis + (size_t)b * kJ;
+  float h0[kJ], h1[kJ];
+  const float sh = L.shift[n];
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) {
+    const float v = vb_[j] ? 1.f : 0.f;
+    float s0 = fmaf(v, img[0], base[0]), s1 = fmaf(v, img[1], base[1]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float xv = xb[j * 6 + c];
+      s0 = fmaf(xv, wx[0][c], s0);
+      s1 = fmaf(xv, wx[1][c], s1);
+    }
+    h0[j] = fmaf(L.D[j * N + n], s0, sh);
+    h1[j] = L.M1[j * N + n] * s1;
+  }
+  float zero[kJ];
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) zero[j] = 0.f;
+  gcn_mix_store(h0, h1, zero, n, N, (size_t)vb * kJ, L.Aoff, Y, L.relu != 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// output conv (hid -> 6) + visibility fuse.  One block per body: 24 x passes rows of K floats.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gcn_output_kernel(const float* __restrict__ X, OutDev O,
+                                                         const uint8_t* __restrict__ vis, float* __restrict__ x0,
+                                                         int B, int passes) {
+  __shared__ float hs[2][kJ][12];   // [pass][joint][W0 c0..5 | W1 c0..5]
+  __shared__ float outs[2][kJ][6];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = O.K;
+  const int nrows = kJ * passes;
+  for (int r = wave; r < nrows; r += 4) {
+    const int p = r / kJ, j = r % kJ;
+    const float* xr = X + ((size_t)(p * B + b) * kJ + j) * K;
+    float acc[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) acc[c] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 xv = *(const f32x4*)(xr + k);
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        const f32x4 wv = *(const f32x4*)(O.Wt + (size_t)c * K + k);
+        acc[c] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[c]))));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      float v = acc[c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) hs[p][j][c] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < passes * kJ * 6; e += 256) {
+    const int p = e / (kJ * 6), j = (e / 6) % kJ, c = e % 6;
+    // modulated_gcn_conv.py:47: (adj*E) @ (M*h0) + (adj*(1-E)) @ (M*h1) + bias
+    float s = O.A[j * kJ + j] * (O.M[j * 6 + c] * hs[p][j][c]);
+    float t = 0.f;
+    for (int jp = 0; jp < kJ; ++jp)
+      if (jp != j) t = fmaf(O.A[j * kJ + jp], O.M[jp * 6 + c] * hs[p][jp][6 + c], t);
+    outs[p][j][c] = s + t + O.bias[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < kPoseDim) {
+    const int j = threadIdx.x / 6, c = threadIdx.x % 6;
+    float v = outs[0][j][c];
+    if (passes == 2 && !vis[(size_t)b * kJ + j]) v = outs[1][j][c];   // egohmr.py:249-254
+    x0[(size_t)b * kPoseDim + threadIdx.x] = v;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+struct ehm_gcn {
+  int hid = 0;
+  int num_hidden = 0;
+  LayerDev input{};
+  LayerDev hidden[16]{};
+  OutDev out{};
+  float* arena = nullptr;
+};
+
+static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, float*& cursor, bool with_w, hipStream_t st) {
+  const int N = p.out_dim, K = p.in_dim;
+  L.K = K;
+  L.N = N;
+  L.relu = p.bn_weight != nullptr;
+  if (with_w) {
+    L.Wp = cursor;
+    cursor += (size_t)2 * K * N;
+  }
+  L.D = cursor;      cursor += (size_t)kJ * N;
+  L.M1 = cursor;     cursor += (size_t)kJ * N;
+  L.shift = cursor;  cursor += N;
+  L.Aoff = cursor;   cursor += kJ * kJ;
+  if (with_w) {
+    dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(K, 32), 2);
+    hipLaunchKernelGGL(pack_w_kernel, grid, dim3(256), 0, st, p.W, L.Wp, K, N);
+  }
+  const int threads = 1024;  // block 0 also fills the 24x24 adjacency (576 <= 1024 threads)
+  hipLaunchKernelGGL(pack_epilogue_kernel, dim3((unsigned)ceil_div(N, threads)), dim3(threads), 0, st, adj, p, L.D, L.M1,
+                     L.shift, L.Aoff);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_row_tile(void) { return BM; }
+
+extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_params* input_conv,
+                              const ehm_gconv_params* hidden, int num_hidden, const ehm_gconv_params* output_conv,
+                              int hid_dim, void* stream) {
+  EHM_CHECK_ARG(out && adj && input_conv && hidden && output_conv);
+  EHM_CHECK_ARG(num_hidden >= 0 && num_hidden <= 16);
+  EHM_CHECK_ARG(hid_dim > 0 && hid_dim % 64 == 0 && hid_dim % BK == 0);
+  EHM_CHECK_ARG(input_conv->out_dim == hid_dim && output_conv->in_dim == hid_dim && output_conv->out_dim == 6);
+  for (int i = 0; i < num_hidden; ++i) EHM_CHECK_ARG(hidden[i].in_dim == hid_dim && hidden[i].out_dim == hid_dim && hidden[i].W);
+  hipStream_t st = (hipStream_t)stream;
+  auto* g = new ehm_gcn();
+  g->hid = hid_dim;
+  g->num_hidden = num_hidden;
+  const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ;
+  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * 2 * hid_dim * hid_dim + 12 * (size_t)hid_dim + kJ * 6 +
+                  kJ * kJ + 8 + 64;
+  if (hipMalloc(&g->arena, floats * sizeof(float)) != hipSuccess) {
+    delete g;
+    ehm_set_error("ehm_gcn_create: hipMalloc of %zu bytes failed", floats * sizeof(float));
+    return EHM_ENOMEM;
+  }
+  float* cur = g->arena;
+  int rc = pack_layer(adj, *input_conv, g->input, cur, false, st);
+  for (int i = 0; i < num_hidden && rc == 0; ++i) rc = pack_layer(adj, hidden[i], g->hidden[i], cur, true, st);
+  if (rc == 0) {
+    g->out.K = hid_dim;
+    g->out.Wt = cur;   cur += 12 * (size_t)hid_dim;
+    g->out.M = cur;    cur += kJ * 6;
+    g->out.A = cur;    cur += kJ * kJ;
+    g->out.bias = cur; cur += 8;
+    hipLaunchKernelGGL(pack_out_kernel, dim3((unsigned)ceil_div(12 * hid_dim, 256)), dim3(256), 0, st, adj, *output_conv,
+                       g->out.Wt, g->out.M, g->out.A, g->out.bias);
+    if (hipGetLastError() != hipSuccess) rc = EHM_EIO;
+  }
+  if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
+  if (rc != 0) {
+    (void)hipFree(g->arena);
+    delete g;
+    ehm_set_error("ehm_gcn_create: packing kernels failed");
+    return rc;
+  }
+  *out = g;
+  return 0;
+}
+
+extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
+  if (!h) return;
+  (void)hipFree(h->arena);
+  delete h;
+}
+
+extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x,
+                                   const float* Wx, const float* tvec, float* out, int B, int passes, void* stream) {
+  EHM_CHECK_ARG(h && h_img && h_oth && vis && x && Wx && tvec && out);
+  EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
+  dim3 grid((unsigned)(B * passes), (unsigned)ceil_div(h->hid, 256));
+  hipLaunchKernelGGL(gcn_input_kernel, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
+                     out, B, passes);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const float* residual, float* out,
+                                    int64_t rows_pad, void* stream) {
+  EHM_CHECK_ARG(h && X && out);
+  EHM_CHECK_ARG(layer >= 0 && layer < h->num_hidden);
+  EHM_CHECK_ARG(rows_pad > 0 && rows_pad % BM == 0);
+  EHM_CHECK_ARG(X != out);
+  const int m_tiles = (int)(rows_pad / BM);
+  const int blocks = m_tiles * (h->hid / BNH);
+  if (residual)
+    hipLaunchKernelGGL(gcn_hidden_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, h->hidden[layer], residual,
+                       out, m_tiles);
+  else
+    hipLaunchKernelGGL(gcn_hidden_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, h->hidden[layer],
+                       (const float*)nullptr, out, m_tiles);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* vis, float* x0, int B, int passes,
+                                    void* stream) {
+  EHM_CHECK_ARG(h && X && x0);
+  EHM_CHECK_ARG(B > 0 && (passes == 1 || (passes == 2 && vis)));
+  hipLaunchKernelGGL(gcn_output_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, h->out, vis, x0, B, passes);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+int ehm_gcn_hid(const ehm_gcn* h) { return h->hid; }
+int ehm_gcn_num_hidden(const ehm_gcn* h) { return h->num_hidden; }

@@ -1,0 +1,197 @@
+// DDPM / DDIM sampler steps and the whole stream-ordered sampling loop for gfx950.
+//
+// Replaces, for the hot path, diffusion/gaussian_diffusion.py:
+//   p_mean_variance :233-276 + q_posterior_mean_variance :209-231   (mean = coef1*x0 + coef2*x)
+//   p_sample :298-337, p_sample_with_grad :340-388, ddim_sample :511-556 (+ _predict_eps_from_xstart :286-290)
+//   p_sample_loop_progressive :449-508, ddim_sample_loop_progressive :661-718
+// The reference's loop is Python with >= 6 tiny host->device copies and ~12 eager kernels per step plus a
+// host sync on t[0] in guided steps; here the host enqueues the T steps back to back on one HIP stream
+// with every schedule coefficient passed by value (no device-side table, no sync, graph-capturable).
+#include <stdarg.h>
+
+#include "common.h"
+#include "egohmr_hip.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void ehm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ehm_last_error(void) { return g_err; }
+extern "C" const char* ehm_target_arch(void) { return "gfx950"; }
+
+int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x, bool from_rot6d, const float* mean,
+                          const float* std_, float* verts, float* joints, float* Rws, float* Aws, float* pose6d_out, int B,
+                          hipStream_t st);
+int ehm_smpl_num_verts(const ehm_smpl* h);
+int ehm_smpl_num_extra(const ehm_smpl* h);
+int ehm_gcn_hid(const ehm_gcn* h);
+int ehm_gcn_num_hidden(const ehm_gcn* h);
+int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
+                      const float* scene, int B, int N, float tau, float denom, float* verts_ws, float* joints_ws, float* R_ws,
+                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, hipStream_t st);
+
+namespace {
+
+// torch evaluates these chains as separate rounded float32 ops; keep the same roundings (no FMA contraction)
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ x0, const float* __restrict__ noise,
+                                 const float* __restrict__ grad, float* __restrict__ out, float c1, float c2, float logvar,
+                                 float nz, float gscale, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float mean = __fadd_rn(__fmul_rn(c1, x0[i]), __fmul_rn(c2, x[i]));                 // :217-220
+  if (grad) mean = __fadd_rn(mean, __fmul_rn(gscale, grad[i]));                      // :381 / :385
+  const float sd = expf(__fmul_rn(0.5f, logvar));
+  out[i] = __fadd_rn(mean, __fmul_rn(__fmul_rn(nz, sd), noise[i]));                  // :336
+}
+
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ x0, const float* __restrict__ noise,
+                                 float* __restrict__ out, float sr, float srm1, float sap, float dir, float sigma, float nz,
+                                 int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(sr, x[i]), x0[i]), srm1);          // :286-290
+  const float mean = __fadd_rn(__fmul_rn(x0[i], sap), __fmul_rn(dir, eps));          // :548-551
+  out[i] = __fadd_rn(mean, __fmul_rn(__fmul_rn(nz, sigma), noise[i]));               // :555
+}
+
+}  // namespace
+
+extern "C" int ehm_ddpm_step(const float* x, const float* x0, const float* noise, const float* grad, float* x_next, float coef1,
+                             float coef2, float log_variance, float nonzero, float grad_scale, int64_t n, void* stream) {
+  EHM_CHECK_ARG(x && x0 && noise && x_next && n >= 0);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x0, noise, grad,
+                     x_next, coef1, coef2, log_variance, nonzero, grad_scale, n);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_ddim_step(const float* x, const float* x0, const float* noise, float* x_next, float sqrt_recip_ac,
+                             float sqrt_recipm1_ac, float sqrt_ac_prev, float dir_coef, float sigma, float nonzero, int64_t n,
+                             void* stream) {
+  EHM_CHECK_ARG(x && x0 && noise && x_next && n >= 0);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x0, noise, x_next,
+                     sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_prev, dir_coef, sigma, nonzero, n);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ whole loop
+namespace {
+struct Workspace {
+  float* X[3];      // activation ping-pong [rows_pad, hid]
+  float* x_cur;     // [B,144]
+  float* A;         // [B,24,12]
+  float* g_verts_in;   // guidance: body decoded from x_t           [B,V,3]
+  float* g_joints;     //                                            [B,45,3]
+  float* g_R;          //                                            [B,24,9]
+  float* g_A;          //                                            [B,24,12]
+  float* g_gverts;     // d loss / d verts                           [B,V,3]
+  float* g_loss;       // [B]
+  float* g_gpose;      // [B,144]
+  float* g_grad;       // [B,144]
+  int64_t rows, rows_pad;
+  int64_t total_bytes;
+};
+
+Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* base) {
+  Workspace w{};
+  w.rows = (int64_t)d->passes * d->B * kJ;
+  w.rows_pad = round_up(w.rows, ehm_gcn_row_tile());
+  int64_t off = 0;
+  auto take = [&](int64_t floats) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += round_up(floats * 4, 256);
+    return p;
+  };
+  for (int i = 0; i < 3; ++i) w.X[i] = take(w.rows_pad * hid);
+  w.x_cur = take((int64_t)d->B * kPoseDim);
+  w.A = take((int64_t)d->B * kJ * 12);
+  const bool guided = d->num_scene_points > 0;
+  if (guided) {
+    w.g_verts_in = take((int64_t)d->B * V * 3);
+    w.g_joints = take((int64_t)d->B * n_joints * 3);
+    w.g_R = take((int64_t)d->B * kJ * 9);
+    w.g_A = take((int64_t)d->B * kJ * 12);
+    w.g_gverts = take((int64_t)d->B * V * 3);
+    w.g_loss = take(d->B);
+    w.g_gpose = take((int64_t)d->B * kPoseDim);
+    w.g_grad = take((int64_t)d->B * kPoseDim);
+  }
+  w.total_bytes = off;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t ehm_sample_workspace_bytes(const ehm_sample_desc* d, int hid_dim, int num_verts) {
+  if (!d || d->B <= 0 || (d->passes != 1 && d->passes != 2) || hid_dim <= 0 || num_verts <= 0) return EHM_EINVAL;
+  return carve(d, hid_dim, num_verts, 64 + kJ, nullptr).total_bytes;
+}
+
+extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_desc* d, const ehm_step_coefs* steps,
+                               const float* h_img, const float* h_oth, const uint8_t* vis, const float* Wx, const float* tvecs,
+                               const float* noise, const float* scene, const float* betas, const float* mean, const float* std_,
+                               float* x_final, float* x0_final, float* verts, float* joints, float* R, float* pose6d,
+                               float* trace, void* workspace, int64_t workspace_bytes, void* stream) {
+  EHM_CHECK_ARG(gcn && smpl && d && steps && h_img && h_oth && vis && Wx && tvecs && noise && betas && mean && std_);
+  EHM_CHECK_ARG(x_final && x0_final && verts && joints && R && pose6d && workspace);
+  EHM_CHECK_ARG(d->B > 0 && d->num_steps > 0 && (d->passes == 1 || d->passes == 2));
+  const int hid = ehm_gcn_hid(gcn), nh = ehm_gcn_num_hidden(gcn), V = ehm_smpl_num_verts(smpl);
+  EHM_CHECK_ARG(nh % 2 == 0);
+  bool any_guided = false;
+  for (int k = 0; k < d->num_steps; ++k) any_guided |= steps[k].grad_scale != 0.f;
+  EHM_CHECK_ARG(!any_guided || (scene && d->num_scene_points > 0 && !d->ddim));
+  Workspace w = carve(d, hid, V, 64 + kJ, (char*)workspace);
+  EHM_CHECK_ARG(workspace_bytes >= w.total_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int B = d->B;
+  const int64_t n = (int64_t)B * kPoseDim;
+
+  for (int i = 0; i < 3; ++i)
+    if (w.rows_pad > w.rows)
+      EHM_HIP(hipMemsetAsync(w.X[i] + w.rows * hid, 0, (size_t)(w.rows_pad - w.rows) * hid * sizeof(float), st));
+  EHM_HIP(hipMemcpyAsync(w.x_cur, noise, n * sizeof(float), hipMemcpyDeviceToDevice, st));   // x_T, :476-478
+
+  int rc = 0;
+  for (int k = 0; k < d->num_steps && rc == 0; ++k) {
+    const ehm_step_coefs& c = steps[k];
+    const bool last = k == d->num_steps - 1;
+    if (trace) EHM_HIP(hipMemcpyAsync(trace + (int64_t)k * n, w.x_cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257) ----
+    rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
+    int in = 0;
+    for (int blk = 0; blk < nh / 2 && rc == 0; ++blk) {
+      const int y1 = 1, y2 = in == 0 ? 2 : 0;
+      rc = ehm_gcn_hidden_layer(gcn, 2 * blk, w.X[in], nullptr, w.X[y1], w.rows_pad, st);
+      if (rc == 0) rc = ehm_gcn_hidden_layer(gcn, 2 * blk + 1, w.X[y1], w.X[in], w.X[y2], w.rows_pad, st);
+      in = y2;
+    }
+    if (rc == 0) rc = ehm_gcn_output_layer(gcn, w.X[in], vis, x0_final, B, d->passes, st);
+    // ---- body decode (egohmr.py:258-278) ----
+    if (rc == 0 && (d->lbs_every_step || last))
+      rc = ehm_smpl_forward_impl(smpl, betas, x0_final, true, mean, std_, verts, joints, R, w.A, pose6d, B, st);
+    // ---- collision guidance on x_t (gaussian_diffusion.py:378-385, egohmr.py:517-570) ----
+    const float* grad = nullptr;
+    if (rc == 0 && c.grad_scale != 0.f) {
+      rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom,
+                             w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, st);
+      grad = w.g_grad;
+    }
+    // ---- x_{t-1} ----
+    if (rc == 0) {
+      const float* eps = noise + (int64_t)(1 + k) * n;
+      float* dst = last ? x_final : w.x_cur;
+      if (d->ddim)
+        rc = ehm_ddim_step(w.x_cur, x0_final, eps, dst, c.sqrt_recip_ac, c.sqrt_recipm1_ac, c.sqrt_ac_prev, c.dir_coef, c.sigma,
+                           c.nonzero, n, st);
+      else
+        rc = ehm_ddpm_step(w.x_cur, x0_final, eps, grad, dst, c.coef1, c.coef2, c.log_variance, c.nonzero, c.grad_scale, n, st);
+    }
+  }
+  return rc;
+}

@@ -1,0 +1,431 @@
+// SMPL linear blend skinning for gfx950 (MI355X).
+//
+// Replaces smplx.SMPL.forward / smplx.lbs.lbs (pip smplx==0.1.28; third-party, absent from the
+// reference tree - environment.yml:197) as called by the reference at
+//   models/egohmr/egohmr.py:276 (every denoising step), :492, :537; test_egohmr.py:291 (final decode)
+// and utils/geometry.py:47-66 (rot6d_to_rotmat, fused in front for the hot path, egohmr.py:258-260).
+//
+// Design: two kernels per call.
+//   pose_chain_kernel  one wave per body, lane j = joint j: rot6d -> R, joint regression from betas
+//                      (J = J_template + J_shapedirs.beta, the regressor pre-contracted with the shape
+//                      basis at create time), then the 24-node kinematic chain resolved level by level
+//                      with wavefront shuffles (child lane pulls its parent's 3x4 transform); writes the
+//                      skinning transforms A[b,24,3,4] and the 24 posed joints.
+//   skin_kernel        thread = vertex, block = 256 vertices x 8 bodies.  Shape blend, pose-corrective
+//                      blend (207 basis rows streamed once per block, reused across the 8 bodies held in
+//                      registers), 24-joint weighted transform, apply.  Per-body constants (betas,
+//                      R - I, A) sit in LDS and are read as broadcasts.  Blocks that share a vertex tile
+//                      are placed on the same XCD so the 17 MB pose basis is fetched from HBM/MALL once
+//                      per XCD-resident tile and re-used out of that XCD's L2.
+// HBM traffic per body-step: 82.7 KB vertices out (+ ~1.5 KB small tensors); shared constants 19.3 MB per launch.
+#include "common.h"
+#include "egohmr_hip.h"
+
+namespace {
+
+constexpr int kBG = 8;       // bodies per skinning block
+constexpr int kVT = 256;     // vertices per skinning block
+constexpr int kPoseBasis = 207;
+
+struct Tree {
+  int8_t parent[kJ];
+  int8_t depth[kJ];
+  int max_depth;
+};
+
+struct SmplDev {
+  int V;
+  int n_extra;
+  float* v_template;   // [V*3]
+  float* shape_t;      // [10][V*3]   shapedirs transposed (basis-major like posedirs)
+  const float* posedirs;  // [207][V*3] caller-owned (smplx layout already streams well)
+  float* w_t;          // [24][V]     lbs_weights transposed
+  float* J_template;   // [24][3]     J_regressor . v_template
+  float* J_shape;      // [24][3][10] J_regressor . shapedirs
+  int32_t* extra_idx;  // [n_extra]
+  Tree tree;
+};
+
+// ------------------------------------------------------------------------------------------------ setup
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  // in [rows][cols] -> out [cols][rows]
+  __shared__ float tile[32][33];
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? in[(size_t)(r0 + r) * cols + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (c0 + r < cols && r0 + tx < rows) out[(size_t)(c0 + r) * rows + r0 + tx] = tile[tx][r];
+}
+
+__global__ void joint_basis_kernel(const float* __restrict__ Jr, const float* __restrict__ v_template,
+                                   const float* __restrict__ shapedirs, float* __restrict__ Jt, float* __restrict__ Js,
+                                   int V) {
+  // block (j, m): m in [0,33): m<3 -> J_template[j][m]; else J_shape[j][c][l] with m-3 = c*10+l
+  const int j = blockIdx.x, m = blockIdx.y;
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float x = (m < 3) ? v_template[v * 3 + m] : shapedirs[(size_t)v * 30 + (m - 3)];
+    s = fmaf(Jr[(size_t)j * V + v], x, s);
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (m < 3) Jt[j * 3 + m] = red[0];
+    else Js[j * 30 + (m - 3)] = red[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ rot6d
+__device__ __forceinline__ void rot6d_to_R(float a1x, float a1y, float a1z, float a2x, float a2y, float a2z, float (&R)[9]) {
+  // utils/geometry.py:61-66; F.normalize = x / max(||x||_2, 1e-12)
+  float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+  float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+  float d = b1x * a2x + b1y * a2y + b1z * a2z;
+  float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+  float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+  float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+  float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+  R[0] = b1x; R[1] = b2x; R[2] = b3x;
+  R[3] = b1y; R[4] = b2y; R[5] = b3y;
+  R[6] = b1z; R[7] = b2z; R[8] = b3z;
+}
+
+__global__ void rot6d_kernel(const float* __restrict__ x, float* __restrict__ Rout, int64_t n, int mode) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = x + i * 6;
+  float R[9];
+  if (mode == 1) rot6d_to_R(p[0], p[2], p[4], p[1], p[3], p[5], R);
+  else rot6d_to_R(p[0], p[1], p[2], p[3], p[4], p[5], R);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rout[i * 9 + k] = R[k];
+}
+
+// ------------------------------------------------------------------------------------------------ pose + chain
+template <bool FROM_ROT6D>
+__global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rot_or_x,
+                                                        const float* __restrict__ mean, const float* __restrict__ std_,
+                                                        SmplDev S, float* __restrict__ Rws, float* __restrict__ Aout,
+                                                        float* __restrict__ joints, float* __restrict__ pose6d_out,
+                                                        int joints_stride) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int j = lane < kJ ? lane : 0;
+  float R[9];
+  if (FROM_ROT6D) {
+    float p[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int e = j * 6 + c;
+      p[c] = rot_or_x[(size_t)b * kPoseDim + e] * std_[e] + mean[e];   // egohmr.py:258
+      if (pose6d_out && lane < kJ) pose6d_out[(size_t)b * kPoseDim + e] = p[c];
+    }
+    rot6d_to_R(p[0], p[2], p[4], p[1], p[3], p[5], R);                 // 'diffusion' layout
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rot_or_x[((size_t)b * kJ + j) * 9 + k];
+  }
+  // joint regression: J = J_template + J_shape . beta
+  float Jx[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < 10; ++l) s = fmaf(S.J_shape[j * 30 + c * 10 + l], betas[(size_t)b * 10 + l], s);
+    Jx[c] = S.J_template[j * 3 + c] + s;
+  }
+  const int par = S.tree.parent[j];
+  const int plane = par < 0 ? 0 : par;
+  float t[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float pj = __shfl(Jx[c], plane);
+    t[c] = par < 0 ? Jx[c] : Jx[c] - pj;     // rel_joints
+  }
+  // G = [R | t] for the root; children: G = G_parent * [R | t]
+  float G[12];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    G[r * 4 + 0] = R[r * 3 + 0]; G[r * 4 + 1] = R[r * 3 + 1]; G[r * 4 + 2] = R[r * 3 + 2]; G[r * 4 + 3] = t[r];
+  }
+  const int my_depth = S.tree.depth[j];
+  for (int d = 1; d <= S.tree.max_depth; ++d) {
+    float P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = __shfl(G[k], plane);
+    if (my_depth == d) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float p0 = P[r * 4 + 0], p1 = P[r * 4 + 1], p2 = P[r * 4 + 2], p3 = P[r * 4 + 3];
+        G[r * 4 + 0] = p0 * R[0] + p1 * R[3] + p2 * R[6];
+        G[r * 4 + 1] = p0 * R[1] + p1 * R[4] + p2 * R[7];
+        G[r * 4 + 2] = p0 * R[2] + p1 * R[5] + p2 * R[8];
+        G[r * 4 + 3] = p0 * t[0] + p1 * t[1] + p2 * t[2] + p3;
+      }
+    }
+  }
+  if (lane >= kJ) return;
+  const size_t o = (size_t)b * kJ + j;
+  if (Rws) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rws[o * 9 + k] = R[k];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    joints[(size_t)b * joints_stride + j * 3 + r] = G[r * 4 + 3];           // posed joint = chain translation
+    const float gj = G[r * 4 + 0] * Jx[0] + G[r * 4 + 1] * Jx[1] + G[r * 4 + 2] * Jx[2];
+    Aout[o * 12 + r * 4 + 0] = G[r * 4 + 0];
+    Aout[o * 12 + r * 4 + 1] = G[r * 4 + 1];
+    Aout[o * 12 + r * 4 + 2] = G[r * 4 + 2];
+    Aout[o * 12 + r * 4 + 3] = G[r * 4 + 3] - gj;                              // rel_transforms
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ skinning
+__global__ __launch_bounds__(kVT, 4) void skin_kernel(const float* __restrict__ betas, const float* __restrict__ Rws,
+                                                   const float* __restrict__ A, SmplDev S, float* __restrict__ verts,
+                                                   int B, int v_tiles, int b_groups) {
+  __shared__ __attribute__((aligned(16))) float sA[kBG][kJ][12];
+  __shared__ float sPF[kBG][kPoseBasis + 1];
+  __shared__ float sBeta[kBG][10];
+
+  // XCD-aware order: blocks of one XCD (bid % 8) walk body groups of the same vertex tile back to back
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int vt = (k / b_groups) * 8 + xcd;
+  const int bg = k % b_groups;
+  if (vt >= v_tiles) return;
+  const int b0 = bg * kBG;
+  const int nb = min(kBG, B - b0);
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < kBG * kJ * 12; i += kVT) {
+    const int bb = i / (kJ * 12);
+    (&sA[0][0][0])[i] = bb < nb ? A[(size_t)b0 * kJ * 12 + i] : 0.f;
+  }
+  for (int i = tid; i < kBG * kPoseBasis; i += kVT) {
+    const int bb = i / kPoseBasis, p = i % kPoseBasis;
+    const int e = p % 9;
+    float v = 0.f;
+    if (bb < nb) v = Rws[((size_t)(b0 + bb) * kJ + 1) * 9 + p] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);  // R[1:] - I
+    sPF[bb][p] = v;
+  }
+  if (tid < kBG * 10) sBeta[tid / 10][tid % 10] = (tid / 10) < nb ? betas[(size_t)b0 * 10 + tid] : 0.f;
+  __syncthreads();
+
+  const int v = vt * kVT + tid;
+  if (v >= S.V) return;
+  const int V3 = S.V * 3;
+
+  // shape blend: v_shaped = v_template + shapedirs . beta   (accumulated straight into the posed position)
+  float po[kBG][3];
+  {
+    const float t0 = S.v_template[v * 3 + 0], t1 = S.v_template[v * 3 + 1], t2 = S.v_template[v * 3 + 2];
+#pragma unroll
+    for (int bb = 0; bb < kBG; ++bb) { po[bb][0] = 0.f; po[bb][1] = 0.f; po[bb][2] = 0.f; }
+#pragma unroll 2
+    for (int l = 0; l < 10; ++l) {
+      const float s0 = S.shape_t[(size_t)l * V3 + v * 3 + 0], s1 = S.shape_t[(size_t)l * V3 + v * 3 + 1],
+                  s2 = S.shape_t[(size_t)l * V3 + v * 3 + 2];
+#pragma unroll
+      for (int bb = 0; bb < kBG; ++bb) {
+        const float be = sBeta[bb][l];
+        po[bb][0] = fmaf(be, s0, po[bb][0]); po[bb][1] = fmaf(be, s1, po[bb][1]); po[bb][2] = fmaf(be, s2, po[bb][2]);
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < kBG; ++bb) { po[bb][0] += t0; po[bb][1] += t1; po[bb][2] += t2; }
+  }
+  // pose-corrective blend: + pose_feature . posedirs (207 basis rows, each reused by the 8 bodies in registers)
+  const float* pd = S.posedirs + (size_t)v * 3;
+#pragma unroll 2
+  for (int p = 0; p < kPoseBasis; ++p) {
+    const float d0 = pd[(size_t)p * V3 + 0], d1 = pd[(size_t)p * V3 + 1], d2 = pd[(size_t)p * V3 + 2];
+#pragma unroll
+    for (int bb = 0; bb < kBG; ++bb) {
+      const float f = sPF[bb][p];
+      po[bb][0] = fmaf(f, d0, po[bb][0]); po[bb][1] = fmaf(f, d1, po[bb][1]); po[bb][2] = fmaf(f, d2, po[bb][2]);
+    }
+  }
+  const float* wv = S.w_t + v;   // [24][V]: re-read per body, L1/L2 resident (keeps 24 registers free)
+#pragma unroll
+  for (int bb = 0; bb < kBG; ++bb) {
+    if (bb >= nb) break;
+    __builtin_amdgcn_sched_barrier(0);   // one body at a time: keeps the 8x288 FMAs from being interleaved (register pressure)
+    const float px = po[bb][0], py = po[bb][1], pz = po[bb][2];
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < kJ; ++j) {
+      const float wj = wv[(size_t)j * S.V];
+      const f32x4 r0 = *(const f32x4*)&sA[bb][j][0], r1 = *(const f32x4*)&sA[bb][j][4], r2 = *(const f32x4*)&sA[bb][j][8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T[e] = fmaf(wj, r0[e], T[e]); T[4 + e] = fmaf(wj, r1[e], T[4 + e]); T[8 + e] = fmaf(wj, r2[e], T[8 + e]);
+      }
+    }
+    float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
+    o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+    o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+  }
+}
+
+__global__ void extra_joints_kernel(const float* __restrict__ verts, const int32_t* __restrict__ idx, float* __restrict__ joints,
+                                    int B, int V, int n_extra) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n_extra * 3) return;
+  const int c = i % 3, e = (i / 3) % n_extra, b = i / (3 * n_extra);
+  joints[((size_t)b * (kJ + n_extra) + kJ + e) * 3 + c] = verts[((size_t)b * V + idx[e]) * 3 + c];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+struct ehm_smpl {
+  SmplDev d{};
+  float* arena = nullptr;      // packed constants
+  float* ws = nullptr;         // per-call scratch: R [cap,24,9] + A [cap,24,12]
+  int ws_cap = 0;
+};
+
+static int smpl_scratch(ehm_smpl* h, int B) {
+  if (B <= h->ws_cap) return 0;
+  if (h->ws) (void)hipFree(h->ws);
+  h->ws = nullptr;
+  h->ws_cap = 0;
+  const int cap = (int)round_up(B, 64);
+  EHM_HIP(hipMalloc(&h->ws, (size_t)cap * kJ * 21 * sizeof(float)));
+  h->ws_cap = cap;
+  return 0;
+}
+
+extern "C" int ehm_smpl_create(ehm_smpl** out, const float* v_template, const float* shapedirs, const float* posedirs,
+                               const float* J_regressor, const float* lbs_weights, const int32_t* parents,
+                               const int32_t* extra_joint_vertex_ids, int num_verts, int n_extra, void* stream) {
+  EHM_CHECK_ARG(out && v_template && shapedirs && posedirs && J_regressor && lbs_weights && parents);
+  EHM_CHECK_ARG(num_verts > 0 && n_extra >= 0 && n_extra <= 64 && (n_extra == 0 || extra_joint_vertex_ids));
+  EHM_CHECK_ARG(parents[0] < 0);
+  hipStream_t st = (hipStream_t)stream;
+  auto* h = new ehm_smpl();
+  SmplDev& d = h->d;
+  d.V = num_verts;
+  d.n_extra = n_extra;
+  d.tree.max_depth = 0;
+  for (int j = 0; j < kJ; ++j) {
+    if (j > 0 && !(parents[j] >= 0 && parents[j] < j)) {
+      delete h;
+      ehm_set_error("ehm_smpl_create: parents[%d]=%d must satisfy 0 <= parent < child", j, parents[j]);
+      return EHM_EINVAL;
+    }
+    d.tree.parent[j] = (int8_t)parents[j];
+    d.tree.depth[j] = j == 0 ? 0 : (int8_t)(d.tree.depth[parents[j]] + 1);
+    if (d.tree.depth[j] > d.tree.max_depth) d.tree.max_depth = d.tree.depth[j];
+  }
+  const size_t V = num_verts;
+  const size_t floats = V * 3 + 10 * V * 3 + kJ * V + kJ * 3 + kJ * 30 + 64 + 64;
+  if (hipMalloc(&h->arena, floats * sizeof(float)) != hipSuccess) {
+    delete h;
+    ehm_set_error("ehm_smpl_create: hipMalloc failed");
+    return EHM_ENOMEM;
+  }
+  float* cur = h->arena;
+  d.v_template = cur;  cur += V * 3;
+  d.shape_t = cur;     cur += 10 * V * 3;
+  d.w_t = cur;         cur += kJ * V;
+  d.J_template = cur;  cur += kJ * 3;
+  d.J_shape = cur;     cur += kJ * 30;
+  d.extra_idx = (int32_t*)cur;
+  d.posedirs = posedirs;
+  int rc = 0;
+  if (hipMemcpyAsync(d.v_template, v_template, V * 3 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = EHM_EIO;
+  if (n_extra && hipMemcpyAsync(d.extra_idx, extra_joint_vertex_ids, n_extra * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) rc = EHM_EIO;
+  for (int e = 0; e < n_extra; ++e)
+    if (extra_joint_vertex_ids[e] < 0 || extra_joint_vertex_ids[e] >= num_verts) rc = EHM_EINVAL;
+  if (rc == 0) {
+    // shapedirs [V*3][10] -> [10][V*3];  lbs_weights [V][24] -> [24][V]
+    hipLaunchKernelGGL(transpose_kernel, dim3(1, (unsigned)ceil_div(V * 3, 32)), dim3(256), 0, st, shapedirs, d.shape_t, (int)(V * 3), 10);
+    hipLaunchKernelGGL(transpose_kernel, dim3(1, (unsigned)ceil_div(V, 32)), dim3(256), 0, st, lbs_weights, d.w_t, (int)V, kJ);
+    hipLaunchKernelGGL(joint_basis_kernel, dim3(kJ, 33), dim3(256), 0, st, J_regressor, v_template, shapedirs, d.J_template,
+                       d.J_shape, (int)V);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
+  }
+  if (rc != 0) {
+    (void)hipFree(h->arena);
+    delete h;
+    ehm_set_error("ehm_smpl_create: setup failed (rc=%d)", rc);
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" void ehm_smpl_destroy(ehm_smpl* h) {
+  if (!h) return;
+  (void)hipFree(h->arena);
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+}
+
+// internal entry shared with sampler.hip: caller provides R/A scratch (no allocation -> graph safe)
+int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x, bool from_rot6d, const float* mean,
+                          const float* std_, float* verts, float* joints, float* Rws, float* Aws, float* pose6d_out, int B,
+                          hipStream_t st) {
+  const SmplDev& d = h->d;
+  const int jstride = (kJ + d.n_extra) * 3;
+  if (from_rot6d)
+    hipLaunchKernelGGL(pose_chain_kernel<true>, dim3(B), dim3(64), 0, st, betas, rot_or_x, mean, std_, d, Rws, Aws, joints,
+                       pose6d_out, jstride);
+  else
+    hipLaunchKernelGGL(pose_chain_kernel<false>, dim3(B), dim3(64), 0, st, betas, rot_or_x, (const float*)nullptr,
+                       (const float*)nullptr, d, Rws, Aws, joints, (float*)nullptr, jstride);
+  const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBG);
+  const int blocks = (int)round_up(v_tiles, 8) * b_groups;
+  hipLaunchKernelGGL(skin_kernel, dim3(blocks), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);
+  if (d.n_extra)
+    hipLaunchKernelGGL(extra_joints_kernel, dim3((unsigned)ceil_div((int64_t)B * d.n_extra * 3, 256)), dim3(256), 0, st, verts,
+                       d.extra_idx, joints, B, d.V, d.n_extra);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_smpl_forward(ehm_smpl* h, const float* betas, const float* rotmats, float* verts, float* joints, float* A_out,
+                                int B, void* stream) {
+  EHM_CHECK_ARG(h && betas && rotmats && verts && joints && B > 0);
+  int rc = smpl_scratch(h, B);
+  if (rc) return rc;
+  float* Rws = h->ws;
+  float* Aws = A_out ? A_out : h->ws + (size_t)h->ws_cap * kJ * 9;
+  // the skinning kernel reads R from scratch: copy the caller's matrices through the pose kernel (Rws written there)
+  return ehm_smpl_forward_impl(h, betas, rotmats, false, nullptr, nullptr, verts, joints, Rws, Aws, nullptr, B, (hipStream_t)stream);
+}
+
+extern "C" int ehm_smpl_forward_rot6d(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_,
+                                      float* verts, float* joints, float* R_out, float* pose6d_out, float* A_out, int B,
+                                      void* stream) {
+  EHM_CHECK_ARG(h && betas && x && mean && std_ && verts && joints && B > 0);
+  int rc = smpl_scratch(h, B);
+  if (rc) return rc;
+  float* Rws = R_out ? R_out : h->ws;
+  float* Aws = A_out ? A_out : h->ws + (size_t)h->ws_cap * kJ * 9;
+  return ehm_smpl_forward_impl(h, betas, x, true, mean, std_, verts, joints, Rws, Aws, pose6d_out, B, (hipStream_t)stream);
+}
+
+extern "C" int ehm_rot6d_to_rotmat(const float* x6d, float* R, int64_t n, int mode, void* stream) {
+  EHM_CHECK_ARG(x6d && R && n >= 0 && (mode == 0 || mode == 1));
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rot6d_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x6d, R, n, mode);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+int ehm_smpl_num_verts(const ehm_smpl* h) { return h->d.V; }
+int ehm_smpl_num_extra(const ehm_smpl* h) { return h->d.n_extra; }

@@ -1,0 +1,80 @@
+"""Multi-GPU layer: one process per GPU, items sharded, ONE collective at the end.
+
+Every (image, scene, sample) item is independent in sampling - the reference itself
+is single-process (test_egohmr.py:92) and only suggests "running multiple jobs" (README.md:154-156).  So:
+contiguous blocks of items per rank, weights and SMPL constants replicated, no per-step communication,
+and a single all-gather (RCCL over xGMI when the backend is "nccl") of the packed result rows
+    [betas 10 | global_orient 9 | body_pose 207] = 226 float32 per body  (what test_egohmr.py:261-266 collects).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+PACKED_WIDTH = 226
+
+
+def init_from_env(backend: str | None = None):
+    """(rank, world, local_rank); initialises torch.distributed when launched by torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced split (first n_items % world ranks get one extra item)."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def pack_params(pred_smpl_params: dict) -> torch.Tensor:
+    """{'betas' [B,10], 'global_orient' [B,1,3,3], 'body_pose' [B,23,3,3]} -> [B,226]."""
+    B = pred_smpl_params["betas"].shape[0]
+    return torch.cat([pred_smpl_params["betas"].reshape(B, 10), pred_smpl_params["global_orient"].reshape(B, 9),
+                      pred_smpl_params["body_pose"].reshape(B, 207)], dim=1).contiguous()
+
+
+def unpack_params(packed: torch.Tensor) -> dict:
+    B = packed.shape[0]
+    return {"betas": packed[:, :10], "global_orient": packed[:, 10:19].reshape(B, 1, 3, 3),
+            "body_pose": packed[:, 19:].reshape(B, 23, 3, 3)}
+
+
+def gather_packed(packed: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
+    """All ranks receive every rank's rows in rank order.  ``counts`` = rows per rank when ragged."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return packed
+    world = dist.get_world_size()
+    if counts is None or len(set(counts)) == 1:
+        out = torch.empty(world * packed.shape[0], packed.shape[1], dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(out, packed)
+        return out
+    width, cap = packed.shape[1], max(counts)                       # ragged: pad to the largest shard, one collective
+    padded = torch.zeros(cap, width, dtype=packed.dtype, device=packed.device)
+    padded[: packed.shape[0]] = packed
+    out = torch.empty(world * cap, width, dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, padded)
+    return torch.cat([out[r * cap: r * cap + counts[r]] for r in range(world)], dim=0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,508 @@
+"""EgoHMR stage-2 model with the reference's constructor / call surface, executing on libegohmr_hip.
+
+Reference seams honoured (models/egohmr/egohmr.py):
+  EgoHMR(cfg, device, body_rep_mean, body_rep_std, with_focal_length, with_bbox_info, with_cam_center, ...)   :29-40
+  .forward(batch, timesteps) -> dict(pred_x_start, pred_smpl_params, pred_pose_6d, pred_keypoints_3d,
+                                     pred_vertices, pred_keypoints_3d_full, pred_keypoints_2d_full)          :173-303
+  .validation_setup()  :475-484     .guide_coll(batch, output, t, compute_grad)  :517-605
+  .eval_coll(output)   :487-514     .parameters() / load_state_dict(strict=False) with the reference's names
+plus ``fused_sampler`` (build extension) which diffusion.py uses to run the whole sampling loop natively.
+
+What is different by design: the encoders (ResNet-50, scene PointNet), the translation / beta heads and
+the conditioning + timestep slices of the GCN input conv do not depend on x_t, so they are evaluated once
+per batch (``prepare``) instead of once per denoising step (egohmr.py:183,:214 sit inside forward); the
+denoiser, rot6d->rotmat, SMPL LBS and the sampler update are hand-written HIP kernels (csrc/*.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, geometry, synthetic
+from . import smpl as smpl_mod
+from .encoders import ResnetPointnet, ResNet50Features
+
+OPENPOSE_TO_SMPL = [8, 12, 9, 8, 13, 10, 8, 14, 11, 8, 14, 11, 0, 5, 2, 0, 5, 2, 6, 3, 7, 4, 7, 4]           # egohmr.py:111
+OPENPOSE_TO_SMPL_LOOSE = [8, 13, 10, 8, 13, 10, 8, 14, 11, 8, 14, 11, 1, 5, 2, 0, 5, 2, 6, 3, 7, 4, 7, 4]     # egohmr.py:114
+IMG_DIM, COND_SPLIT = 2048, (2048, 2694, 3206, 3718)   # img | scene+transl+cam | x_t embed | timestep embed
+GRAD_ZERO_JOINTS = [0, 3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23]                               # egohmr.py:567
+
+
+def default_cfg():
+    """The yacs keys the sampling path reads (configs/prohmr.yaml:41-56)."""
+    return SimpleNamespace(MODEL=SimpleNamespace(BACKBONE=SimpleNamespace(NUM_LAYERS=50, OUT_CHANNELS=2048)),
+                           CAM=SimpleNamespace(FX_NORM_COEFF=1500.0), EXTRA=SimpleNamespace(FOCAL_LENGTH=5000.0),
+                           TRAIN=SimpleNamespace(LR=1e-4, WEIGHT_DECAY=1e-4))
+
+
+def smpl_tree_adjacency() -> torch.Tensor:
+    """egohmr.py:86-93: symmetric SMPL-tree adjacency, rows normalised, diagonal forced to one."""
+    a = np.zeros((24, 24), dtype=np.float32)
+    for p, c in synthetic.SMPL_EDGES:
+        a[p, c] = a[c, p] = 1.0
+    a = a / a.sum(1, keepdims=True)
+    np.fill_diagonal(a, 1.0)
+    return torch.from_numpy(a)
+
+
+# ---------------------------------------------------------------------------------------------- parameter holders
+class ModulatedGraphConv(nn.Module):
+    """Parameters of modulated_gcn_conv.py:16-37 (the arithmetic lives in csrc/gcn.hip)."""
+
+    def __init__(self, in_features, out_features, adj):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.W = nn.Parameter(torch.empty(2, in_features, out_features))
+        self.M = nn.Parameter(torch.empty(adj.size(0), out_features))
+        self.adj2 = nn.Parameter(torch.full_like(adj, 1e-6))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.xavier_uniform_(self.W.data, gain=1.414)
+        nn.init.xavier_uniform_(self.M.data, gain=1.414)
+        bound = 1.0 / np.sqrt(out_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _GraphConv(nn.Module):
+    def __init__(self, adj, cin, cout):
+        super().__init__()
+        self.gconv = ModulatedGraphConv(cin, cout, adj)
+        self.bn = nn.BatchNorm1d(cout)
+
+
+class _ResGraphConv(nn.Module):
+    def __init__(self, adj, dim):
+        super().__init__()
+        self.gconv1 = _GraphConv(adj, dim, dim)
+        self.gconv2 = _GraphConv(adj, dim, dim)
+
+
+class ModulatedGCN(nn.Module):
+    """modulated_gcn.py:60-97 parameter tree: gconv_input.0, gconv_layers.{b}.gconv{1,2}, gconv_output."""
+
+    def __init__(self, adj, in_dim, out_dim=6, hid_dim=1024, num_layers=4, nonlocal_layer=False, p_dropout=0.0):
+        super().__init__()
+        if nonlocal_layer:
+            raise NotImplementedError("gcn_nonlocal_layer=True is off in every shipped reference config and not built here yet")
+        self.register_buffer("adj", adj.clone(), persistent=False)
+        self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
+        self.gconv_input = nn.Sequential(_GraphConv(adj, in_dim, hid_dim))
+        self.gconv_layers = nn.Sequential(*[_ResGraphConv(adj, hid_dim) for _ in range(num_layers)])
+        self.gconv_output = ModulatedGraphConv(hid_dim, out_dim, adj)
+
+    def forward(self, x):
+        raise NotImplementedError("the denoiser runs through EgoHMR.forward / EgoHMR.fused_sampler (hoisted input conv)")
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.register_buffer("pe", torch.from_numpy(synthetic.positional_table(max_len, d_model)))
+
+
+class TimestepEmbedder(nn.Module):
+    def __init__(self, latent_dim, sequence_pos_encoder):
+        super().__init__()
+        self.sequence_pos_encoder = sequence_pos_encoder
+        self.time_embed = nn.Sequential(nn.Linear(latent_dim, latent_dim), nn.SiLU(), nn.Linear(latent_dim, latent_dim))
+
+    def forward(self, timesteps):
+        return self.time_embed(self.sequence_pos_encoder.pe[timesteps]).permute(1, 0, 2)   # egohmr.py:642-643
+
+
+class InputProcess(nn.Module):
+    def __init__(self, input_dim, latent_dim):
+        super().__init__()
+        self.poseEmbedding = nn.Linear(input_dim, latent_dim)
+
+
+class FCHeadBeta(nn.Module):
+    def __init__(self, in_dim):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(in_dim, 1024), nn.ReLU(), nn.Linear(1024, 10))
+        self.register_buffer("init_betas", torch.zeros(1, 10))   # data/smpl_mean_params.npz['shape'] in the reference (:669-671)
+
+    def forward(self, feats, pred_pose=None):
+        return self.layers(feats) + self.init_betas
+
+
+class TranslEnc(nn.Module):
+    def __init__(self, in_dim=3, out_dim=128):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(in_dim, 64), nn.ReLU(), nn.Linear(64, out_dim))
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+# ---------------------------------------------------------------------------------------------- model
+class EgoHMR(nn.Module):
+    def __init__(self, cfg=None, device=None, body_rep_mean=None, body_rep_std=None,
+                 with_focal_length=False, with_bbox_info=False, with_cam_center=False,
+                 scene_feat_dim=512, scene_type="whole_scene", scene_cano=False,
+                 weight_loss_v2v=0, weight_loss_keypoints_3d=0, weight_loss_keypoints_3d_full=0, weight_loss_keypoints_2d_full=0,
+                 weight_loss_betas=0, weight_loss_body_pose=0, weight_loss_global_orient=0, weight_loss_pose_6d_ortho=0,
+                 weight_coap_penetration=0, start_coap_epoch=0, cond_mask_prob=0, only_mask_img_cond=False,
+                 diffusion_blk=4, gcn_dropout=0.0, gcn_nonlocal_layer=False, gcn_hid_dim=1024,
+                 pelvis_vis_loosen=False, diffuse_fuse=False, smpl_asset=None, smpl_model_path="data/smpl"):
+        super().__init__()
+        self.cfg = cfg if cfg is not None else default_cfg()
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        if not (with_focal_length and with_bbox_info and with_cam_center):
+            raise NotImplementedError("the sampling path is built for the test-time flags of test_egohmr.py:112-118 "
+                                      "(with_focal_length = with_bbox_info = with_cam_center = True)")
+        if cond_mask_prob not in (0, 0.0):
+            raise NotImplementedError("cond_mask_prob > 0 is a training-time option")
+        self.with_focal_length, self.with_bbox_info, self.with_cam_center = True, True, True
+        self.scene_type, self.scene_cano = scene_type, scene_cano
+        self.only_mask_img_cond, self.diffuse_fuse = only_mask_img_cond, diffuse_fuse
+        if diffuse_fuse and not only_mask_img_cond:
+            raise NotImplementedError("diffuse_fuse with only_mask_img_cond=False zeroes the whole condition (egohmr.py:157-158); "
+                                      "the shipped test configuration uses only_mask_img_cond=True")
+        self.cond_mask_prob = 0.0
+        self.diffuse_feat_dim = 6
+        dev = self.device
+        self.register_buffer("body_rep_mean_buf", torch.as_tensor(body_rep_mean, dtype=torch.float32).reshape(144).clone(), persistent=False)
+        self.register_buffer("body_rep_std_buf", torch.as_tensor(body_rep_std, dtype=torch.float32).reshape(144).clone(), persistent=False)
+        self.body_rep_mean, self.body_rep_std = body_rep_mean, body_rep_std
+
+        self.input_process = InputProcess(6, 512)
+        self.sequence_pos_encoder = PositionalEncoding(512)
+        self.embed_timestep = TimestepEmbedder(512, self.sequence_pos_encoder)
+        if self.cfg.MODEL.BACKBONE.NUM_LAYERS != 50:
+            raise NotImplementedError("only the ResNet-50 backbone of configs/prohmr.yaml is built")
+        self.backbone = ResNet50Features()
+        self.scene_enc = ResnetPointnet(out_dim=scene_feat_dim, hidden_dim=256)
+        self.transl_enc = TranslEnc(3, 128)
+        ctx = self.cfg.MODEL.BACKBONE.OUT_CHANNELS + 1 + 3 + 2 + scene_feat_dim + 128
+        self.context_feats_dim = ctx
+        self.diffusion_model = ModulatedGCN(adj=smpl_tree_adjacency(), in_dim=ctx + 512 + 512, hid_dim=gcn_hid_dim, out_dim=6,
+                                            num_layers=diffusion_blk, nonlocal_layer=gcn_nonlocal_layer)
+        self.beta_layer = FCHeadBeta(ctx)
+        self.smpl = smpl_mod.create(smpl_model_path, model_type="smpl", gender="neutral", asset=smpl_asset)
+        self.openpose_to_smpl = OPENPOSE_TO_SMPL_LOOSE if pelvis_vis_loosen else OPENPOSE_TO_SMPL
+        self.smpl_to_openpose = [24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34]
+        self.collision_tau = 0.05
+        self.guide_reduction = "mean"          # COAP variant: -loss.mean() (egohmr.py:562); 'sum' = VolSMPL variant
+        self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        self.fused_sampler = FusedSampler(self)
+        self.to(dev)
+        self.eval()
+
+    # ------------------------------------------------------------------ reference API
+    def validation_setup(self):
+        self.training = False
+        self.eval()
+
+    def _std_mean(self):
+        return self.body_rep_mean_buf, self.body_rep_std_buf
+
+    def visibility(self, batch):
+        vis = batch["orig_keypoints_2d"][:, :, -1] > 0                                 # :186
+        vis = vis.clone()
+        vis[:, 8] = True                                                               # :187
+        return vis[:, self.openpose_to_smpl]                                           # :188
+
+    def forward(self, batch, timesteps, eval_with_uncond=True):
+        """One denoising evaluation (egohmr.py:173-303).  Conditioning is cached per batch object."""
+        fs = self.fused_sampler
+        st = fs.prepare(batch)
+        x_t = _lib.f32(batch["x_t"], self.device).reshape(-1, 144)
+        B = x_t.shape[0]
+        passes = 2 if (self.diffuse_fuse and eval_with_uncond) else 1
+        tvec = fs.timestep_vectors(timesteps[:1].to(self.device))[0]
+        x0 = fs.denoise_once(st, x_t, tvec, passes)
+        mean, std = self._std_mean()
+        verts = torch.empty(B, self.smpl.num_verts, 3, device=self.device)
+        joints = torch.empty(B, self.smpl.num_joints_out, 3, device=self.device)
+        R = torch.empty(B, 24, 3, 3, device=self.device)
+        pose6d = torch.empty(B, 144, device=self.device)
+        _lib.check(_lib.lib().ehm_smpl_forward_rot6d(self.smpl.handle(), _lib.ptr(st.betas), _lib.ptr(x0), _lib.ptr(mean), _lib.ptr(std),
+                                                     _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(R), _lib.ptr(pose6d), None, B,
+                                                     _lib.stream_ptr()), "ehm_smpl_forward_rot6d")
+        batch["vis_mask_smpl"] = st.vis_bool
+        return self._pack_output(batch, st, x0, pose6d, R, verts, joints)
+
+    def _pack_output(self, batch, st, x0, pose6d, R, verts, joints):
+        self.scene_pcd_verts = st.scene
+        self.input_transl = st.transl
+        self.smpl_output = smpl_mod.SMPLOutput(vertices=verts, joints=joints, full_pose=R)
+        focal = st.fx.unsqueeze(-1).repeat(1, 2) * self.cfg.CAM.FX_NORM_COEFF          # :283-285
+        center = torch.stack([st.cam_cx, st.cam_cy], dim=-1)
+        self.focal_length, self.camera_center_full = focal, center
+        kp2d = geometry.perspective_projection(joints, st.transl, focal, center)        # :295-298
+        kp2d = torch.stack([kp2d[..., 0] / 1920 - 0.5, kp2d[..., 1] / 1080 - 0.5], dim=-1)
+        return {
+            "pred_x_start": x0,
+            "pred_smpl_params": {"global_orient": R[:, [0]].clone(), "body_pose": R[:, 1:].clone(), "betas": st.betas.clone()},
+            "pred_pose_6d": pose6d,
+            "pred_keypoints_3d": joints,
+            "pred_vertices": verts,
+            "pred_keypoints_3d_full": joints + st.transl.unsqueeze(1),
+            "pred_keypoints_2d_full": kp2d,
+        }
+
+    def guide_coll(self, batch, output, t, compute_grad="x_t"):
+        """egohmr.py:517-570 with the build's collision proxy in place of COAP; returns [B,144]."""
+        fs = self.fused_sampler
+        st = fs.prepare(batch)
+        x = _lib.f32(batch["x_t"] if compute_grad == "x_t" else output["pred_x_start"], self.device).reshape(-1, 144)
+        return fs.guidance_gradient(st, x, _lib.f32(output["pred_smpl_params"]["betas"], self.device))
+
+    def eval_coll(self, output):
+        """egohmr.py:487-514 with the proxy: share of scene points closer than tau to the body surface."""
+        fs = self.fused_sampler
+        R = torch.cat([output["pred_smpl_params"]["global_orient"], output["pred_smpl_params"]["body_pose"]], dim=1)
+        so = self.smpl(betas=output["pred_smpl_params"]["betas"], body_pose=R[:, 1:], global_orient=R[:, [0]], pose2rot=False)
+        loss, hits = fs.collision(so.vertices, self.scene_pcd_verts, want_grad=False)
+        return (hits / self.scene_pcd_verts.shape[1]).tolist()
+
+    def compute_loss(self, batch, output, cur_epoch=0):
+        """Evaluation losses need ground-truth annotations (egohmr.py:307-449); the sampling path has none."""
+        output["losses"] = {}
+        return torch.zeros((), device=self.device)
+
+    def training_step(self, *a, **k):
+        raise NotImplementedError("training is outside the sampling hot path this package implements")
+
+
+# ---------------------------------------------------------------------------------------------- native engine
+class _Prepared(SimpleNamespace):
+    pass
+
+
+class FusedSampler:
+    """Owns the native denoiser handle and runs sampling loops through ehm_sample_loop."""
+
+    def __init__(self, model: EgoHMR):
+        self._model_ref = [model]
+        self._gcn = None
+        self._gcn_key = None
+        self._folded = None
+        self._prep_key = None
+        self._prep = None
+        self._ws = None
+        self.last_trace = None
+
+    @property
+    def model(self) -> EgoHMR:
+        return self._model_ref[0]
+
+    # ------------------------------------------------------------------ weights -> native handle
+    def _param_key(self):
+        dm = self.model.diffusion_model
+        return tuple((p.data_ptr(), p._version) for p in dm.parameters()) + tuple((b.data_ptr(), b._version) for b in dm.buffers()) \
+            + tuple((p.data_ptr(), p._version) for p in self.model.input_process.parameters())
+
+    def gcn(self):
+        key = self._param_key()
+        if self._gcn is None or key != self._gcn_key:
+            self._free()
+            m = self.model
+            dm = m.diffusion_model
+            keep = []
+
+            def params(gc, bn):
+                def t(x):
+                    x = _lib.f32(x, m.device)
+                    keep.append(x)
+                    return x.data_ptr()
+                p = _lib.GConvParams()
+                p.W, p.M, p.adj2, p.bias = t(gc.W), t(gc.M), t(gc.adj2), t(gc.bias)
+                if bn is not None:
+                    p.bn_weight, p.bn_bias, p.bn_mean, p.bn_var = t(bn.weight), t(bn.bias), t(bn.running_mean), t(bn.running_var)
+                p.in_dim, p.out_dim = gc.in_features, gc.out_features
+                return p
+
+            gi = dm.gconv_input[0]
+            inp = params(gi.gconv, gi.bn)
+            hidden = []
+            for blk in dm.gconv_layers:
+                hidden += [params(blk.gconv1.gconv, blk.gconv1.bn), params(blk.gconv2.gconv, blk.gconv2.bn)]
+            outp = params(dm.gconv_output, None)
+            arr = (_lib.GConvParams * len(hidden))(*hidden)
+            adj = _lib.f32(dm.adj, m.device)
+            h = C.c_void_p()
+            with torch.cuda.device(m.device):
+                _lib.check(_lib.lib().ehm_gcn_create(C.byref(h), _lib.ptr(adj), C.byref(inp), arr, len(hidden), C.byref(outp), dm.hid_dim,
+                                                     _lib.stream_ptr()), "ehm_gcn_create")
+            self._gcn, self._gcn_key = h, key
+            # fold InputProcess (Linear 6->512) into the x_t slice of the input conv: x @ (Wp^T W_k[2694:3206]) + bp W_k[...]
+            W = gi.gconv.W.detach().double()                                            # [2, 3718, hid]
+            Wp, bp = m.input_process.poseEmbedding.weight.detach().double(), m.input_process.poseEmbedding.bias.detach().double()
+            a, b, c, d = COND_SPLIT
+            Wx = torch.einsum("ec,kef->kcf", Wp, W[:, b:c, :])                          # [2,6,hid]
+            bx = torch.einsum("e,kef->kf", bp, W[:, b:c, :])                            # [2,hid]
+            self._folded = SimpleNamespace(Wx=Wx.float().contiguous(), bx=bx, W_img=gi.gconv.W.detach()[:, :a, :],
+                                           W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :])
+        return self._gcn
+
+    def _free(self):
+        if self._gcn is not None:
+            try:
+                _lib.lib().ehm_gcn_destroy(self._gcn)
+            except Exception:
+                pass
+            self._gcn = None
+
+    def __del__(self):
+        self._free()
+
+    # ------------------------------------------------------------------ step-invariant conditioning
+    @torch.no_grad()
+    def prepare(self, batch) -> _Prepared:
+        """Everything in EgoHMR.forward that does not depend on x_t / t (egohmr.py:182-223, :263-265)."""
+        m = self.model
+        key = (id(batch), batch["img"].data_ptr(), batch["scene_pcd_verts_full"].data_ptr(), self._param_key())
+        if self._prep is not None and self._prep_key == key:
+            return self._prep
+        self.gcn()
+        dev = m.device
+        g = lambda k: _lib.f32(batch[k], dev)
+        img_feats = m.backbone(g("img"))                                               # :183
+        transl = _lib.f32(batch["smpl_params"]["transl"], dev)
+        scene = g("scene_pcd_verts_full")
+        if m.scene_cano:
+            scene = scene - transl.unsqueeze(1)                                        # :211
+        scene = scene.contiguous()
+        scene_feats = m.scene_enc(scene)                                               # :214
+        transl_feat = m.transl_enc(transl)                                             # :217
+        fx, cx, cy = g("fx"), g("cam_cx"), g("cam_cy")
+        ofx = fx * m.cfg.CAM.FX_NORM_COEFF
+        bc, bs = g("box_center"), g("box_size")
+        cam = torch.cat([torch.stack([cx / ofx, cy / ofx], -1), torch.stack([bc[:, 0] / ofx, bc[:, 1] / ofx, bs / ofx], -1),
+                         fx.unsqueeze(1)], dim=1)                                      # :195-205
+        other = torch.cat([scene_feats, transl_feat, cam], dim=1)                      # :220-221
+        vis = m.visibility({"orig_keypoints_2d": batch["orig_keypoints_2d"].to(dev)})
+        f = self._folded
+        h_img = torch.einsum("bi,kio->bko", img_feats, f.W_img).contiguous()           # [B,2,hid]
+        h_oth = torch.einsum("bi,kio->bko", other, f.W_oth).contiguous()
+        betas = m.beta_layer(torch.cat([img_feats, other], dim=1)).contiguous()        # :263-265
+        self._prep = _Prepared(B=img_feats.shape[0], h_img=h_img, h_oth=h_oth, vis=vis.to(torch.uint8).contiguous(), vis_bool=vis,
+                               betas=betas, scene=scene, transl=transl, fx=fx, cam_cx=cx, cam_cy=cy, img_feats=img_feats,
+                               scene_feats=scene_feats)
+        self._prep_key = key
+        return self._prep
+
+    @torch.no_grad()
+    def timestep_vectors(self, t_orig: torch.Tensor) -> torch.Tensor:
+        """[n] original timesteps -> [n,2,hid]: TimestepEmbedder (egohmr.py:642-643) pushed through the timestep
+        slice of the input conv, plus the folded InputProcess bias."""
+        m = self.model
+        self.gcn()
+        temb = m.embed_timestep.time_embed(m.sequence_pos_encoder.pe[t_orig][:, 0])    # [n,512]
+        tv = torch.einsum("ne,kef->nkf", temb.double(), self._folded.W_t) + self._folded.bx[None]
+        return tv.float().contiguous()
+
+    # ------------------------------------------------------------------ granular denoiser (EgoHMR.forward)
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    @torch.no_grad()
+    def denoise_once(self, st, x_t, tvec, passes):
+        m, L = self.model, _lib.lib()
+        hid, B = m.diffusion_model.hid_dim, st.B
+        tile = L.ehm_gcn_row_tile()
+        rows = passes * B * 24
+        rows_pad = (rows + tile - 1) // tile * tile
+        X = [torch.zeros(rows_pad, hid, device=m.device) for _ in range(3)]
+        s = _lib.stream_ptr()
+        h = self.gcn()
+        _lib.check(L.ehm_gcn_input_layer(h, _lib.ptr(st.h_img), _lib.ptr(st.h_oth), _lib.ptr(st.vis), _lib.ptr(x_t), _lib.ptr(self._folded.Wx),
+                                         _lib.ptr(tvec), _lib.ptr(X[0]), B, passes, s), "ehm_gcn_input_layer")
+        cur = 0
+        for blk in range(m.diffusion_model.num_layers):
+            y1, y2 = 1, (2 if cur == 0 else 0)
+            _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk, _lib.ptr(X[cur]), None, _lib.ptr(X[y1]), rows_pad, s), "ehm_gcn_hidden_layer")
+            _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk + 1, _lib.ptr(X[y1]), _lib.ptr(X[cur]), _lib.ptr(X[y2]), rows_pad, s), "ehm_gcn_hidden_layer")
+            cur = y2
+        x0 = torch.empty(B, 144, device=m.device)
+        _lib.check(L.ehm_gcn_output_layer(h, _lib.ptr(X[cur]), _lib.ptr(st.vis), _lib.ptr(x0), B, passes, s), "ehm_gcn_output_layer")
+        self.last_hidden = X[cur][:rows]
+        return x0
+
+    # ------------------------------------------------------------------ guidance pieces
+    @torch.no_grad()
+    def collision(self, verts, scene, want_grad=True):
+        m, L = self.model, _lib.lib()
+        verts, scene = _lib.f32(verts, m.device), _lib.f32(scene, m.device)
+        B, V, N = verts.shape[0], verts.shape[1], scene.shape[1]
+        loss = torch.empty(B, device=m.device)
+        gverts = torch.empty_like(verts)
+        _lib.check(L.ehm_collision_proxy(_lib.ptr(verts), _lib.ptr(scene), _lib.ptr(loss), _lib.ptr(gverts), B, V, N, m.collision_tau,
+                                         _lib.stream_ptr()), "ehm_collision_proxy")
+        return (loss, gverts) if want_grad else (loss, self._hits(verts, scene))
+
+    def _hits(self, verts, scene):
+        # number of bbox-selected scene points within tau of the surface (post-loop metric, off the sampling path)
+        out = []
+        for v, s in zip(verts, scene):
+            inside = ((s >= v.min(0).values) & (s <= v.max(0).values)).all(-1)
+            pts = s[inside]
+            out.append((torch.cdist(pts, v).min(dim=1).values < self.model.collision_tau).sum() if pts.numel() else pts.new_zeros(()))
+        return torch.stack(out).float()
+
+    @torch.no_grad()
+    def guidance_gradient(self, st, x, betas):
+        m, L = self.model, _lib.lib()
+        B = x.shape[0]
+        mean, std = m._std_mean()
+        verts = torch.empty(B, m.smpl.num_verts, 3, device=m.device)
+        joints = torch.empty(B, m.smpl.num_joints_out, 3, device=m.device)
+        s = _lib.stream_ptr()
+        _lib.check(L.ehm_smpl_forward_rot6d(m.smpl.handle(), _lib.ptr(betas), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(verts),
+                                            _lib.ptr(joints), None, None, None, B, s), "ehm_smpl_forward_rot6d")
+        loss, gverts = self.collision(verts, st.scene)
+        gpose = torch.empty(B, 144, device=m.device)
+        _lib.check(L.ehm_smpl_backward_rot6d(m.smpl.handle(), _lib.ptr(betas), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(gverts),
+                                             _lib.ptr(gpose), B, s), "ehm_smpl_backward_rot6d")
+        grad = torch.empty(B, 144, device=m.device)
+        denom = float(B) if m.guide_reduction == "mean" else 1.0
+        _lib.check(L.ehm_guidance_grad_finish(_lib.ptr(gpose), _lib.ptr(loss), _lib.ptr(grad), B, denom, s), "ehm_guidance_grad_finish")
+        return grad
+
+    # ------------------------------------------------------------------ whole loop
+    @torch.no_grad()
+    def run(self, diffusion, batch, noise_stack, ddim=False, guided=False, cond_grad_weight=1.0, trace=False, prepared=None):
+        """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
+        Returns the reference's dict(sample, pred_xstart, other_outputs)."""
+        m, L = self.model, _lib.lib()
+        st = prepared if prepared is not None else self.prepare(batch)
+        B, T, hid, V = st.B, diffusion.num_timesteps, m.diffusion_model.hid_dim, m.smpl.num_verts
+        noise = _lib.f32(noise_stack, m.device)
+        assert noise.shape[0] >= T + 1 and noise.shape[1] == B and noise.shape[2] == 144, noise.shape
+        steps = (_lib.StepCoefs * T)(*[diffusion.step_coefs(i, ddim, 0.0, cond_grad_weight, guided) for i in range(T - 1, -1, -1)])
+        any_guided = any(s.grad_scale != 0.0 for s in steps)
+        tmap = torch.tensor([diffusion.timestep_map[i] for i in range(T - 1, -1, -1)], device=m.device, dtype=torch.long)
+        tvecs = self.timestep_vectors(tmap)                                            # [T,2,hid]
+        desc = _lib.SampleDesc(B=B, passes=2 if m.diffuse_fuse else 1, num_steps=T, ddim=int(ddim),
+                               lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
+                               guide_denom=float(B) if m.guide_reduction == "mean" else 1.0, tau=m.collision_tau)
+        nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
+        if nbytes < 0:
+            raise _lib.EgoHMRHipError(f"ehm_sample_workspace_bytes rejected the descriptor (rc={nbytes})")
+        ws = self._workspace(nbytes, m.device)
+        dev = m.device
+        x_final, x0 = torch.empty(B, 144, device=dev), torch.empty(B, 144, device=dev)
+        verts, joints = torch.empty(B, V, 3, device=dev), torch.empty(B, m.smpl.num_joints_out, 3, device=dev)
+        R, pose6d = torch.empty(B, 24, 3, 3, device=dev), torch.empty(B, 144, device=dev)
+        tr = torch.empty(T, B, 144, device=dev) if trace else None
+        mean, std = m._std_mean()
+        with torch.cuda.device(dev):
+            _lib.check(L.ehm_sample_loop(self.gcn(), m.smpl.handle(), C.byref(desc), steps, _lib.ptr(st.h_img), _lib.ptr(st.h_oth),
+                                         _lib.ptr(st.vis), _lib.ptr(self._folded.Wx), _lib.ptr(tvecs), _lib.ptr(noise),
+                                         _lib.ptr(st.scene) if any_guided else None, _lib.ptr(st.betas), _lib.ptr(mean), _lib.ptr(std),
+                                         _lib.ptr(x_final), _lib.ptr(x0), _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(R), _lib.ptr(pose6d),
+                                         _lib.ptr(tr), _lib.ptr(ws), nbytes, _lib.stream_ptr()), "ehm_sample_loop")
+        self.last_trace = tr
+        if tr is not None:
+            batch["x_t"] = tr[-1]
+        batch["vis_mask_smpl"] = st.vis_bool
+        out = m._pack_output(batch, st, x0, pose6d, R, verts, joints)
+        return {"sample": x_final, "pred_xstart": x0, "other_outputs": out}

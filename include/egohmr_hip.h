@@ -1,0 +1,199 @@
+/*
+ * egohmr_hip.h - C ABI of libegohmr_hip.so: the MI355X (gfx950) kernels of the EgoHMR stage-2
+ * diffusion-sampling hot path.
+ *
+ * The reference (sanweiliti/EgoHMR) is single-process eager PyTorch and has NO FFI boundary of
+ * its own.  Each entry point below therefore names the reference Python
+ * interface (file:line under /root/reference) whose arithmetic it replaces; the Python host side
+ * (egohmr_amd/) keeps those interfaces' names and calls in here through ctypes.
+ *
+ * Conventions
+ *   - every `const float*` / `float*` is a DEVICE pointer, float32, contiguous row-major, owned by
+ *     the caller, unless the parameter comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     stream-ordered, never synchronises and never allocates after *_create, so a sequence of
+ *     calls may be captured into a hipGraph;
+ *   - return value: 0 on success, negative on error (-22 bad argument, -12 out of memory,
+ *     -5 HIP runtime error).  ehm_last_error() returns a thread-local description;
+ *   - handles are opaque; create/destroy are host-synchronous.
+ */
+#ifndef EGOHMR_HIP_H
+#define EGOHMR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EHM_NUM_JOINTS 24
+#define EHM_NUM_BETAS 10
+#define EHM_POSE_DIM 144 /* 24 joints x 6-D rotation */
+
+const char* ehm_last_error(void);
+/* compile-time facts, for the loader's sanity check: returns "gfx950" */
+const char* ehm_target_arch(void);
+
+/* ------------------------------------------------------------------ geometry ------------------ */
+/* utils/geometry.py:47-66 rot6d_to_rotmat(x, rot6d_mode).  x6d [n,6] -> R [n,3,3].
+ * mode 0 = 'prohmr' (a1 = x[0:3], a2 = x[3:6]); 1 = 'diffusion' (a1 = x[0::2], a2 = x[1::2]). */
+int ehm_rot6d_to_rotmat(const float* x6d, float* R, int64_t n, int mode, void* stream);
+/* vector-Jacobian product of the above (autograd of geometry.py:47-66 as used under
+ * torch.enable_grad() in models/egohmr/egohmr.py:518-529): gR [n,3,3] -> gx [n,6]. */
+int ehm_rot6d_to_rotmat_bwd(const float* x6d, const float* gR, float* gx, int64_t n, int mode, void* stream);
+
+/* ------------------------------------------------------------------ SMPL body model ----------- */
+typedef struct ehm_smpl ehm_smpl;
+
+/* smplx.create('data/smpl', model_type='smpl', ...) (models/egohmr/egohmr.py:105-107): uploads /
+ * re-packs the model constants.  v_template [V,3], shapedirs [V,3,10], posedirs [207,V*3],
+ * J_regressor [24,V], lbs_weights [V,24] are device pointers (smplx buffer layouts);
+ * parents [24] and extra_joint_vertex_ids [n_extra] are HOST int32 arrays. */
+int ehm_smpl_create(ehm_smpl** out, const float* v_template, const float* shapedirs, const float* posedirs,
+                    const float* J_regressor, const float* lbs_weights, const int32_t* parents,
+                    const int32_t* extra_joint_vertex_ids, int num_verts, int n_extra, void* stream);
+void ehm_smpl_destroy(ehm_smpl* h);
+
+/* smplx SMPL.forward(betas, body_pose, global_orient, pose2rot=False) as called at
+ * models/egohmr/egohmr.py:276,492,537 and test_egohmr.py:291.
+ * betas [B,10]; rotmats [B,24,3,3] (global_orient then body_pose); verts [B,V,3];
+ * joints [B,24+n_extra,3]; A_out (may be NULL) [B,24,3,4] = the skinning transforms. */
+int ehm_smpl_forward(ehm_smpl* h, const float* betas, const float* rotmats, float* verts, float* joints,
+                     float* A_out, int B, void* stream);
+
+/* egohmr.py:258-260 + :276 fused: x [B,144] (normalised 6-D pose), pose6d = x*std+mean,
+ * R = rot6d_to_rotmat(pose6d,'diffusion'), then SMPL.forward.  mean/std [144]; R_out (may be NULL)
+ * [B,24,3,3]; pose6d_out (may be NULL) [B,144]. */
+int ehm_smpl_forward_rot6d(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std,
+                           float* verts, float* joints, float* R_out, float* pose6d_out, float* A_out, int B,
+                           void* stream);
+
+/* ------------------------------------------------------------------ Modulated-GCN denoiser ---- */
+/* One ModulatedGraphConv (+ optional BatchNorm1d) in the reference's parameter layout
+ * (models/egohmr/modulated_gcn/modulated_gcn_conv.py:16-37, modulated_gcn.py:12-13). */
+typedef struct {
+  const float* W;         /* [2, in_dim, out_dim] */
+  const float* M;         /* [24, out_dim]        */
+  const float* adj2;      /* [24, 24]             */
+  const float* bias;      /* [out_dim]            */
+  const float* bn_weight; /* [out_dim] or NULL (no BatchNorm/ReLU after this conv) */
+  const float* bn_bias;
+  const float* bn_mean;
+  const float* bn_var;
+  int in_dim;
+  int out_dim;
+} ehm_gconv_params;
+
+typedef struct ehm_gcn ehm_gcn;
+
+/* ModulatedGCN(adj, in_dim, hid_dim, out_dim=6, num_layers) (modulated_gcn.py:60-97) with the
+ * step-invariant part of the input conv hoisted (SURVEY.md section 0 finding 5):
+ *   adj        [24,24]  fixed adjacency (egohmr.py:86-93)
+ *   input_conv          epilogue parameters of gconv_input (its W is consumed by the caller's
+ *                       one-off projections, so .W may be NULL; in_dim is ignored)
+ *   hidden              2*num_blocks convs hid->hid, order gconv_layers.{b}.gconv1, gconv2
+ *   output_conv         hid->6, no batch norm
+ * HOST array of structs holding DEVICE pointers. */
+int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_params* input_conv,
+                   const ehm_gconv_params* hidden, int num_hidden, const ehm_gconv_params* output_conv,
+                   int hid_dim, void* stream);
+void ehm_gcn_destroy(ehm_gcn* h);
+
+/* rows of the activation matrices must be padded to a multiple of this many rows (zero-filled) */
+int ehm_gcn_row_tile(void);
+
+/* gconv_input (modulated_gcn.py:21-28 applied to egohmr.py:236/:245's concatenated feature) with
+ * the conditioning/timestep part pre-projected.  For virtual body vb = p*B + b (p = 0 conditional
+ * pass, p = 1 image-masked pass, egohmr.py:239-246), joint j, branch k (W[0] / W[1]):
+ *   pre_k = (p==0 ? vis[b,j] * h_img[b,k,:] : 0) + h_oth[b,k,:] + tvec[k,:] + x[b,j,0:6] @ Wx[k]
+ * then the modulated adjacency mix, bias, BatchNorm(eval), ReLU.
+ *   h_img, h_oth [B,2,hid]; vis [B,24] uint8; x [B,144]; Wx [2,6,hid]; tvec [2,hid];
+ *   out [rows_pad,hid], rows = passes*B*24. */
+int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x,
+                        const float* Wx, const float* tvec, float* out, int B, int passes, void* stream);
+
+/* _GraphConv hid->hid (modulated_gcn.py:21-28): out = ReLU(BN(mix(X W0, X W1))) [+ residual,
+ * modulated_gcn.py:42].  X, out, residual [rows_pad,hid]; residual may be NULL. */
+int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const float* residual, float* out,
+                         int64_t rows_pad, void* stream);
+
+/* gconv_output (modulated_gcn.py:113) + the visibility fuse of egohmr.py:247-256:
+ *   x0[b, j*6+c] = vis[b,j] ? out_cond[b,j,c] : out_uncond[b,j,c]      (passes == 2)
+ *   x0 = out_cond                                                      (passes == 1)
+ * X [rows_pad,hid] -> x0 [B,144]. */
+int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* vis, float* x0, int B, int passes,
+                         void* stream);
+
+/* ------------------------------------------------------------------ sampler steps ------------- */
+/* diffusion/gaussian_diffusion.py:217-220 + :333-336 (p_sample) and :378-385 (p_sample_with_grad):
+ *   mean = coef1*x0 + coef2*x  [+ grad_scale * grad]
+ *   x_next = mean + nonzero * exp(0.5*log_variance) * noise
+ * grad may be NULL.  All [B,144]; x_next may alias x. */
+int ehm_ddpm_step(const float* x, const float* x0, const float* noise, const float* grad, float* x_next,
+                  float coef1, float coef2, float log_variance, float nonzero, float grad_scale, int64_t n,
+                  void* stream);
+/* gaussian_diffusion.py:286-290 + :539-555 (ddim_sample):
+ *   eps = (sqrt_recip_ac*x - x0) / sqrt_recipm1_ac
+ *   x_next = x0*sqrt_ac_prev + dir_coef*eps + nonzero*sigma*noise,  dir_coef = sqrt(1-ac_prev-sigma^2) */
+int ehm_ddim_step(const float* x, const float* x0, const float* noise, float* x_next, float sqrt_recip_ac,
+                  float sqrt_recipm1_ac, float sqrt_ac_prev, float dir_coef, float sigma, float nonzero,
+                  int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ collision guidance -------- */
+/* Build-defined proxy for smpl.coap.collision_loss (egohmr.py:555; COAP is unavailable offline,
+ * see DESIGN.md): with the bbox selection of egohmr.py:550-552,
+ *   loss[b] = sum over scene points p inside bbox(verts[b]) of relu(tau - min_v |p - v|)^2
+ * and gverts[b,v,:] = d(loss[b])/d(verts[b,v,:]).  scene [B,N,3] (already canonicalised,
+ * egohmr.py:211); loss [B]; gverts [B,V,3] (overwritten). */
+int ehm_collision_proxy(const float* verts, const float* scene, float* loss, float* gverts, int B, int V, int N,
+                        float tau, void* stream);
+
+/* VJP of ehm_smpl_forward_rot6d w.r.t. the DE-NORMALISED 6-D pose (the quirk of egohmr.py:523-528:
+ * autograd.grad is taken w.r.t. x_t*std+mean): gverts [B,V,3] -> gpose6d [B,144].
+ * Needs the forward's x/mean/std/betas again (recomputes the chain). */
+int ehm_smpl_backward_rot6d(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std,
+                            const float* gverts, float* gpose6d, int B, void* stream);
+
+/* egohmr.py:561-570: g = -(1/denom) * gpose6d (denom = B for loss.mean(), 1 for loss.sum()),
+ * joints 3..23 scaled by 2, joints {0,3,6,9,12..23} zeroed; all-zero loss -> zeros. */
+int ehm_guidance_grad_finish(const float* gpose6d, const float* loss, float* grad, int B, float denom, void* stream);
+
+/* ------------------------------------------------------------------ whole sampling loop ------- */
+/* One executed step of the loop (host-side table lookup already done, float32 like
+ * _extract_into_tensor, gaussian_diffusion.py:794). */
+typedef struct {
+  float coef1, coef2, log_variance, variance; /* DDPM */
+  float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_prev, dir_coef, sigma; /* DDIM */
+  float nonzero;   /* 0 at respaced index 0 */
+  float grad_scale; /* 0 = unguided step; else cond_grad_weight*variance or cond_grad_weight*0.01 */
+} ehm_step_coefs;
+
+typedef struct {
+  int B;              /* bodies                                                     */
+  int passes;         /* 2 = diffuse_fuse (conditional + image-masked pass), 1      */
+  int num_steps;      /* executed steps T                                           */
+  int ddim;           /* 0 = p_sample loop, 1 = ddim_sample loop (eta = 0)          */
+  int lbs_every_step; /* 1 = decode the body every step like EgoHMR.forward does    */
+  int num_scene_points; /* N (guidance only)                                        */
+  float guide_denom;  /* B for COAP-style loss.mean(), 1 for VolSMPL-style sum()    */
+  float tau;          /* collision proxy contact distance                          */
+} ehm_sample_desc;
+
+/* GaussianDiffusion.p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508, :618-718)
+ * around EgoHMR.forward's per-step part (egohmr.py:232-278), everything step-invariant hoisted:
+ *   steps [num_steps] HOST; tvecs [num_steps,2,hid] (timestep-embedding projection per step);
+ *   noise [num_steps+1,B,144] (row 0 = x_T); scene [B,N,3] or NULL; betas [B,10];
+ *   outputs: x_final [B,144], x0_final [B,144] (pred_x_start), verts [B,V,3], joints [B,45,3],
+ *   R [B,24,3,3], pose6d [B,144] of the LAST step; trace (may be NULL) [num_steps,B,144] = x_t fed
+ *   to each step.  workspace from ehm_sample_workspace_bytes(). */
+int64_t ehm_sample_workspace_bytes(const ehm_sample_desc* d, int hid_dim, int num_verts);
+int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_desc* d, const ehm_step_coefs* steps,
+                    const float* h_img, const float* h_oth, const uint8_t* vis, const float* Wx, const float* tvecs,
+                    const float* noise, const float* scene, const float* betas, const float* mean, const float* std,
+                    float* x_final, float* x0_final, float* verts, float* joints, float* R, float* pose6d,
+                    float* trace, void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOHMR_HIP_H */

@@ -76,9 +76,10 @@ def cpu_baseline(n, rs, num_scene_points, budget_s):
     on a bounded sample: B=8 items, as many leading steps of the same schedule as fit the time budget."""
     from egohmr_amd import synthetic as syn
     from oracle import model as om, schedule as osched
-    cores = os.cpu_count() or 1
+    # eager torch-CPU on small batches is fastest at 16 threads on the MI355X host (measured 16/32/64: 0.28/0.20/0.10 bodies/s); use what helps and report it
+    cores = int(os.environ.get("EGOHMR_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
-    B = 8
+    B = 4
     sd, asset = syn.make_state_dict(0), syn.make_smpl_asset(0)
     mean, std = syn.make_body_rep_stats(0)
     ref = om.EgoHMROracle(sd, asset, mean, std, faithful=True)

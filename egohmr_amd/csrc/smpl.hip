@@ -84,14 +84,18 @@ __global__ void joint_basis_kernel(const float* __restrict__ Jr, const float* __
 
 // ------------------------------------------------------------------------------------------------ rot6d
 __device__ __forceinline__ void rot6d_to_R(float a1x, float a1y, float a1z, float a2x, float a2y, float a2z, float (&R)[9]) {
-  // utils/geometry.py:61-66; F.normalize = x / max(||x||_2, 1e-12)
-  float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
-  float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
-  float d = b1x * a2x + b1y * a2y + b1z * a2z;
-  float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
-  float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
-  float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
-  float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+  // utils/geometry.py:61-66; F.normalize = x / max(||x||_2, 1e-12).  Every product / sum is rounded separately
+  // (no FMA contraction) like the eager torch ops, so the cancellation in a2 - (b1.a2) b1 for nearly parallel
+  // a1, a2 behaves as in the reference.
+  const float n1 = fmaxf(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(a1x, a1x), __fmul_rn(a1y, a1y)), __fmul_rn(a1z, a1z))), 1e-12f);
+  const float b1x = __fdiv_rn(a1x, n1), b1y = __fdiv_rn(a1y, n1), b1z = __fdiv_rn(a1z, n1);
+  const float d = __fadd_rn(__fadd_rn(__fmul_rn(b1x, a2x), __fmul_rn(b1y, a2y)), __fmul_rn(b1z, a2z));
+  const float ux = __fsub_rn(a2x, __fmul_rn(d, b1x)), uy = __fsub_rn(a2y, __fmul_rn(d, b1y)), uz = __fsub_rn(a2z, __fmul_rn(d, b1z));
+  const float n2 = fmaxf(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz))), 1e-12f);
+  const float b2x = __fdiv_rn(ux, n2), b2y = __fdiv_rn(uy, n2), b2z = __fdiv_rn(uz, n2);
+  const float b3x = __fsub_rn(__fmul_rn(b1y, b2z), __fmul_rn(b1z, b2y));
+  const float b3y = __fsub_rn(__fmul_rn(b1z, b2x), __fmul_rn(b1x, b2z));
+  const float b3z = __fsub_rn(__fmul_rn(b1x, b2y), __fmul_rn(b1y, b2x));
   R[0] = b1x; R[1] = b2x; R[2] = b3x;
   R[3] = b1y; R[4] = b2y; R[5] = b3y;
   R[6] = b1z; R[7] = b2z; R[8] = b3z;

@@ -31,7 +31,7 @@ class EgoHMRHipError(RuntimeError):
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "smpl_dev.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

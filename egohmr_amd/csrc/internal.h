@@ -1,0 +1,22 @@
+// Cross-translation-unit internals of libegohmr_hip (not part of the C ABI).
+#pragma once
+#include "common.h"
+#include "egohmr_hip.h"
+
+// smpl.hip
+int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x, bool from_rot6d, const float* mean,
+                          const float* std_, float* verts, float* joints, float* Rws, float* Aws, float* pose6d_out, int B,
+                          hipStream_t st);
+// rot6d -> R, joint regression, kinematic chain only (no skinning): R [B,24,9], A [B,24,12], joints24 into jws [B,(24+n_extra),3]
+int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_, float* Rws, float* Aws,
+                       float* jws, int B, hipStream_t st);
+int ehm_smpl_num_verts(const ehm_smpl* h);
+int ehm_smpl_num_extra(const ehm_smpl* h);
+// gcn.hip
+int ehm_gcn_hid(const ehm_gcn* h);
+int ehm_gcn_num_hidden(const ehm_gcn* h);
+// guidance.hip
+int64_t ehm_guidance_scratch_bytes(int B, int N);
+int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
+                      const float* scene, int B, int N, float tau, float denom, float* verts_ws, float* joints_ws, float* R_ws,
+                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st);

@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "egohmr_hip.h"
+#include "internal.h"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -22,17 +23,6 @@ void ehm_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ehm_last_error(void) { return g_err; }
 extern "C" const char* ehm_target_arch(void) { return "gfx950"; }
-
-int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x, bool from_rot6d, const float* mean,
-                          const float* std_, float* verts, float* joints, float* Rws, float* Aws, float* pose6d_out, int B,
-                          hipStream_t st);
-int ehm_smpl_num_verts(const ehm_smpl* h);
-int ehm_smpl_num_extra(const ehm_smpl* h);
-int ehm_gcn_hid(const ehm_gcn* h);
-int ehm_gcn_num_hidden(const ehm_gcn* h);
-int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
-                      const float* scene, int B, int N, float tau, float denom, float* verts_ws, float* joints_ws, float* R_ws,
-                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, hipStream_t st);
 
 namespace {
 
@@ -95,6 +85,7 @@ struct Workspace {
   float* g_loss;       // [B]
   float* g_gpose;      // [B,144]
   float* g_grad;       // [B,144]
+  void* g_scratch;     // bbox / selection / dA / dpose-feature (guidance.hip)
   int64_t rows, rows_pad;
   int64_t total_bytes;
 };
@@ -122,6 +113,7 @@ Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* ba
     w.g_loss = take(d->B);
     w.g_gpose = take((int64_t)d->B * kPoseDim);
     w.g_grad = take((int64_t)d->B * kPoseDim);
+    w.g_scratch = take(ehm_guidance_scratch_bytes(d->B, d->num_scene_points) / 4 + 64);
   }
   w.total_bytes = off;
   return w;
@@ -179,7 +171,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     const float* grad = nullptr;
     if (rc == 0 && c.grad_scale != 0.f) {
       rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom,
-                             w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, st);
+                             w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, w.g_scratch, st);
       grad = w.g_grad;
     }
     // ---- x_{t-1} ----

@@ -20,31 +20,10 @@
 // HBM traffic per body-step: 82.7 KB vertices out (+ ~1.5 KB small tensors); shared constants 19.3 MB per launch.
 #include "common.h"
 #include "egohmr_hip.h"
+#include "internal.h"
+#include "smpl_dev.h"
 
 namespace {
-
-constexpr int kBG = 8;       // bodies per skinning block
-constexpr int kVT = 256;     // vertices per skinning block
-constexpr int kPoseBasis = 207;
-
-struct Tree {
-  int8_t parent[kJ];
-  int8_t depth[kJ];
-  int max_depth;
-};
-
-struct SmplDev {
-  int V;
-  int n_extra;
-  float* v_template;   // [V*3]
-  float* shape_t;      // [10][V*3]   shapedirs transposed (basis-major like posedirs)
-  const float* posedirs;  // [207][V*3] caller-owned (smplx layout already streams well)
-  float* w_t;          // [24][V]     lbs_weights transposed
-  float* J_template;   // [24][3]     J_regressor . v_template
-  float* J_shape;      // [24][3][10] J_regressor . shapedirs
-  int32_t* extra_idx;  // [n_extra]
-  Tree tree;
-};
 
 // ------------------------------------------------------------------------------------------------ setup
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
@@ -83,24 +62,6 @@ __global__ void joint_basis_kernel(const float* __restrict__ Jr, const float* __
 }
 
 // ------------------------------------------------------------------------------------------------ rot6d
-__device__ __forceinline__ void rot6d_to_R(float a1x, float a1y, float a1z, float a2x, float a2y, float a2z, float (&R)[9]) {
-  // utils/geometry.py:61-66; F.normalize = x / max(||x||_2, 1e-12).  Every product / sum is rounded separately
-  // (no FMA contraction) like the eager torch ops, so the cancellation in a2 - (b1.a2) b1 for nearly parallel
-  // a1, a2 behaves as in the reference.
-  const float n1 = fmaxf(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(a1x, a1x), __fmul_rn(a1y, a1y)), __fmul_rn(a1z, a1z))), 1e-12f);
-  const float b1x = __fdiv_rn(a1x, n1), b1y = __fdiv_rn(a1y, n1), b1z = __fdiv_rn(a1z, n1);
-  const float d = __fadd_rn(__fadd_rn(__fmul_rn(b1x, a2x), __fmul_rn(b1y, a2y)), __fmul_rn(b1z, a2z));
-  const float ux = __fsub_rn(a2x, __fmul_rn(d, b1x)), uy = __fsub_rn(a2y, __fmul_rn(d, b1y)), uz = __fsub_rn(a2z, __fmul_rn(d, b1z));
-  const float n2 = fmaxf(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ux, ux), __fmul_rn(uy, uy)), __fmul_rn(uz, uz))), 1e-12f);
-  const float b2x = __fdiv_rn(ux, n2), b2y = __fdiv_rn(uy, n2), b2z = __fdiv_rn(uz, n2);
-  const float b3x = __fsub_rn(__fmul_rn(b1y, b2z), __fmul_rn(b1z, b2y));
-  const float b3y = __fsub_rn(__fmul_rn(b1z, b2x), __fmul_rn(b1x, b2z));
-  const float b3z = __fsub_rn(__fmul_rn(b1x, b2y), __fmul_rn(b1y, b2x));
-  R[0] = b1x; R[1] = b2x; R[2] = b3x;
-  R[3] = b1y; R[4] = b2y; R[5] = b3y;
-  R[6] = b1z; R[7] = b2z; R[8] = b3z;
-}
-
 __global__ void rot6d_kernel(const float* __restrict__ x, float* __restrict__ Rout, int64_t n, int mode) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -294,13 +255,6 @@ __global__ void extra_joints_kernel(const float* __restrict__ verts, const int32
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
-struct ehm_smpl {
-  SmplDev d{};
-  float* arena = nullptr;      // packed constants
-  float* ws = nullptr;         // per-call scratch: R [cap,24,9] + A [cap,24,12]
-  int ws_cap = 0;
-};
-
 static int smpl_scratch(ehm_smpl* h, int B) {
   if (B <= h->ws_cap) return 0;
   if (h->ws) (void)hipFree(h->ws);
@@ -397,6 +351,15 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
   if (d.n_extra)
     hipLaunchKernelGGL(extra_joints_kernel, dim3((unsigned)ceil_div((int64_t)B * d.n_extra * 3, 256)), dim3(256), 0, st, verts,
                        d.extra_idx, joints, B, d.V, d.n_extra);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_, float* Rws, float* Aws,
+                       float* jws, int B, hipStream_t st) {
+  const SmplDev& d = h->d;
+  hipLaunchKernelGGL(pose_chain_kernel<true>, dim3(B), dim3(64), 0, st, betas, x, mean, std_, d, Rws, Aws, jws, (float*)nullptr,
+                     (kJ + d.n_extra) * 3);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -609,8 +609,9 @@ extern "C" int ehm_guidance_grad_finish(const float* gpose6d, const float* loss,
 }
 
 extern "C" int ehm_rot6d_to_rotmat_bwd(const float* x6d, const float* gR, float* gx, int64_t n, int mode, void* stream) {
-  EHM_CHECK_ARG(x6d && gR && gx && n >= 0 && (mode == 0 || mode == 1));
+  EHM_CHECK_ARG(n >= 0 && (mode == 0 || mode == 1));
   if (n == 0) return 0;
+  EHM_CHECK_ARG(x6d && gR && gx);
   hipLaunchKernelGGL(rot6d_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x6d, gR, gx, n, mode);
   EHM_LAUNCH_CHECK();
   return 0;

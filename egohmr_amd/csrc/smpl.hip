@@ -387,8 +387,9 @@ extern "C" int ehm_smpl_forward_rot6d(ehm_smpl* h, const float* betas, const flo
 }
 
 extern "C" int ehm_rot6d_to_rotmat(const float* x6d, float* R, int64_t n, int mode, void* stream) {
-  EHM_CHECK_ARG(x6d && R && n >= 0 && (mode == 0 || mode == 1));
-  if (n == 0) return 0;
+  EHM_CHECK_ARG(n >= 0 && (mode == 0 || mode == 1));
+  if (n == 0) return 0;   // empty batch: nothing to do, pointers may be null
+  EHM_CHECK_ARG(x6d && R);
   hipLaunchKernelGGL(rot6d_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x6d, R, n, mode);
   EHM_LAUNCH_CHECK();
   return 0;

@@ -96,8 +96,10 @@ def test_smpl_backward_vs_autograd(dev, model, smpl_asset, B):
     (smpl64(betas=betas.double(), body_pose=R[:, 1:], global_orient=R[:, [0]]).vertices * gv.double()).sum().backward()
     out = torch.empty(B, 144, device=dev)
     L = _lib.lib()
-    _lib.check(L.ehm_smpl_backward_rot6d(model.smpl.handle(), betas.to(dev).data_ptr(), x.to(dev).data_ptr(), mean.to(dev).data_ptr(),
-                                         std.to(dev).data_ptr(), gv.to(dev).contiguous().data_ptr(), out.data_ptr(), B, None))
+    d_betas, d_x, d_mean, d_std, d_gv = (t.to(dev).contiguous() for t in (betas, x, mean, std, gv))   # keep alive across the call
+    _lib.check(L.ehm_smpl_backward_rot6d(model.smpl.handle(), d_betas.data_ptr(), d_x.data_ptr(), d_mean.data_ptr(),
+                                         d_std.data_ptr(), d_gv.data_ptr(), out.data_ptr(), B, None))
+    torch.cuda.synchronize()
     ref = p6.grad.float().numpy()
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-3)
 

@@ -33,11 +33,22 @@ WORKLOADS = {
     "c1_ddim5": (50, "ddim5", "BASELINE config 1 shape: DDIM-5 of 50"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (~2.5 PFLOP/s)
 
 
 def hidden_layer_flops(virtual_bodies: int, hid: int) -> float:
     """per body-pass and hidden conv 24*2*hid^2 MAC (W0,W1) + 24*24*hid MAC (adjacency mix)."""
     return virtual_bodies * (24 * 2 * hid * hid + 24 * 24 * hid) * 2.0
+
+
+def pmc_traffic(precision):
+    """HBM-side bytes per launch of the dominant kernel, from the last committed rocprofv3 --pmc passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/pmc_traffic.json); None when no pass exists."""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(precision, {}).get("bytes_per_launch")
+    except OSError:
+        return None
 
 
 def time_dominant_kernel(model, B, passes, reps=5):
@@ -52,6 +63,10 @@ def time_dominant_kernel(model, B, passes, reps=5):
     X = torch.randn(rows_pad, hid, device=model.device, generator=g)
     Y1, Y2 = torch.empty_like(X), torch.empty_like(X)
     h = model.fused_sampler.gcn()
+    if model.gcn_precision != "f32":     # split-f16 modes exchange activations in the X2 format
+        X2 = torch.empty_like(X)
+        _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, _lib.stream_ptr()))
+        X = X2
     nl = 2 * model.diffusion_model.num_layers
     s = _lib.stream_ptr()
 
@@ -117,6 +132,8 @@ def main():
     ap.add_argument("--scene-points", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-lbs-every-step", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("EGOHMR_GCN_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16"],
+                    help="arithmetic of the hidden GCN convs (DESIGN.md 3.2): f32 MFMA | split-f16 MFMA (f32-grade) | plain f16 (not parity-grade)")
     args = ap.parse_args()
 
     from egohmr_amd import dist as edist
@@ -134,6 +151,7 @@ def main():
     B, N = args.batch, args.scene_points
     model = build_synthetic_model(dev, 0, diffuse_fuse=True)
     model.lbs_every_step = not args.no_lbs_every_step
+    model.gcn_precision = args.precision
     diffusion = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
     T = diffusion.num_timesteps
     batch = batch_to_device(syn.make_batch(B, N, seed=100 + rank), dev)            # inputs resident in HBM before timing
@@ -162,6 +180,24 @@ def main():
     assert torch.isfinite(res["other_outputs"]["pred_vertices"]).all()
     assert gathered.shape == (world * B, edist.PACKED_WIDTH)
 
+    # reference leg: the same job with the hidden convs on the f32-input MFMA (exact f32 products), one call, rank-local
+    f32_leg = None
+    if args.precision != "f32" and world == 1:
+        model.gcn_precision = "f32"
+        one_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_step()
+        torch.cuda.synchronize()
+        f32_dt = time.perf_counter() - t1
+        kd, _ = time_dominant_kernel(model, B, 2)
+        fl = hidden_layer_flops(2 * B, model.diffusion_model.hid_dim)
+        f32_leg = {"value": B / f32_dt, "unit": "bodies/s", "ms_per_step": f32_dt * 1e3,
+                   "roofline": {"bound": "mfma", "kernel": "gcn_hidden_kernel (f32-input MFMA)", "achieved": fl / kd / 1e12,
+                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / kd / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                "avg_launch_ms": kd * 1e3}}
+        model.gcn_precision = args.precision
+
     # split of one call (rank 0, informative)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -176,6 +212,10 @@ def main():
         hid = model.diffusion_model.hid_dim
         flops = hidden_layer_flops(passes * B, hid)
         achieved = flops / k_dur / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
+        kname = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue)",
+                 "f16x3": "gcn_hidden_f16_kernel<3> (split-f16 MFMA, 3 MFMA per algorithmic product, f32 accumulate, same fused epilogue)",
+                 "f16": "gcn_hidden_f16_kernel<1> (plain f16 MFMA, f32 accumulate, same fused epilogue)"}[args.precision]
         out = {
             "metric": "sampled bodies/sec (100-step DDPM, batch 256)" if args.workload == "ddpm100" else f"sampled bodies/sec ({args.workload})",
             "value": world * B * args.steps / dt,
@@ -187,19 +227,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"f32": "f32", "f16x3": "f32 (denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands, f32 accumulate)",
+                      "f16": "f16 denoiser GEMMs (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": 1, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
-                       "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
+                       "gcn_precision": args.precision, "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
                        "parallelism": f"items sharded x{world}, one RCCL all-gather of [B,226] at the end"},
-            "roofline": {"bound": "mfma", "kernel": "gcn_hidden_kernel (f32 MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": k_dur * 1e3, "flops_per_launch": flops,
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "mfma_flops_per_algorithmic_flop": 3 if args.precision == "f16x3" else 1,
+                         "traffic": pmc_traffic(args.precision), "avg_launch_ms": k_dur * 1e3, "flops_per_launch": flops,
                          "formula": "virtual_bodies*(24*2*hid^2 + 24*24*hid)*2, virtual_bodies = passes*B (SURVEY 8d, hoisted)"},
             "breakdown_ms": {"encoders_and_projections_once": t_enc * 1e3, "per_call_total": dt / args.steps * 1e3,
                              "hidden_convs_est": k_dur * 1e3 * 2 * model.diffusion_model.num_layers * T},
         }
+        out["f32_mfma_path"] = f32_leg
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, rs, N, args.cpu_seconds)
         else:

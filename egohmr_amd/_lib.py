@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_f16.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -31,7 +31,7 @@ class EgoHMRHipError(RuntimeError):
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "smpl_dev.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "smpl_dev.h"), os.path.join(CSRC, "gcn_dev.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -79,6 +79,11 @@ PROTOTYPES = {
     "ehm_gcn_create": (_I, [C.POINTER(_P), _P, C.POINTER(GConvParams), C.POINTER(GConvParams), _I, C.POINTER(GConvParams), _I, _P]),
     "ehm_gcn_destroy": (None, [_P]),
     "ehm_gcn_row_tile": (_I, []),
+    "ehm_gcn_set_precision": (_I, [_P, _I]),
+    "ehm_gcn_get_precision": (_I, [_P]),
+    "ehm_gcn_set_tile_override": (_I, [_P, _I]),
+    "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _P]),
+    "ehm_gcn_unpack_activations": (_I, [_P, _P, _L, _I, _P]),
     "ehm_gcn_input_layer": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ehm_gcn_hidden_layer": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),

@@ -18,33 +18,10 @@
 //   * BatchNorm is folded into per-channel scale/shift, the adjacency is symmetrised once.
 #include "common.h"
 #include "egohmr_hip.h"
+#include "gcn_dev.h"
+#include "internal.h"
 
 namespace {
-
-constexpr int BM = 192;   // rows per block = 8 bodies x 24 joints
-constexpr int BNH = 64;   // output channels per block (x2: W0 and W1 branch)
-constexpr int BK = 32;    // K tile (128 B per row)
-constexpr int A_TILE = BM * BK;        // floats
-constexpr int B_TILE = 2 * BNH * BK;   // floats
-constexpr int STAGE = A_TILE + B_TILE; // 10240 floats = 40 KiB
-
-struct LayerDev {
-  float* Wp;     // [N/64][128][K]   packed W0|W1 columns, K contiguous
-  float* D;      // [24][N]  A[j][j] * M[j][n] * scale[n]
-  float* M1;     // [24][N]  M[j][n] * scale[n]
-  float* shift;  // [N]      (bias - mean) * scale + beta      (bias when no BN)
-  float* Aoff;   // [24][24] symmetrised adjacency, zero diagonal
-  int K, N;
-  int relu;
-};
-
-struct OutDev {
-  float* Wt;    // [12][K]  rows 0-5: W0 columns, rows 6-11: W1 columns
-  float* M;     // [24][6]
-  float* A;     // [24][24] symmetrised adjacency (diagonal kept)
-  float* bias;  // [6]
-  int K;
-};
 
 // ------------------------------------------------------------------------------------------------
 // parameter packing (runs once per model)
@@ -113,18 +90,26 @@ __global__ void pack_out_kernel(const float* __restrict__ adj, ehm_gconv_params 
 // ------------------------------------------------------------------------------------------------
 // shared epilogue: one lane = one output channel n of one body; h0/h1 = the 24 joints' W0/W1 responses
 // ------------------------------------------------------------------------------------------------
-// d0[j] = D[j][n]*h0[j] + shift[n] (diagonal branch, bias and BatchNorm folded), g1[j] = M1[j][n]*h1[j];
-// res[j] = residual input (already loaded, zeros when unused).
-__device__ __forceinline__ void gcn_mix_store(const float (&d0)[kJ], const float (&g1)[kJ], const float (&res)[kJ], int n, int N,
-                                              size_t row0, const float* __restrict__ Aoff, float* __restrict__ Y, bool relu) {
+__global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned int* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
-  for (int j = 0; j < kJ; ++j) {
-    float s = d0[j];
-#pragma unroll
-    for (int jp = 0; jp < kJ; ++jp) s = fmaf(Aoff[j * kJ + jp], g1[jp], s);  // Aoff: wave-uniform -> scalar loads
-    if (relu) s = fmaxf(s, 0.f);
-    Y[(row0 + j) * (size_t)N + n] = s + res[j];
-  }
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+}
+
+// Wp (f32, packed tiles) -> X2 split-f16 tiles scaled by `scale`; Ds/M1s = D/scale, M1/scale
+__global__ void pack_ws_kernel(const float* __restrict__ Wp, half_t* __restrict__ Ws, size_t rows, int K, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  split_store(Ws, i / K, (int)(i % K), K, Wp[i] * scale);
+}
+__global__ void scale_epilogue_kernel(const float* __restrict__ D, const float* __restrict__ M1, float* __restrict__ Ds,
+                                      float* __restrict__ M1s, int n, float inv_scale) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ds[i] = D[i] * inv_scale;
+  M1s[i] = M1[i] * inv_scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,14 +238,14 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_kernel(const float* __restr
     float d0[kJ], g1[kJ];
 #pragma unroll
     for (int j = 0; j < kJ; ++j) { d0[j] = acc0[j >> 4][j & 15]; g1[j] = acc1[j >> 4][j & 15]; }
-    gcn_mix_store(d0, g1, res0, n, N, rowb, L.Aoff, Y, L.relu != 0);
+    gcn_mix_store<false>(d0, g1, res0, n, N, rowb, L.Aoff, Y, L.relu != 0);
   }
   __builtin_amdgcn_sched_barrier(0);
   {
     float d0[kJ], g1[kJ];
 #pragma unroll
     for (int j = 0; j < kJ; ++j) { d0[j] = acc0[(24 + j) >> 4][(24 + j) & 15]; g1[j] = acc1[(24 + j) >> 4][(24 + j) & 15]; }
-    gcn_mix_store(d0, g1, res1, n, N, rowb + 24, L.Aoff, Y, L.relu != 0);
+    gcn_mix_store<false>(d0, g1, res1, n, N, rowb + 24, L.Aoff, Y, L.relu != 0);
   }
 }
 
@@ -268,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_kernel(const float* __restr
 // input conv with the step-invariant projections hoisted (see ehm_gcn_input_layer in the header)
 // one wave = one virtual body x 64 channels; 4 waves per block = 4 channel groups
 // ------------------------------------------------------------------------------------------------
+template <bool SPLIT_OUT>
 __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict__ h_img, const float* __restrict__ h_oth,
                                                         const uint8_t* __restrict__ vis, const float* __restrict__ x,
                                                         const float* __restrict__ Wx, const float* __restrict__ tvec,
@@ -305,7 +291,7 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
   float zero[kJ];
 #pragma unroll
   for (int j = 0; j < kJ; ++j) zero[j] = 0.f;
-  gcn_mix_store(h0, h1, zero, n, N, (size_t)vb * kJ, L.Aoff, Y, L.relu != 0);
+  gcn_mix_store<SPLIT_OUT>(h0, h1, zero, n, N, (size_t)vb * kJ, L.Aoff, Y, L.relu != 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,15 +352,6 @@ __global__ __launch_bounds__(256) void gcn_output_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-struct ehm_gcn {
-  int hid = 0;
-  int num_hidden = 0;
-  LayerDev input{};
-  LayerDev hidden[16]{};
-  OutDev out{};
-  float* arena = nullptr;
-};
-
 static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, float*& cursor, bool with_w, hipStream_t st) {
   const int N = p.out_dim, K = p.in_dim;
   L.K = K;
@@ -383,6 +360,10 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   if (with_w) {
     L.Wp = cursor;
     cursor += (size_t)2 * K * N;
+    L.Ws = (half_t*)cursor;
+    cursor += (size_t)2 * K * N;       // X2 format has the same byte size as float32
+    L.Ds = cursor;   cursor += (size_t)kJ * N;
+    L.M1s = cursor;  cursor += (size_t)kJ * N;
   }
   L.D = cursor;      cursor += (size_t)kJ * N;
   L.M1 = cursor;     cursor += (size_t)kJ * N;
@@ -396,6 +377,30 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   hipLaunchKernelGGL(pack_epilogue_kernel, dim3((unsigned)ceil_div(N, threads)), dim3(threads), 0, st, adj, p, L.D, L.M1,
                      L.shift, L.Aoff);
   EHM_LAUNCH_CHECK();
+  if (with_w) {
+    // power-of-two weight scale that keeps |W|*scale well inside f16 and pushes the lo parts out of the subnormal range
+    unsigned int* d_max = (unsigned int*)cursor;   // scratch word at the current arena cursor (overwritten by later packing)
+    EHM_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, p.W, (size_t)2 * K * N, d_max);
+    unsigned int bits = 0;
+    EHM_HIP(hipMemcpyAsync(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost, st));
+    EHM_HIP(hipStreamSynchronize(st));
+    float wmax;
+    memcpy(&wmax, &bits, sizeof(wmax));
+    int e = 0;
+    if (wmax > 0.f && wmax < 3.0e38f) {
+      (void)frexpf(wmax, &e);                 // wmax = m * 2^e, m in [0.5,1)
+      e = 12 - e;                             // |W| * 2^e < 4096
+      if (e > 24) e = 24;
+      if (e < -24) e = -24;
+    }
+    L.w_scale = ldexpf(1.f, e);
+    hipLaunchKernelGGL(pack_ws_kernel, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws, (size_t)2 * N, K,
+                       L.w_scale);
+    hipLaunchKernelGGL(scale_epilogue_kernel, dim3((unsigned)ceil_div(kJ * N, 256)), dim3(256), 0, st, L.D, L.M1, L.Ds, L.M1s, kJ * N,
+                       1.f / L.w_scale);
+    EHM_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -414,8 +419,8 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
   const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ;
-  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * 2 * hid_dim * hid_dim + 12 * (size_t)hid_dim + kJ * 6 +
-                  kJ * kJ + 8 + 64;
+  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (4 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
+                  12 * (size_t)hid_dim + kJ * 6 + kJ * kJ + 8 + 64;
   if (hipMalloc(&g->arena, floats * sizeof(float)) != hipSuccess) {
     delete g;
     ehm_set_error("ehm_gcn_create: hipMalloc of %zu bytes failed", floats * sizeof(float));
@@ -456,8 +461,12 @@ extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* 
   EHM_CHECK_ARG(h && h_img && h_oth && vis && x && Wx && tvec && out);
   EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
   dim3 grid((unsigned)(B * passes), (unsigned)ceil_div(h->hid, 256));
-  hipLaunchKernelGGL(gcn_input_kernel, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
-                     out, B, passes);
+  if (h->precision == EHM_PREC_F32)
+    hipLaunchKernelGGL(gcn_input_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
+                       out, B, passes);
+  else   // split-f16 modes: the activation matrices travel in the X2 format (same byte size)
+    hipLaunchKernelGGL(gcn_input_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
+                       out, B, passes);
   EHM_LAUNCH_CHECK();
   return 0;
 }
@@ -468,6 +477,8 @@ extern "C" int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const
   EHM_CHECK_ARG(layer >= 0 && layer < h->num_hidden);
   EHM_CHECK_ARG(rows_pad > 0 && rows_pad % BM == 0);
   EHM_CHECK_ARG(X != out);
+  if (h->precision != EHM_PREC_F32)   // X / residual in X2 format; output X2 except for the last hidden conv (f32 for the output conv)
+    return ehm_gcn_hidden_f16_impl(h, layer, X, residual, out, rows_pad, layer != h->num_hidden - 1, (hipStream_t)stream);
   const int m_tiles = (int)(rows_pad / BM);
   const int blocks = m_tiles * (h->hid / BNH);
   if (residual)
@@ -491,3 +502,15 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
 
 int ehm_gcn_hid(const ehm_gcn* h) { return h->hid; }
 int ehm_gcn_num_hidden(const ehm_gcn* h) { return h->num_hidden; }
+
+extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
+  EHM_CHECK_ARG(h && (mode == EHM_PREC_F32 || mode == EHM_PREC_F16X3 || mode == EHM_PREC_F16));
+  h->precision = mode;
+  return 0;
+}
+extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
+extern "C" int ehm_gcn_set_tile_override(ehm_gcn* h, int mode) {
+  EHM_CHECK_ARG(h && mode >= 0 && mode <= 2);
+  h->tile_override = mode;
+  return 0;
+}

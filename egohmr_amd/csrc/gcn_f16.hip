@@ -1,0 +1,242 @@
+// Modulated-GCN hidden conv on the f16 matrix cores of gfx950, float32-grade accuracy by operand splitting.
+//
+// Same conv as gcn.hip's gcn_hidden_kernel (modulated_gcn.py:21-28,38-42; modulated_gcn_conv.py:39-50) and the same
+// block / wave tiling, LDS swizzle, XCD-aware order and in-register epilogue.  What changes is the MFMA:
+// v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32-input MFMA (2.5 PFLOP/s dense vs 157 TFLOP/s), and an f32
+// value x is carried as two f16 numbers  x = hi + lo,  hi = rn16(x), lo = rn16(x - hi)  (22 significant bits).
+//   PASSES == 3:  A.B ~ Ahi.Bhi + Ahi.Blo + Alo.Bhi   (dropped term ~2^-22 relative; f16 products are exact in the
+//                 f32 accumulator) -> "f16x3": f32-grade results at up to 5.3x the f32 MFMA roofline.
+//   PASSES == 1:  Ahi.Bhi only -> plain f16 denoiser (BASELINE config 5's "fp16 denoiser"); NOT parity-grade.
+// Activations and weights live in the "X2" format of gcn_dev.h: per row, every 32-k group is 32 hi halves then
+// 32 lo halves = the same 128-byte line a float32 row tile occupies, so HBM/LDS traffic per element is unchanged
+// and the global_load_lds staging is byte-identical to the f32 kernel.  Weights are pre-scaled by a power of two
+// (w_scale) so that their lo parts stay out of the f16 subnormal range; the epilogue constants carry 1/w_scale.
+#include "common.h"
+#include "egohmr_hip.h"
+#include "gcn_dev.h"
+#include "internal.h"
+
+namespace {
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+// WM x WN = how many 96-row groups x 32-channel groups one wave owns.  Block = 2 x 2 waves, so the block tile is
+// (192*WM) rows x (64*WN) channels (x2 branches):
+//   <1,1>: 192 x 64,  80 KiB LDS, 2 blocks/CU (2 waves/SIMD)          - small launches
+//   <1,2>: 192 x 128, 112 KiB LDS, 1 block/CU (1 wave/SIMD)          - 30 % less L2->LDS traffic, measured slower (see launch())
+//   <2,2>: 384 x 128 would halve the traffic but hipcc spills its 384 accumulator registers inside the K loop.
+template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN>
+__global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_kernel(const half_t* __restrict__ X, LayerDev L,
+                                                                                     const half_t* __restrict__ Res,
+                                                                                     float* __restrict__ Y, int m_tiles) {
+  constexpr int BM_ = 192 * WM;              // rows per block
+  constexpr int BR_ = 128 * WN;              // weight rows per block (2 branches x 64*WN channels) = WN consecutive packed tiles
+  constexpr int A_T = BM_ * BK, B_T = BR_ * BK, STG = A_T + B_T;   // floats
+  constexpr int NLA = BM_ / 32, NLB = BR_ / 32;                    // DMA wave-instructions per wave: A rows/8/4, B rows/8/4
+  __shared__ __attribute__((aligned(16))) float lds[2 * STG];
+
+  const int K = L.K, N = L.N;
+  const int n_tiles = N / (64 * WN);
+  int bid = blockIdx.x;
+  const int total = m_tiles * n_tiles;
+  int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
+  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
+  const size_t m0 = (size_t)m_tile * BM_;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- global -> LDS DMA: rows of 128 B (= K-tile of 32: 4 hi chunks + 4 lo chunks), physical chunk c holds logical c ^ key(row)
+  const int ld_r = lane >> 3, ld_c = lane & 7;
+  const float* Xf = (const float*)X;                 // row stride K floats == K*4 bytes in both formats
+  const float* Wf = (const float*)L.Ws;
+  // row r_i = 8*(wave + 4i) + ld_r = r_0 + 32 i  =>  same swizzle key for every i: keep ONE pointer per operand (the
+  // 2 x 20 per-instruction pointers cost 40 VGPRs and pushed the 384 accumulator registers of the big tile into scratch)
+  const int r0 = 8 * wave + ld_r;
+  const int swz = (ld_c ^ ((r0 >> 1) & 7)) << 2;
+  const float* pA = Xf + (m0 + r0) * K + swz;
+  const float* pB = Wf + ((size_t)n_tile * BR_ + r0) * K + swz;
+  const size_t row32 = (size_t)32 * K;
+  auto stage = [&](int buf, int kt) {
+    float* base = lds + buf * STG;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i)
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * BK), (AS3 void*)(base + (wave + 4 * i) * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NLB; ++i)
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * BK), (AS3 void*)(base + A_T + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+
+  // ---- fragments: v_mfma_f32_32x32x16_f16 lane l holds row l&31, k = 8*(l>>5) .. +7 of a 16-wide step
+  const int mi = lane & 31, g = lane >> 5;
+  // row permutation inside a 96-row group (same as the f32 kernel): MFMA row i of tile t <-> 48*((i>>2)&1) + 16t + (i&3) + 4*(i>>3)
+  const int rA = 96 * WM * wm + 48 * ((mi >> 2) & 1) + (mi & 3) + 4 * (mi >> 3);
+  // channel group cg of this wave: channels 64*WN*n_tile + 32*(WN*wn + cg) + mi; packed weight tile = (32*(WN*wn+cg))/64
+  int rB[WN];
+#pragma unroll
+  for (int cg = 0; cg < WN; ++cg) {
+    const int ch0 = 32 * (WN * wn + cg);
+    rB[cg] = (ch0 >> 6) * 128 + (ch0 & 63) + mi;
+  }
+  const int keyA = (rA >> 1) & 7;                     // +16t, +96 do not change (row>>1)&7
+  int keyB[WN];
+#pragma unroll
+  for (int cg = 0; cg < WN; ++cg) keyB[cg] = (rB[cg] >> 1) & 7;   // +64 (branch) does not change it
+
+  f32x16 acc0[WM][WN][3], acc1[WM][WN][3];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int c = 0; c < WN; ++c)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[a][c][t][r] = 0.f; acc1[a][c][t][r] = 0.f; }
+
+  const int KT = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
+    const float* As = lds + (kt & 1) * STG;
+    const float* Bs = As + A_T;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                          // two 16-wide k steps per 32-wide tile
+      const int ch = 2 * s + g, cl = 4 + 2 * s + g;         // logical hi / lo chunk (8 halves = 16 B each)
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        half8 ah[3], al[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          ah[t] = *(const half8*)(As + (rA + 96 * a + 16 * t) * BK + ((ch ^ keyA) << 2));
+          if (PASSES == 3) al[t] = *(const half8*)(As + (rA + 96 * a + 16 * t) * BK + ((cl ^ keyA) << 2));
+        }
+#pragma unroll
+        for (int c = 0; c < WN; ++c) {
+          half8 bh[2], bl[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            bh[u] = *(const half8*)(Bs + (rB[c] + 64 * u) * BK + ((ch ^ keyB[c]) << 2));
+            if (PASSES == 3) bl[u] = *(const half8*)(Bs + (rB[c] + 64 * u) * BK + ((cl ^ keyB[c]) << 2));
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            if (PASSES == 3) {                              // small cross terms first, leading term last
+              acc0[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[0], acc0[a][c][t], 0, 0, 0);
+              acc1[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[1], acc1[a][c][t], 0, 0, 0);
+              acc0[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[0], acc0[a][c][t], 0, 0, 0);
+              acc1[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[1], acc1[a][c][t], 0, 0, 0);
+            }
+            acc0[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[0], acc0[a][c][t], 0, 0, 0);
+            acc1[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[1], acc1[a][c][t], 0, 0, 0);
+          }
+          if (WM * WN > 1) __builtin_amdgcn_sched_barrier(0);   // big tile: keep hipcc from hoisting every fragment load (spills)
+        }
+      }
+    }
+  }
+
+  // ---- epilogue (same staging as the f32 kernel; Ds/M1s carry 1/w_scale), one (row group, channel group) at a time ----
+#pragma unroll
+  for (int c = 0; c < WN; ++c) {
+    const int n = 64 * WN * n_tile + 32 * (WN * wn + c) + mi;
+    float dj[kJ], mj[kJ];
+    const float sh = L.shift[n];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) { dj[j] = L.Ds[j * N + n]; mj[j] = L.M1s[j * N + n]; }
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const size_t rowb = m0 + 96 * (WM * wm + a) + 48 * g;
+      float res0[kJ], res1[kJ];
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) res0[j] = RES ? split_load(Res, rowb + j, n, N) : 0.f;
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) res1[j] = RES ? split_load(Res, rowb + 24 + j, n, N) : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      float d0[kJ], g1[kJ];
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) {
+        d0[j] = fmaf(dj[j], acc0[a][c][j >> 4][j & 15], sh);
+        g1[j] = acc1[a][c][j >> 4][j & 15] * mj[j];
+      }
+      gcn_mix_store<OUT_SPLIT>(d0, g1, res0, n, N, rowb, L.Aoff, Y, L.relu != 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kJ; ++j) {
+        d0[j] = fmaf(dj[j], acc0[a][c][(24 + j) >> 4][(24 + j) & 15], sh);
+        g1[j] = acc1[a][c][(24 + j) >> 4][(24 + j) & 15] * mj[j];
+      }
+      gcn_mix_store<OUT_SPLIT>(d0, g1, res1, n, N, rowb + 24, L.Aoff, Y, L.relu != 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// float32 [rows][K] <-> X2 split format (tests / interop; the sampler never needs them)
+__global__ void pack_x2_kernel(const float* __restrict__ X, half_t* __restrict__ Y, int64_t rows, int K) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  split_store(Y, (size_t)(i / K), (int)(i % K), K, X[i]);
+}
+__global__ void unpack_x2_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int64_t rows, int K) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  Y[i] = split_load(X, (size_t)(i / K), (int)(i % K), K);
+}
+
+template <int PASSES, int WM, int WN>
+int launch_cfg(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split,
+               hipStream_t st) {
+  const int m_tiles = (int)(rows_pad / (192 * WM));
+  const int blocks = m_tiles * (h->hid / (64 * WN));
+  const LayerDev& L = h->hidden[layer];
+  const half_t* x = (const half_t*)X;
+  const half_t* r = (const half_t*)residual;
+  float* y = (float*)out;
+  if (residual) {
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+  } else {
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+  }
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int PASSES>
+int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split, hipStream_t st) {
+  // Measured on MI355X at B=256 (tools/bench_hidden.py): 192x64 tiles at 2 blocks/CU 191 us, 192x128 tiles at 1 block/CU
+  // (1 wave/SIMD) 217 us - halving the L2->LDS traffic does not pay for the lost latency hiding, so the small tile is the
+  // default and the big one stays selectable for experiments.
+  const int force = h->tile_override;   // 0 / 1 = 192x64, 2 = 192x128
+  if (force == 2 && h->hid % 128 == 0)
+    return launch_cfg<PASSES, 1, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
+  return launch_cfg<PASSES, 1, 1>(h, layer, X, residual, out, rows_pad, out_split, st);
+}
+
+}  // namespace
+
+int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
+                            bool out_split, hipStream_t st) {
+  if (h->precision == EHM_PREC_F16X3) return launch<3>(h, layer, X, residual, out, rows_pad, out_split, st);
+  return launch<1>(h, layer, X, residual, out, rows_pad, out_split, st);
+}
+
+extern "C" int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, void* stream) {
+  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0);
+  hipLaunchKernelGGL(pack_x2_kernel, dim3((unsigned)ceil_div(rows * K, 256)), dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, void* stream) {
+  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0);
+  hipLaunchKernelGGL(unpack_x2_kernel, dim3((unsigned)ceil_div(rows * K, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X2, X, rows, K);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}

@@ -15,6 +15,9 @@ int ehm_smpl_num_extra(const ehm_smpl* h);
 // gcn.hip
 int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
+// gcn_f16.hip
+int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
+                            bool out_split, hipStream_t st);
 // guidance.hip
 int64_t ehm_guidance_scratch_bytes(int B, int N);
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,

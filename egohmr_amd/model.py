@@ -30,6 +30,7 @@ from .encoders import ResnetPointnet, ResNet50Features
 OPENPOSE_TO_SMPL = [8, 12, 9, 8, 13, 10, 8, 14, 11, 8, 14, 11, 0, 5, 2, 0, 5, 2, 6, 3, 7, 4, 7, 4]           # egohmr.py:111
 OPENPOSE_TO_SMPL_LOOSE = [8, 13, 10, 8, 13, 10, 8, 14, 11, 8, 14, 11, 1, 5, 2, 0, 5, 2, 6, 3, 7, 4, 7, 4]     # egohmr.py:114
 IMG_DIM, COND_SPLIT = 2048, (2048, 2694, 3206, 3718)   # img | scene+transl+cam | x_t embed | timestep embed
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
 GRAD_ZERO_JOINTS = [0, 3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23]                               # egohmr.py:567
 
 
@@ -189,6 +190,8 @@ class EgoHMR(nn.Module):
         self.collision_tau = 0.05
         self.guide_reduction = "mean"          # COAP variant: -loss.mean() (egohmr.py:562); 'sum' = VolSMPL variant
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
+        self.gcn_precision = "f16x3"
         self.fused_sampler = FusedSampler(self)
         self.to(dev)
         self.eval()
@@ -339,6 +342,9 @@ class FusedSampler:
             bx = torch.einsum("e,kef->kf", bp, W[:, b:c, :])                            # [2,hid]
             self._folded = SimpleNamespace(Wx=Wx.float().contiguous(), bx=bx, W_img=gi.gconv.W.detach()[:, :a, :],
                                            W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :])
+        mode = PRECISIONS[self.model.gcn_precision]
+        if _lib.lib().ehm_gcn_get_precision(self._gcn) != mode:
+            _lib.check(_lib.lib().ehm_gcn_set_precision(self._gcn, mode), "ehm_gcn_set_precision")
         return self._gcn
 
     def _free(self):

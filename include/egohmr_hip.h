@@ -99,6 +99,19 @@ int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_params* inpu
                    int hid_dim, void* stream);
 void ehm_gcn_destroy(ehm_gcn* h);
 
+/* Arithmetic of the hidden convs.  0 = f32-input MFMA (default, exact f32 products);
+ * 1 = "f16x3": f16 MFMA on hi/lo-split operands, three products per term, f32 accumulate (22-bit operands,
+ * f32-grade results); 2 = plain f16 MFMA (hi part only; NOT parity-grade - BASELINE config 5's fp16 denoiser).
+ * In modes 1/2 the activation matrices exchanged between ehm_gcn_input_layer -> ehm_gcn_hidden_layer use the
+ * opaque "X2" split format (same byte size as float32 [rows_pad,hid]); the last hidden conv writes float32 for
+ * ehm_gcn_output_layer.  ehm_gcn_pack/unpack_activations convert float32 <-> X2 (tests, interop). */
+int ehm_gcn_set_precision(ehm_gcn* h, int mode);
+int ehm_gcn_get_precision(const ehm_gcn* h);
+/* tuning knob of the split-f16 convs: 0 = tile picked by problem size (default), 1 = 192x64 tiles, 2 = 384x128 tiles */
+int ehm_gcn_set_tile_override(ehm_gcn* h, int mode);
+int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, void* stream);
+int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, void* stream);
+
 /* rows of the activation matrices must be padded to a multiple of this many rows (zero-filled) */
 int ehm_gcn_row_tile(void);
 

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_f16.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_f16.hip", "linear.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -50,6 +50,14 @@ class GConvParams(C.Structure):
     _fields_ = [("W", C.c_void_p), ("M", C.c_void_p), ("adj2", C.c_void_p), ("bias", C.c_void_p),
                 ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p),
                 ("in_dim", C.c_int), ("out_dim", C.c_int)]
+
+
+class LinearDesc(C.Structure):
+    """ehm_linear_desc"""
+    _fields_ = [("A0", C.c_void_p), ("A1", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("group_bias", C.c_void_p),
+                ("Y", C.c_void_p), ("colmax", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K0", C.c_int), ("K1", C.c_int),
+                ("rows_per_group", C.c_int), ("valid_rows_per_group", C.c_int), ("relu_in0", C.c_int), ("relu_out", C.c_int),
+                ("w_scale", C.c_float)]
 
 
 class StepCoefs(C.Structure):
@@ -87,6 +95,9 @@ PROTOTYPES = {
     "ehm_gcn_input_layer": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ehm_gcn_hidden_layer": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "ehm_linear_split": (_I, [C.POINTER(LinearDesc), _P]),
+    "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),
+    "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_collision_proxy": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),

@@ -1,0 +1,233 @@
+// Fused linear layer on the f16 matrix cores with f32-grade accuracy (split-f16 "f16x3", see gcn_f16.hip):
+//     Y = act_out( [act_in(A0) | A1] . W^T * (1/w_scale) + bias + group_bias[row / rows_per_group] )   (+ column max per group)
+// Used for the scene PointNet of the conditioning path (models/respointnet.py:33-97: ResnetPointnet / ResnetBlockFC), where
+// the reference runs ~40 eager torch kernels over [B,N,256..1024] float32 tensors per call.  Restructuring used by the host
+// (egohmr_amd/encoders.py), all exact up to float re-association:
+//   * the pooled half of every block input (`cat([net, pooled])`, respointnet.py:41-51) is constant per body, so its
+//     contribution to fc_0 and to the shortcut is a per-body bias vector (group_bias) and the per-point GEMMs shrink to 256 wide;
+//   * shortcut and fc_1 of a block accumulate into the same output, so they are ONE GEMM over the concatenated K
+//     ([relu(h) | net] . [W1 | S]^T): the loader switches source pointer at K0 (dual-source A operand);
+//   * the global max-pool over the N points is fused into the epilogue (wave shuffle -> LDS -> one atomic per column and block).
+// Operands are in the X2 split format of gcn_dev.h (32 hi halves + 32 lo halves per 32-k group).  Tile 128 x 128 x 32,
+// 4 waves (2x2, 64x64 each), global_load_lds double buffering, the same conflict-free XOR swizzle as the GCN kernels.
+#include "common.h"
+#include "egohmr_hip.h"
+#include "gcn_dev.h"
+#include "internal.h"
+
+namespace {
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+constexpr int LBM = 128, LBN = 128;
+constexpr int L_STAGE = (LBM + LBN) * BK;   // floats: 32 KiB
+
+struct LinArgs {
+  const half_t* A0; const half_t* A1; const half_t* W;
+  const float* bias; const float* gbias;
+  half_t* Y; float* colmax;
+  int K0, K1, M, N;
+  int rows_per_group, valid_rows_per_group;
+  int relu_in0, relu_out;
+  float inv_scale;
+};
+
+__device__ __forceinline__ void relu_split(half8& hi, half8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool pos = hi[e] > (half_t)0;
+    hi[e] = pos ? hi[e] : (half_t)0;
+    lo[e] = pos ? lo[e] : (half_t)0;
+  }
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256, 2) void linear_split_kernel(LinArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * L_STAGE];   // 64 KiB; the ONLY LDS object (a second one makes hipcc
+                                                                    // drain vmcnt before every fragment read of the DMA pipeline)
+
+  const int n_tiles = p.N / LBN, m_tiles = p.M / LBM;
+  const int total = m_tiles * n_tiles;
+  const int bid = blockIdx.x;
+  const int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;   // XCD b%8 owns a contiguous run of row tiles
+  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
+  const size_t m0 = (size_t)m_tile * LBM;
+  const int n0 = n_tile * LBN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int K = p.K0 + p.K1;
+
+  // DMA: 4 wave-instructions of 8 rows per wave and operand; row r_i = r0 + 32 i -> one swizzle key
+  const int ld_r = lane >> 3, ld_c = lane & 7;
+  const int r0 = 8 * wave + ld_r;
+  const int swz = (ld_c ^ ((r0 >> 1) & 7)) << 2;
+  const float* pA0 = (const float*)p.A0 + (m0 + r0) * p.K0 + swz;
+  const float* pA1 = p.K1 ? (const float*)p.A1 + (m0 + r0) * p.K1 + swz : nullptr;
+  const float* pW = (const float*)p.W + ((size_t)n0 + r0) * K + swz;
+  const int KT0 = p.K0 / BK, KT = K / BK;
+  auto stage = [&](int buf, int kt) {
+    float* base = lds + buf * L_STAGE;
+    const bool second = kt >= KT0;
+    const float* a = second ? pA1 + (size_t)(kt - KT0) * BK : pA0 + (size_t)kt * BK;
+    const size_t arow = (size_t)32 * (second ? p.K1 : p.K0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(a + i * arow), (AS3 void*)(base + (wave + 4 * i) * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(pW + (size_t)i * 32 * K + (size_t)kt * BK),
+                                       (AS3 void*)(base + LBM * BK + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+
+  const int mi = lane & 31, g = lane >> 5;
+  const int rA = 64 * wm + mi, rB = 64 * wn + mi;
+  const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
+    const float* As = lds + (kt & 1) * L_STAGE;
+    const float* Bs = As + LBM * BK;
+    const bool relu_a = p.relu_in0 && kt < KT0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ch = 2 * s + g, cl = 4 + 2 * s + g;
+      half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *(const half8*)(As + (rA + 32 * t) * BK + ((ch ^ keyA) << 2));
+        al[t] = *(const half8*)(As + (rA + 32 * t) * BK + ((cl ^ keyA) << 2));
+        if (relu_a) relu_split(ah[t], al[t]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bh[u] = *(const half8*)(Bs + (rB + 32 * u) * BK + ((ch ^ keyB) << 2));
+        bl[u] = *(const half8*)(Bs + (rB + 32 * u) * BK + ((cl ^ keyB) << 2));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: lane = output column, registers = rows ----
+  float (*smax)[LBN] = (float (*)[LBN])lds;          // column-max exchange re-uses the staging buffers
+  if (p.colmax) __syncthreads();                      // every wave is done reading the last K tile
+  const int group = (int)(m0 / p.rows_per_group);
+  const int row_in_group0 = (int)(m0 % p.rows_per_group);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = n0 + 64 * wn + 32 * u + mi;
+    float add = p.bias ? p.bias[n] : 0.f;
+    if (p.gbias) add += p.gbias[(size_t)group * p.N + n];
+    float cmax = -3.4e38f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 64 * wm + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
+        float v = fmaf(acc[t][u][r], p.inv_scale, add);
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        if (p.Y) split_store(p.Y, m0 + row, n, p.N, v);
+        if (row_in_group0 + row < p.valid_rows_per_group) cmax = fmaxf(cmax, v);
+      }
+    }
+    if (p.colmax) {
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+      if (g == 0) smax[wm][64 * wn + 32 * u + mi] = cmax;
+    }
+  }
+  if (p.colmax) {
+    __syncthreads();
+    if (tid < LBN) atomic_max_float(p.colmax + (size_t)group * p.N + n0 + tid, fmaxf(smax[0][tid], smax[1][tid]));
+  }
+}
+
+// relu(fc_pos(p)) in X2 format plus the raw points zero-padded to 32 columns (X2) for the folded stage-0 shortcut
+__global__ void pointnet_lift_kernel(const float* __restrict__ pts, const float* __restrict__ Wpos, const float* __restrict__ bpos,
+                                     half_t* __restrict__ R0, half_t* __restrict__ P32, int B, int N, int Npad, int C) {
+  const size_t row = blockIdx.x;                       // b * Npad + i
+  const int b = (int)(row / Npad), i = (int)(row % Npad);
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < N) {
+    const float* q = pts + ((size_t)b * N + i) * 3;
+    x = q[0]; y = q[1]; z = q[2];
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float v = fmaf(Wpos[c * 3 + 2], z, fmaf(Wpos[c * 3 + 1], y, fmaf(Wpos[c * 3], x, bpos[c])));   // torch addmm order is free
+    split_store(R0, row, c, C, fmaxf(v, 0.f));
+  }
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    split_store(P32, row, c, 32, c == 0 ? x : (c == 1 ? y : (c == 2 ? z : 0.f)));
+  }
+}
+
+__global__ void pack_scaled_kernel(const float* __restrict__ X, half_t* __restrict__ Y, size_t rows, int K, int Kpad, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Kpad) return;
+  const size_t r = i / Kpad;
+  const int k = (int)(i % Kpad);
+  split_store(Y, r, k, Kpad, k < K ? X[r * K + k] * scale : 0.f);
+}
+
+}  // namespace
+
+extern "C" int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int K_padded, float scale, void* stream) {
+  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K_padded >= K && K_padded % 32 == 0 && scale > 0.f);
+  hipLaunchKernelGGL(pack_scaled_kernel, dim3((unsigned)ceil_div(rows * K_padded, 256)), dim3(256), 0, (hipStream_t)stream, X,
+                     (half_t*)X2, (size_t)rows, K, K_padded, scale);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
+  EHM_CHECK_ARG(d && d->A0 && d->W && (d->Y || d->colmax));
+  EHM_CHECK_ARG(d->M > 0 && d->M % LBM == 0 && d->N > 0 && d->N % LBN == 0);
+  EHM_CHECK_ARG(d->K0 > 0 && d->K0 % BK == 0 && d->K1 >= 0 && d->K1 % BK == 0 && (d->K1 == 0 || d->A1));
+  EHM_CHECK_ARG(d->rows_per_group > 0 && d->rows_per_group % LBM == 0 && d->M % d->rows_per_group == 0);
+  EHM_CHECK_ARG(d->w_scale > 0.f);
+  LinArgs a;
+  a.A0 = (const half_t*)d->A0; a.A1 = (const half_t*)d->A1; a.W = (const half_t*)d->W;
+  a.bias = d->bias; a.gbias = d->group_bias; a.Y = (half_t*)d->Y; a.colmax = d->colmax;
+  a.K0 = d->K0; a.K1 = d->K1; a.M = (int)d->M; a.N = d->N;
+  a.rows_per_group = d->rows_per_group;
+  a.valid_rows_per_group = d->valid_rows_per_group > 0 ? d->valid_rows_per_group : d->rows_per_group;
+  a.relu_in0 = d->relu_in0; a.relu_out = d->relu_out; a.inv_scale = 1.f / d->w_scale;
+  EHM_CHECK_ARG(d->M < (int64_t)1 << 31);
+  const int blocks = (int)(d->M / LBM) * (d->N / LBN);
+  hipLaunchKernelGGL(linear_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
+                                 int C, void* stream) {
+  EHM_CHECK_ARG(pts && Wpos && bpos && R0 && P32 && B > 0 && N > 0 && N_padded >= N && N_padded % LBM == 0 && C > 0 && C % 32 == 0);
+  hipLaunchKernelGGL(pointnet_lift_kernel, dim3((unsigned)((size_t)B * N_padded)), dim3(256), 0, (hipStream_t)stream, pts, Wpos, bpos,
+                     (half_t*)R0, (half_t*)P32, B, N, N_padded, C);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}

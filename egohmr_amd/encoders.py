@@ -8,6 +8,7 @@ its checkpoints load (``backbone.*`` models/resnet.py:97-136, ``scene_enc.*`` mo
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -66,18 +67,97 @@ class _ResBlockFC(nn.Module):
 
 
 class ResnetPointnet(nn.Module):
-    """models/respointnet.py:33-59: per-point MLP with three global max-pool-concat stages -> [B,out_dim]."""
+    """models/respointnet.py:33-59: per-point MLP with three global max-pool-concat stages -> [B,out_dim].
+
+    Parameters keep the reference's names; the arithmetic runs on the split-f16 matrix-core kernels of
+    csrc/linear.hip (f32-grade) with the per-body constant half of every block input folded
+    into bias vectors, fc_1 + shortcut fused into one dual-source GEMM and the max-pool fused into its epilogue."""
 
     def __init__(self, out_dim=512, hidden_dim=256):
         super().__init__()
+        self.hidden_dim = hidden_dim
         self.fc_pos_0 = nn.Linear(3, 2 * hidden_dim)
         for b in range(4):
             setattr(self, f"block_{b}", _ResBlockFC(2 * hidden_dim, hidden_dim, hidden_dim))
         self.fc_c = nn.Linear(hidden_dim, out_dim)
+        self._packed = None
+        self._packed_key = None
 
+    # ------------------------------------------------------------------ weight preparation (once per weight version)
+    @staticmethod
+    def _pack(w64: torch.Tensor, device):
+        """float64 [N,K] -> (X2 buffer, power-of-two scale); K padded to a multiple of 32."""
+        from . import _lib
+        w = w64.float().contiguous().to(device)
+        N, K = w.shape
+        Kp = (K + 31) // 32 * 32
+        amax = float(w.abs().max())
+        scale = 2.0 ** (12 - int(np.floor(np.log2(amax)) + 1)) if amax > 0 else 1.0
+        buf = torch.empty(N, Kp, dtype=torch.float32, device=device)         # X2 has the byte size of float32 [N,Kp]
+        _lib.check(_lib.lib().ehm_split_pack(w.data_ptr(), buf.data_ptr(), N, K, Kp, scale, _lib.stream_ptr()), "ehm_split_pack")
+        return buf, scale, w
+
+    def _prepare(self, device):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        H = self.hidden_dim
+        d = lambda t: t.detach().double()
+        P = {"pos_w": self.fc_pos_0.weight.detach().float().contiguous(), "pos_b": self.fc_pos_0.bias.detach().float().contiguous()}
+        blocks = [self.block_0, self.block_1, self.block_2, self.block_3]
+        b0 = blocks[0]
+        P["g1_0"] = self._pack(d(b0.fc_0.weight), device) + (b0.fc_0.bias.detach().float().contiguous(),)
+        s_pos = d(b0.shortcut.weight) @ d(self.fc_pos_0.weight)                          # shortcut(fc_pos(p)) folded: [H,3]
+        w = torch.cat([d(b0.fc_1.weight), torch.cat([s_pos, s_pos.new_zeros(H, 29)], 1)], dim=1)   # [H, H+32]
+        P["g3_0"] = self._pack(w, device) + ((d(b0.fc_1.bias) + d(b0.shortcut.weight) @ d(self.fc_pos_0.bias)).float().contiguous(),)
+        for i in (1, 2, 3):
+            bl = blocks[i]
+            W0, S = d(bl.fc_0.weight), d(bl.shortcut.weight)
+            P[f"g1_{i}"] = self._pack(W0[:, :H], device)
+            P[f"g3_{i}"] = self._pack(torch.cat([d(bl.fc_1.weight), S[:, :H]], dim=1), device) + (bl.fc_1.bias.detach().float().contiguous(),)
+            P[f"w0b_{i}"], P[f"b0_{i}"] = W0[:, H:].float().contiguous(), bl.fc_0.bias.detach().float()
+            P[f"sb_{i}"] = S[:, H:].float().contiguous()
+        self._packed, self._packed_key = P, key
+        return P
+
+    @torch.no_grad()
     def forward(self, p):
-        net = self.block_0(self.fc_pos_0(p))
-        for blk in (self.block_1, self.block_2, self.block_3):
-            pooled = net.max(dim=1, keepdim=True)[0].expand_as(net)
-            net = blk(torch.cat([net, pooled], dim=2))
-        return self.fc_c(F.relu(net.max(dim=1)[0]))
+        from . import _lib
+        if not p.is_cuda:
+            raise _lib.EgoHMRHipError("ResnetPointnet runs on the HIP kernels only (got a CPU tensor); there is no CPU path")
+        L, dev, H = _lib.lib(), p.device, self.hidden_dim
+        P = self._prepare(dev)
+        p = _lib.f32(p)
+        B, N, _ = p.shape
+        Np = (N + 127) // 128 * 128
+        M = B * Np
+        st = _lib.stream_ptr()
+        f32buf = lambda cols: torch.empty(M, cols, dtype=torch.float32, device=dev)      # X2 buffers (same bytes as float32)
+        R0, P32, Hb, netA, netB = f32buf(2 * H), f32buf(32), f32buf(H), f32buf(H), f32buf(H)
+        _lib.check(L.ehm_pointnet_lift(p.data_ptr(), P["pos_w"].data_ptr(), P["pos_b"].data_ptr(), R0.data_ptr(), P32.data_ptr(),
+                                       B, N, Np, 2 * H, st), "ehm_pointnet_lift")
+
+        def gemm(A0, K0, A1, K1, W, bias, gbias, Y, colmax, relu_in0, relu_out):
+            d = _lib.LinearDesc(A0=A0.data_ptr(), A1=A1.data_ptr() if A1 is not None else None, W=W[0].data_ptr(),
+                                bias=bias.data_ptr() if bias is not None else None,
+                                group_bias=gbias.data_ptr() if gbias is not None else None,
+                                Y=Y.data_ptr() if Y is not None else None, colmax=colmax.data_ptr() if colmax is not None else None,
+                                M=M, N=H, K0=K0, K1=K1, rows_per_group=Np, valid_rows_per_group=N, relu_in0=int(relu_in0),
+                                relu_out=int(relu_out), w_scale=W[1])
+            _lib.check(L.ehm_linear_split(d, st), "ehm_linear_split")
+
+        neg_inf = float("-inf")
+        # block_0 on net0 = fc_pos(p):  h = fc_0(relu(net0));  net1 = fc_1(relu(h)) + shortcut(net0)
+        gemm(R0, 2 * H, None, 0, P["g1_0"], P["g1_0"][3], None, Hb, None, False, True)
+        pooled = torch.full((B, H), neg_inf, device=dev)
+        gemm(Hb, H, P32, 32, P["g3_0"], P["g3_0"][3], None, netA, pooled, False, False)
+        cur, nxt = netA, netB
+        for i in (1, 2, 3):
+            v = (torch.relu(pooled) @ P[f"w0b_{i}"].t() + P[f"b0_{i}"]).contiguous()       # pooled half of fc_0(relu(cat[net, pooled]))
+            s = (pooled @ P[f"sb_{i}"].t()).contiguous()                                  # pooled half of shortcut(cat[net, pooled])
+            gemm(cur, H, None, 0, P[f"g1_{i}"], None, v, Hb, None, True, True)
+            pooled = torch.full((B, H), neg_inf, device=dev)
+            gemm(Hb, H, cur, H, P[f"g3_{i}"], P[f"g3_{i}"][3], s, nxt if i < 3 else None, pooled, False, False)
+            cur, nxt = nxt, cur
+        return self.fc_c(F.relu(pooled))
+

@@ -137,6 +137,35 @@ int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const float* res
 int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* vis, float* x0, int B, int passes,
                          void* stream);
 
+/* ------------------------------------------------------------------ scene PointNet (conditioning) ----------- */
+/* Building blocks of ResnetPointnet.forward (models/respointnet.py:33-59, ResnetBlockFC :89-97) on the split-f16
+ * matrix-core path (f32-grade, see ehm_gcn_set_precision mode 1).  All activation / weight operands are in the "X2"
+ * split format (ehm_split_pack); the host side (egohmr_amd/encoders.py) chains them, see csrc/linear.hip. */
+typedef struct {
+  const void* A0;          /* X2 [M, K0]                                                           */
+  const void* A1;          /* X2 [M, K1] or NULL: second K segment (dual-source A operand)          */
+  const void* W;           /* X2 [N, K0+K1], values pre-multiplied by w_scale (ehm_split_pack)      */
+  const float* bias;       /* [N] or NULL                                                           */
+  const float* group_bias; /* [M/rows_per_group, N] or NULL: per-body bias (pooled half of a block) */
+  void* Y;                 /* X2 [M, N] or NULL                                                     */
+  float* colmax;           /* [M/rows_per_group, N] or NULL: running max over the group's valid rows
+                              (caller initialises to -inf); fused torch.max(dim=1), respointnet.py:38 */
+  int64_t M;               /* rows, multiple of 128                                                 */
+  int N, K0, K1;           /* N multiple of 128; K0, K1 multiples of 32                             */
+  int rows_per_group;      /* padded points per body, multiple of 128                               */
+  int valid_rows_per_group;/* real points per body (<= rows_per_group); 0 = all                     */
+  int relu_in0;            /* apply ReLU to A0 on load (ResnetBlockFC's actvn before fc_0 / fc_1)   */
+  int relu_out;            /* apply ReLU before storing                                             */
+  float w_scale;           /* the power-of-two scale baked into W                                   */
+} ehm_linear_desc;
+int ehm_linear_split(const ehm_linear_desc* d, void* stream);
+/* float32 [rows,K] -> X2 [rows,K_padded] (zero padded), values multiplied by `scale` (1 for activations). */
+int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int K_padded, float scale, void* stream);
+/* fc_pos + ReLU (respointnet.py:35,:90): pts [B,N,3] -> R0 = relu(pts W^T + b) as X2 [B*N_padded, C], and the raw points
+ * zero-padded to 32 columns, P32 X2 [B*N_padded, 32] (input of the folded block_0 shortcut). */
+int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
+                      int C, void* stream);
+
 /* ------------------------------------------------------------------ sampler steps ------------- */
 /* diffusion/gaussian_diffusion.py:217-220 + :333-336 (p_sample) and :378-385 (p_sample_with_grad):
  *   mean = coef1*x0 + coef2*x  [+ grad_scale * grad]

@@ -341,3 +341,24 @@ def test_full_size_batch_items_are_independent(dev, model):
     R = torch.cat([full["pred_smpl_params"]["global_orient"], full["pred_smpl_params"]["body_pose"]], 1)
     eye = torch.eye(3, device=dev)
     assert (R @ R.transpose(-1, -2) - eye).abs().max() < 1e-5         # outputs are rotations
+
+
+# --------------------------------------------------------------------------------------------- scene PointNet
+def test_pointnet_vs_reference_golden_ragged(golden_dir, dev, model):
+    """ResnetPointnet on N = 257 points (not a multiple of the 128-row tile: padded rows must not leak into the max-pool)."""
+    g = _load(golden_dir, "g6_pointnet")
+    out = model.scene_enc(torch.from_numpy(g["pts"]).to(dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["feat"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N", [(1, 128), (3, 4096), (2, 5000)])
+def test_pointnet_vs_oracle(dev, model, synth_weights, B, N):
+    from oracle import model as om
+    g = np.random.Generator(np.random.PCG64(300 + N))
+    pts = g.uniform(-1, 1, size=(B, N, 3)).astype(np.float32)
+    sd = {k: torch.from_numpy(np.asarray(v)).double() for k, v in synth_weights.items() if k.startswith("scene_enc.")}
+    ref = om.resnet_pointnet(sd, torch.from_numpy(pts).double())
+    out = model.scene_enc(torch.from_numpy(pts).to(dev))
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"[pointnet B={B} N={N}] max|err| vs fp64 oracle = {err:.3e} (|feat|max = {ref.abs().max().item():.2f})")
+    assert err < 2e-5

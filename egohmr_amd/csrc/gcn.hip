@@ -295,20 +295,23 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// output conv (hid -> 6) + visibility fuse.  One block per body: 24 x passes rows of K floats.
+// output conv (hid -> 6, both branches) + visibility fuse, two kernels:
+//   gcn_out_dot_kernel   HBM-bound: every activation row is read once (float4, coalesced); the 12 x K output weights sit in
+//                        LDS; one wave per row at a time, 8 rows per wave; 12 dot products reduced with wave shuffles.
+//   gcn_out_mix_kernel   per body: modulated adjacency mix of the [24 x 12] responses, bias, pass selection by visibility.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gcn_output_kernel(const float* __restrict__ X, OutDev O,
-                                                         const uint8_t* __restrict__ vis, float* __restrict__ x0,
-                                                         int B, int passes) {
-  __shared__ float hs[2][kJ][12];   // [pass][joint][W0 c0..5 | W1 c0..5]
-  __shared__ float outs[2][kJ][6];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = O.K;
-  const int nrows = kJ * passes;
-  for (int r = wave; r < nrows; r += 4) {
-    const int p = r / kJ, j = r % kJ;
-    const float* xr = X + ((size_t)(p * B + b) * kJ + j) * K;
+constexpr int OUT_ROWS_PER_BLOCK = 32;
+
+__global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restrict__ X, OutDev O, float* __restrict__ hs, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];   // [12][K]
+  const int K = O.K, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid * 4; i < 12 * K; i += 256 * 4) *(f32x4*)(sW + i) = *(const f32x4*)(O.Wt + i);
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK + wave * (OUT_ROWS_PER_BLOCK / 4);
+  for (int rr = 0; rr < OUT_ROWS_PER_BLOCK / 4; ++rr) {
+    const int64_t r = r0 + rr;
+    if (r >= rows) break;
+    const float* xr = X + r * K;
     float acc[12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) acc[c] = 0.f;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void gcn_output_kernel(const float* __restrict
       const f32x4 xv = *(const f32x4*)(xr + k);
 #pragma unroll
       for (int c = 0; c < 12; ++c) {
-        const f32x4 wv = *(const f32x4*)(O.Wt + (size_t)c * K + k);
+        const f32x4 wv = *(const f32x4*)(sW + c * K + k);
         acc[c] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[c]))));
       }
     }
@@ -325,25 +328,42 @@ __global__ __launch_bounds__(256) void gcn_output_kernel(const float* __restrict
       float v = acc[c];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) hs[p][j][c] = v;
+      acc[c] = v;
+    }
+    if (lane < 12) {
+      float v = acc[0];
+#pragma unroll
+      for (int c = 1; c < 12; ++c) v = lane == c ? acc[c] : v;
+      hs[r * 12 + lane] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(192) void gcn_out_mix_kernel(const float* __restrict__ hs, OutDev O, const uint8_t* __restrict__ vis,
+                                                          float* __restrict__ x0, int B, int passes) {
+  __shared__ float sh[2][kJ][12];
+  __shared__ float outs[2][kJ][6];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < passes * kJ * 12; i += 192) {
+    const int p = i / (kJ * 12), rem = i % (kJ * 12);
+    sh[p][rem / 12][rem % 12] = hs[((size_t)(p * B + b) * kJ) * 12 + rem];
+  }
   __syncthreads();
-  for (int e = threadIdx.x; e < passes * kJ * 6; e += 256) {
+  for (int e = tid; e < passes * kJ * 6; e += 192) {
     const int p = e / (kJ * 6), j = (e / 6) % kJ, c = e % 6;
     // modulated_gcn_conv.py:47: (adj*E) @ (M*h0) + (adj*(1-E)) @ (M*h1) + bias
-    float s = O.A[j * kJ + j] * (O.M[j * 6 + c] * hs[p][j][c]);
+    const float s = O.A[j * kJ + j] * (O.M[j * 6 + c] * sh[p][j][c]);
     float t = 0.f;
     for (int jp = 0; jp < kJ; ++jp)
-      if (jp != j) t = fmaf(O.A[j * kJ + jp], O.M[jp * 6 + c] * hs[p][jp][6 + c], t);
+      if (jp != j) t = fmaf(O.A[j * kJ + jp], O.M[jp * 6 + c] * sh[p][jp][6 + c], t);
     outs[p][j][c] = s + t + O.bias[c];
   }
   __syncthreads();
-  if (threadIdx.x < kPoseDim) {
-    const int j = threadIdx.x / 6, c = threadIdx.x % 6;
+  if (tid < kPoseDim) {
+    const int j = tid / 6, c = tid % 6;
     float v = outs[0][j][c];
     if (passes == 2 && !vis[(size_t)b * kJ + j]) v = outs[1][j][c];   // egohmr.py:249-254
-    x0[(size_t)b * kPoseDim + threadIdx.x] = v;
+    x0[(size_t)b * kPoseDim + tid] = v;
   }
 }
 
@@ -453,6 +473,7 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
 extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
   if (!h) return;
   (void)hipFree(h->arena);
+  if (h->hs) (void)hipFree(h->hs);
   delete h;
 }
 
@@ -495,7 +516,19 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
                                     void* stream) {
   EHM_CHECK_ARG(h && X && x0);
   EHM_CHECK_ARG(B > 0 && (passes == 1 || (passes == 2 && vis)));
-  hipLaunchKernelGGL(gcn_output_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, h->out, vis, x0, B, passes);
+  const int64_t rows = (int64_t)passes * B * kJ;
+  if (rows > h->hs_rows) {      // [rows,12] scratch of the two-kernel output conv; grows on first use of a larger batch only
+    if (h->hs) (void)hipFree(h->hs);
+    h->hs = nullptr;
+    h->hs_rows = 0;
+    EHM_HIP(hipMalloc(&h->hs, (size_t)round_up(rows, 4096) * 12 * sizeof(float)));
+    h->hs_rows = round_up(rows, 4096);
+  }
+  const size_t lds = (size_t)12 * h->hid * sizeof(float);
+  if (lds > 64 * 1024) EHM_HIP(hipFuncSetAttribute((const void*)gcn_out_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(gcn_out_dot_kernel, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), lds, (hipStream_t)stream, X,
+                     h->out, h->hs, rows);
+  hipLaunchKernelGGL(gcn_out_mix_kernel, dim3(B), dim3(192), 0, (hipStream_t)stream, h->hs, h->out, vis, x0, B, passes);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -46,6 +46,8 @@ struct ehm_gcn {
   LayerDev hidden[16]{};
   OutDev out{};
   float* arena = nullptr;
+  float* hs = nullptr;      // [hs_rows,12] responses of the output conv (gcn_out_dot_kernel -> gcn_out_mix_kernel)
+  int64_t hs_rows = 0;
 };
 
 // Split-f16 activation / weight format ("X2"): row-major rows of K values, each group of 32 consecutive k stored as
@@ -64,6 +66,34 @@ static __device__ __forceinline__ float split_load(const half_t* base, size_t ro
   return (float)p[0] + (float)p[32];
 }
 
+// Lane-pair versions for epilogues in which adjacent lanes own adjacent columns (lane parity == parity of n): the even
+// lane moves the dword {hi[n], hi[n+1]}, the odd lane the dword {lo[n-1], lo[n]}, halves are exchanged with one
+// cross-lane move.  One 4-byte access per lane and row instead of two 2-byte ones (the store tail is issue-bound).
+static __device__ __forceinline__ unsigned int split_pack_bits(float v) {
+  const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+  const half_t hi = (half_t)c;
+  const half_t lo = (half_t)(v - (float)hi);
+  return (unsigned int)__builtin_bit_cast(unsigned short, hi) | ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+static __device__ __forceinline__ void split_store_pair(half_t* base, size_t row, int n, int N, float v) {
+  const unsigned int own = split_pack_bits(v);                       // {hi, lo} of my column
+  const unsigned int nbr = (unsigned int)__shfl_xor((int)own, 1);    // {hi, lo} of the neighbouring column
+  const bool odd = n & 1;
+  // even lane: hi[n] | hi[n+1] << 16  at &hi[n];   odd lane: lo[n-1] | lo[n] << 16  at &lo[n-1]
+  const unsigned int word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
+  half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 30) + (odd ? 32 : 0);
+  *(unsigned int*)p = word;
+}
+static __device__ __forceinline__ float split_load_pair(const half_t* base, size_t row, int n, int N) {
+  const bool odd = n & 1;
+  const half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 30) + (odd ? 32 : 0);
+  const unsigned int own = *(const unsigned int*)p;                  // even: {hi[n], hi[n+1]}   odd: {lo[n-1], lo[n]}
+  const unsigned int nbr = (unsigned int)__shfl_xor((int)own, 1);
+  const unsigned short hb = odd ? (unsigned short)(nbr >> 16) : (unsigned short)(own & 0xffffu);
+  const unsigned short lb = odd ? (unsigned short)(own >> 16) : (unsigned short)(nbr & 0xffffu);
+  return (float)__builtin_bit_cast(half_t, hb) + (float)__builtin_bit_cast(half_t, lb);
+}
+
 // d0[j] = D[j][n]*h0[j] + shift[n] (diagonal branch, bias and BatchNorm folded), g1[j] = M1[j][n]*h1[j];
 // res[j] = residual input (already loaded, zeros when unused).
 template <bool SPLIT_OUT>
@@ -75,7 +105,7 @@ static __device__ __forceinline__ void gcn_mix_store(const float (&d0)[kJ], cons
 #pragma unroll
     for (int jp = 0; jp < kJ; ++jp) s = fmaf(Aoff[j * kJ + jp], g1[jp], s);  // Aoff: wave-uniform -> scalar loads
     if (relu) s = fmaxf(s, 0.f);
-    if (SPLIT_OUT) split_store((half_t*)Y, row0 + j, n, N, s + res[j]);
+    if (SPLIT_OUT) split_store_pair((half_t*)Y, row0 + j, n, N, s + res[j]);
     else Y[(row0 + j) * (size_t)N + n] = s + res[j];
   }
 }

@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
       const size_t rowb = m0 + 96 * (WM * wm + a) + 48 * g;
       float res0[kJ], res1[kJ];
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) res0[j] = RES ? split_load(Res, rowb + j, n, N) : 0.f;
+      for (int j = 0; j < kJ; ++j) res0[j] = RES ? split_load_pair(Res, rowb + j, n, N) : 0.f;
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) res1[j] = RES ? split_load(Res, rowb + 24 + j, n, N) : 0.f;
+      for (int j = 0; j < kJ; ++j) res1[j] = RES ? split_load_pair(Res, rowb + 24 + j, n, N) : 0.f;
       __builtin_amdgcn_sched_barrier(0);
       float d0[kJ], g1[kJ];
 #pragma unroll

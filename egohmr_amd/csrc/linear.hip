@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinArgs p) {
         const int row = 64 * wm + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
         float v = fmaf(acc[t][u][r], p.inv_scale, add);
         if (p.relu_out) v = fmaxf(v, 0.f);
-        if (p.Y) split_store(p.Y, m0 + row, n, p.N, v);
+        if (p.Y) split_store_pair(p.Y, m0 + row, n, p.N, v);
         if (row_in_group0 + row < p.valid_rows_per_group) cmax = fmaxf(cmax, v);
       }
     }

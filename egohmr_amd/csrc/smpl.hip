@@ -18,6 +18,8 @@
 //                      are placed on the same XCD so the 17 MB pose basis is fetched from HBM/MALL once
 //                      per XCD-resident tile and re-used out of that XCD's L2.
 // HBM traffic per body-step: 82.7 KB vertices out (+ ~1.5 KB small tensors); shared constants 19.3 MB per launch.
+#include <vector>
+
 #include "common.h"
 #include "egohmr_hip.h"
 #include "internal.h"
@@ -154,12 +156,12 @@ __global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ skinning
-__global__ __launch_bounds__(kVT, 4) void skin_kernel(const float* __restrict__ betas, const float* __restrict__ Rws,
+__global__ __launch_bounds__(kVT, 2) void skin_kernel(const float* __restrict__ betas, const float* __restrict__ Rws,
                                                    const float* __restrict__ A, SmplDev S, float* __restrict__ verts,
                                                    int B, int v_tiles, int b_groups) {
-  __shared__ __attribute__((aligned(16))) float sA[kBG][kJ][12];
-  __shared__ float sPF[kBG][kPoseBasis + 1];
-  __shared__ float sBeta[kBG][10];
+  __shared__ __attribute__((aligned(16))) float sA[kBGF][kJ][12];
+  __shared__ float sPF[kBGF][kPoseBasis + 1];
+  __shared__ float sBeta[kBGF][10];
 
   // XCD-aware order: blocks of one XCD (bid % 8) walk body groups of the same vertex tile back to back
   const int bid = blockIdx.x;
@@ -167,22 +169,22 @@ __global__ __launch_bounds__(kVT, 4) void skin_kernel(const float* __restrict__ 
   const int vt = (k / b_groups) * 8 + xcd;
   const int bg = k % b_groups;
   if (vt >= v_tiles) return;
-  const int b0 = bg * kBG;
-  const int nb = min(kBG, B - b0);
+  const int b0 = bg * kBGF;
+  const int nb = min(kBGF, B - b0);
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < kBG * kJ * 12; i += kVT) {
+  for (int i = tid; i < kBGF * kJ * 12; i += kVT) {
     const int bb = i / (kJ * 12);
     (&sA[0][0][0])[i] = bb < nb ? A[(size_t)b0 * kJ * 12 + i] : 0.f;
   }
-  for (int i = tid; i < kBG * kPoseBasis; i += kVT) {
+  for (int i = tid; i < kBGF * kPoseBasis; i += kVT) {
     const int bb = i / kPoseBasis, p = i % kPoseBasis;
     const int e = p % 9;
     float v = 0.f;
     if (bb < nb) v = Rws[((size_t)(b0 + bb) * kJ + 1) * 9 + p] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);  // R[1:] - I
     sPF[bb][p] = v;
   }
-  if (tid < kBG * 10) sBeta[tid / 10][tid % 10] = (tid / 10) < nb ? betas[(size_t)b0 * 10 + tid] : 0.f;
+  if (tid < kBGF * 10) sBeta[tid / 10][tid % 10] = (tid / 10) < nb ? betas[(size_t)b0 * 10 + tid] : 0.f;
   __syncthreads();
 
   const int v = vt * kVT + tid;
@@ -190,23 +192,23 @@ __global__ __launch_bounds__(kVT, 4) void skin_kernel(const float* __restrict__ 
   const int V3 = S.V * 3;
 
   // shape blend: v_shaped = v_template + shapedirs . beta   (accumulated straight into the posed position)
-  float po[kBG][3];
+  float po[kBGF][3];
   {
     const float t0 = S.v_template[v * 3 + 0], t1 = S.v_template[v * 3 + 1], t2 = S.v_template[v * 3 + 2];
 #pragma unroll
-    for (int bb = 0; bb < kBG; ++bb) { po[bb][0] = 0.f; po[bb][1] = 0.f; po[bb][2] = 0.f; }
+    for (int bb = 0; bb < kBGF; ++bb) { po[bb][0] = 0.f; po[bb][1] = 0.f; po[bb][2] = 0.f; }
 #pragma unroll 2
     for (int l = 0; l < 10; ++l) {
       const float s0 = S.shape_t[(size_t)l * V3 + v * 3 + 0], s1 = S.shape_t[(size_t)l * V3 + v * 3 + 1],
                   s2 = S.shape_t[(size_t)l * V3 + v * 3 + 2];
 #pragma unroll
-      for (int bb = 0; bb < kBG; ++bb) {
+      for (int bb = 0; bb < kBGF; ++bb) {
         const float be = sBeta[bb][l];
         po[bb][0] = fmaf(be, s0, po[bb][0]); po[bb][1] = fmaf(be, s1, po[bb][1]); po[bb][2] = fmaf(be, s2, po[bb][2]);
       }
     }
 #pragma unroll
-    for (int bb = 0; bb < kBG; ++bb) { po[bb][0] += t0; po[bb][1] += t1; po[bb][2] += t2; }
+    for (int bb = 0; bb < kBGF; ++bb) { po[bb][0] += t0; po[bb][1] += t1; po[bb][2] += t2; }
   }
   // pose-corrective blend: + pose_feature . posedirs (207 basis rows, each reused by the 8 bodies in registers)
   const float* pd = S.posedirs + (size_t)v * 3;
@@ -214,33 +216,53 @@ __global__ __launch_bounds__(kVT, 4) void skin_kernel(const float* __restrict__ 
   for (int p = 0; p < kPoseBasis; ++p) {
     const float d0 = pd[(size_t)p * V3 + 0], d1 = pd[(size_t)p * V3 + 1], d2 = pd[(size_t)p * V3 + 2];
 #pragma unroll
-    for (int bb = 0; bb < kBG; ++bb) {
+    for (int bb = 0; bb < kBGF; ++bb) {
       const float f = sPF[bb][p];
       po[bb][0] = fmaf(f, d0, po[bb][0]); po[bb][1] = fmaf(f, d1, po[bb][1]); po[bb][2] = fmaf(f, d2, po[bb][2]);
     }
   }
   const float* wv = S.w_t + v;   // [24][V]: re-read per body, L1/L2 resident (keeps 24 registers free)
+  float wsp[4] = {0.f, 0.f, 0.f, 0.f};
+  int jsp[4] = {0, 0, 0, 0};
+  if (S.sparse4) {
 #pragma unroll
-  for (int bb = 0; bb < kBG; ++bb) {
-    if (bb >= nb) break;
-    __builtin_amdgcn_sched_barrier(0);   // one body at a time: keeps the 8x288 FMAs from being interleaved (register pressure)
+    for (int s4 = 0; s4 < 4; ++s4) { wsp[s4] = S.w_val[(size_t)s4 * S.V + v]; jsp[s4] = S.w_idx[(size_t)s4 * S.V + v]; }
+  }
+#pragma unroll
+  for (int bb = 0; bb < kBGF; ++bb) {      // fully unrolled (po[] must stay in registers): no break, predicate the store instead
+    __builtin_amdgcn_sched_barrier(0);   // one body at a time: keeps the FMAs of different bodies from being interleaved (register pressure)
     const float px = po[bb][0], py = po[bb][1], pz = po[bb][2];
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < kJ; ++j) {
-      const float wj = wv[(size_t)j * S.V];
-      const f32x4 r0 = *(const f32x4*)&sA[bb][j][0], r1 = *(const f32x4*)&sA[bb][j][4], r2 = *(const f32x4*)&sA[bb][j][8];
+    if (S.sparse4) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        T[e] = fmaf(wj, r0[e], T[e]); T[4 + e] = fmaf(wj, r1[e], T[4 + e]); T[8 + e] = fmaf(wj, r2[e], T[8 + e]);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float wj = wsp[s4];
+        const int j = jsp[s4];
+        const f32x4 r0 = *(const f32x4*)&sA[bb][j][0], r1 = *(const f32x4*)&sA[bb][j][4], r2 = *(const f32x4*)&sA[bb][j][8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          T[e] = fmaf(wj, r0[e], T[e]); T[4 + e] = fmaf(wj, r1[e], T[4 + e]); T[8 + e] = fmaf(wj, r2[e], T[8 + e]);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int j = 0; j < kJ; ++j) {
+        const float wj = wv[(size_t)j * S.V];
+        const f32x4 r0 = *(const f32x4*)&sA[bb][j][0], r1 = *(const f32x4*)&sA[bb][j][4], r2 = *(const f32x4*)&sA[bb][j][8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          T[e] = fmaf(wj, r0[e], T[e]); T[4 + e] = fmaf(wj, r1[e], T[4 + e]); T[8 + e] = fmaf(wj, r2[e], T[8 + e]);
+        }
       }
     }
-    float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
-    o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
-    o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
-    o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    if (bb < nb) {
+      float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
+      o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+      o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+      o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    }
   }
 }
 
@@ -289,7 +311,7 @@ extern "C" int ehm_smpl_create(ehm_smpl** out, const float* v_template, const fl
     if (d.tree.depth[j] > d.tree.max_depth) d.tree.max_depth = d.tree.depth[j];
   }
   const size_t V = num_verts;
-  const size_t floats = V * 3 + 10 * V * 3 + kJ * V + kJ * 3 + kJ * 30 + 64 + 64;
+  const size_t floats = V * 3 + 10 * V * 3 + kJ * V + kJ * 3 + kJ * 30 + 64 + 64 + 8 * V;
   if (hipMalloc(&h->arena, floats * sizeof(float)) != hipSuccess) {
     delete h;
     ehm_set_error("ehm_smpl_create: hipMalloc failed");
@@ -301,8 +323,35 @@ extern "C" int ehm_smpl_create(ehm_smpl** out, const float* v_template, const fl
   d.w_t = cur;         cur += kJ * V;
   d.J_template = cur;  cur += kJ * 3;
   d.J_shape = cur;     cur += kJ * 30;
-  d.extra_idx = (int32_t*)cur;
+  d.extra_idx = (int32_t*)cur;  cur += 64;
+  d.w_idx = (int32_t*)cur;      cur += 4 * V;
+  d.w_val = cur;                cur += 4 * V;
   d.posedirs = posedirs;
+  {  // SMPL skinning weights have <= 4 non-zeros per vertex: detect it once and keep a compressed copy
+    std::vector<float> hw(V * kJ);
+    std::vector<int32_t> hi(4 * V, 0);
+    std::vector<float> hv(4 * V, 0.f);
+    d.sparse4 = 0;
+    if (hipMemcpy(hw.data(), lbs_weights, hw.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
+      d.sparse4 = 1;
+      for (size_t v = 0; v < V && d.sparse4; ++v) {
+        int n = 0;
+        for (int j = 0; j < kJ; ++j) {
+          const float w = hw[v * kJ + j];
+          if (w != 0.f) {
+            if (n == 4) { d.sparse4 = 0; break; }
+            hi[(size_t)n * V + v] = j;
+            hv[(size_t)n * V + v] = w;
+            ++n;
+          }
+        }
+      }
+      if (d.sparse4) {
+        (void)hipMemcpy(d.w_idx, hi.data(), hi.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        (void)hipMemcpy(d.w_val, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice);
+      }
+    }
+  }
   int rc = 0;
   if (hipMemcpyAsync(d.v_template, v_template, V * 3 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = EHM_EIO;
   if (n_extra && hipMemcpyAsync(d.extra_idx, extra_joint_vertex_ids, n_extra * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess) rc = EHM_EIO;
@@ -345,7 +394,7 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
   else
     hipLaunchKernelGGL(pose_chain_kernel<false>, dim3(B), dim3(64), 0, st, betas, rot_or_x, (const float*)nullptr,
                        (const float*)nullptr, d, Rws, Aws, joints, (float*)nullptr, jstride);
-  const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBG);
+  const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
   const int blocks = (int)round_up(v_tiles, 8) * b_groups;
   hipLaunchKernelGGL(skin_kernel, dim3(blocks), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);
   if (d.n_extra)

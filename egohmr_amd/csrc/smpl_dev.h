@@ -2,7 +2,8 @@
 #pragma once
 #include "common.h"
 
-constexpr int kBG = 8;       // bodies per skinning block
+constexpr int kBG = 8;       // bodies per block of the skinning VJP (guidance.hip)
+constexpr int kBGF = 16;     // bodies per block of the forward skinning kernel: halves the L2 re-reads of the 17 MB pose basis
 constexpr int kVT = 256;     // vertices per skinning block
 constexpr int kPoseBasis = 207;
 
@@ -19,6 +20,9 @@ struct SmplDev {
   float* shape_t;      // [10][V*3]   shapedirs transposed (basis-major like posedirs)
   const float* posedirs;  // [207][V*3] caller-owned (smplx layout already streams well)
   float* w_t;          // [24][V]     lbs_weights transposed
+  int sparse4;         // 1 when every vertex has <= 4 non-zero skinning weights (true for SMPL): use w_idx / w_val
+  int32_t* w_idx;      // [4][V]      joint ids of the non-zero weights (padding: joint 0 with weight 0)
+  float* w_val;        // [4][V]
   float* J_template;   // [24][3]     J_regressor . v_template
   float* J_shape;      // [24][3][10] J_regressor . shapedirs
   int32_t* extra_idx;  // [n_extra]

@@ -39,3 +39,24 @@ constexpr int kPoseDim = 144;  // 24 x 6
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---- cross-lane helpers on the DPP path (hipcc lowers __shfl_xor to ds_bpermute_b32, an LDS-crossbar instruction) ----
+template <int CTRL>
+static __device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+static __device__ __forceinline__ unsigned int dpp_xor1_u32(unsigned int v) {          // value of lane ^ 1 (quad_perm [1,0,3,2])
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+static __device__ __forceinline__ float row16_sum(float v) {   // every lane ends with the sum over its 16-lane row
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);   // row_half_mirror
+  v += dpp_move<0x140>(v);   // row_mirror
+  return v;
+}
+static __device__ __forceinline__ float wave_sum(float v) {    // wave-uniform sum over the 64 lanes
+  const int b = __builtin_bit_cast(int, row16_sum(v));   // readlane is an integer builtin: move the bits, not the value
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}

@@ -324,12 +324,7 @@ __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restric
       }
     }
 #pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      float v = acc[c];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-      acc[c] = v;
-    }
+    for (int c = 0; c < 12; ++c) acc[c] = wave_sum(acc[c]);   // DPP row reduction + 4 readlanes (no LDS crossbar)
     if (lane < 12) {
       float v = acc[0];
 #pragma unroll

@@ -77,7 +77,7 @@ static __device__ __forceinline__ unsigned int split_pack_bits(float v) {
 }
 static __device__ __forceinline__ void split_store_pair(half_t* base, size_t row, int n, int N, float v) {
   const unsigned int own = split_pack_bits(v);                       // {hi, lo} of my column
-  const unsigned int nbr = (unsigned int)__shfl_xor((int)own, 1);    // {hi, lo} of the neighbouring column
+  const unsigned int nbr = dpp_xor1_u32(own);                         // {hi, lo} of the neighbouring column
   const bool odd = n & 1;
   // even lane: hi[n] | hi[n+1] << 16  at &hi[n];   odd lane: lo[n-1] | lo[n] << 16  at &lo[n-1]
   const unsigned int word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
@@ -88,7 +88,7 @@ static __device__ __forceinline__ float split_load_pair(const half_t* base, size
   const bool odd = n & 1;
   const half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 30) + (odd ? 32 : 0);
   const unsigned int own = *(const unsigned int*)p;                  // even: {hi[n], hi[n+1]}   odd: {lo[n-1], lo[n]}
-  const unsigned int nbr = (unsigned int)__shfl_xor((int)own, 1);
+  const unsigned int nbr = dpp_xor1_u32(own);
   const unsigned short hb = odd ? (unsigned short)(nbr >> 16) : (unsigned short)(own & 0xffffu);
   const unsigned short lb = odd ? (unsigned short)(own >> 16) : (unsigned short)(nbr & 0xffffu);
   return (float)__builtin_bit_cast(half_t, hb) + (float)__builtin_bit_cast(half_t, lb);

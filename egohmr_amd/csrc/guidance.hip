@@ -296,9 +296,7 @@ __global__ __launch_bounds__(256) void posefeat_bwd_kernel(const float* __restri
   for (int bb = 0; bb < kBG; ++bb)
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-      float s = acc[bb][r];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+      const float s = wave_sum(acc[bb][r]);
       if (lane == 0) red[wave][bb * 9 + r] = s;
     }
   __syncthreads();

@@ -16,6 +16,8 @@
 //     double buffered, one barrier per 32-wide K tile; LDS images are XOR-swizzled on the SOURCE
 //     address so the ds_read_b128 fragment reads are bank-conflict free.
 //   * BatchNorm is folded into per-channel scale/shift, the adjacency is symmetrised once.
+#include <stdlib.h>
+
 #include "common.h"
 #include "egohmr_hip.h"
 #include "gcn_dev.h"
@@ -431,6 +433,8 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   for (int i = 0; i < num_hidden; ++i) EHM_CHECK_ARG(hidden[i].in_dim == hid_dim && hidden[i].out_dim == hid_dim && hidden[i].W);
   hipStream_t st = (hipStream_t)stream;
   auto* g = new ehm_gcn();
+  if (const char* e = getenv("EHM_F16_STAGING")) g->reg_staging = strcmp(e, "reg") == 0;
+  if (const char* e = getenv("EHM_F16_PERSISTENT")) g->persistent = atoi(e) != 0;
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
   const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ;
@@ -538,7 +542,7 @@ extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
 }
 extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
 extern "C" int ehm_gcn_set_tile_override(ehm_gcn* h, int mode) {
-  EHM_CHECK_ARG(h && mode >= 0 && mode <= 2);
+  EHM_CHECK_ARG(h && mode >= 0 && mode <= 8);
   h->tile_override = mode;
   return 0;
 }

@@ -41,6 +41,8 @@ struct ehm_gcn {
   int hid = 0;
   int num_hidden = 0;
   int precision = EHM_PREC_F32;
+  int reg_staging = 0;     // split-f16 convs: 1 = global_load -> VGPR -> ds_write staging, 0 = global_load_lds DMA
+  int persistent = 0;      // split-f16 convs: 1 = grid capped at the co-resident slots, blocks loop over tiles
   int tile_override = 0;   // split-f16 convs: 0 = pick by size, 1 = 192x64 tiles, 2 = 384x128 tiles
   LayerDev input{};
   LayerDev hidden[16]{};

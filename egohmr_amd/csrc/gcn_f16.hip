@@ -26,7 +26,7 @@ namespace {
 //   <1,1>: 192 x 64,  80 KiB LDS, 2 blocks/CU (2 waves/SIMD)          - small launches
 //   <1,2>: 192 x 128, 112 KiB LDS, 1 block/CU (1 wave/SIMD)          - 30 % less L2->LDS traffic, measured slower (see launch())
 //   <2,2>: 384 x 128 would halve the traffic but hipcc spills its 384 accumulator registers inside the K loop.
-template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN>
+template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN, int EXP = 8>
 __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_kernel(const half_t* __restrict__ X, LayerDev L,
                                                                                      const half_t* __restrict__ Res,
                                                                                      float* __restrict__ Y, int m_tiles) {
@@ -38,16 +38,20 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
 
   const int K = L.K, N = L.N;
   const int n_tiles = N / (64 * WN);
-  int bid = blockIdx.x;
   const int total = m_tiles * n_tiles;
-  int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
-  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
-  const size_t m0 = (size_t)m_tile * BM_;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+
+  // Persistent blocks: the grid is capped at what is co-resident (2 blocks per CU) and every block walks tiles
+  // bid, bid + grid, ... .  With 1024 tiles on 512 slots each block does exactly two: no CU ends up with 3 or 5 of the
+  // 4-per-CU average (measured: kernel span 2.5x one block's life time instead of 2x with one block per tile).
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+  // XCD-aware order: tile % 8 == blockIdx % 8 == XCD, which owns a contiguous run of (row tile, all channel tiles)
+  const int lin = ((total & 7) == 0 && (gridDim.x & 7) == 0) ? (tile & 7) * (total >> 3) + (tile >> 3) : tile;
+  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
+  const size_t m0 = (size_t)m_tile * BM_;
 
   // ---- global -> LDS DMA: rows of 128 B (= K-tile of 32: 4 hi chunks + 4 lo chunks), physical chunk c holds logical c ^ key(row)
   const int ld_r = lane >> 3, ld_c = lane & 7;
@@ -68,6 +72,24 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
 #pragma unroll
     for (int i = 0; i < NLB; ++i)
       __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * BK), (AS3 void*)(base + A_T + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+
+  // register-staged alternative (EXP & 8): global_load_dwordx4 -> VGPR -> ds_write_b128 to the same LDS image.  Measured
+  // (rocprofv3 SQ_WAVE_CYCLES, with vs without the loads): one global_load_lds costs the issuing wave ~134 cycles, ten of
+  // them per K tile = more than the tile's 1152 MFMA cycles; a plain load + LDS write is several times cheaper to issue.
+  f32x4 sreg[(EXP & 8) ? NLA + NLB : 1];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) sreg[i] = *(const f32x4*)(pA + i * row32 + kt * BK);
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) sreg[NLA + i] = *(const f32x4*)(pB + i * row32 + kt * BK);
+  };
+  auto lwrite = [&](int buf) {
+    float* base = lds + buf * STG + lane * 4;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) *(f32x4*)(base + (wave + 4 * i) * 256) = sreg[i];
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) *(f32x4*)(base + A_T + (wave + 4 * i) * 256) = sreg[NLA + i];
   };
 
   // ---- fragments: v_mfma_f32_32x32x16_f16 lane l holds row l&31, k = 8*(l>>5) .. +7 of a 16-wide step
@@ -97,12 +119,24 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
         for (int r = 0; r < 16; ++r) { acc0[a][c][t][r] = 0.f; acc1[a][c][t][r] = 0.f; }
 
   const int KT = K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (EXP & 8) {
+    gload(0);
+    lwrite(0);
     __syncthreads();
-    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
-    const float* As = lds + (kt & 1) * STG;
+  } else {
+    stage(0, 0);
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    if (EXP & 8) {
+      if (kt + 1 < KT) gload(kt + 1);                      // in flight during this tile's MFMAs
+    } else {
+      if (!(EXP & 2)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (!(EXP & 1) && kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
+    }
+    const float* As = lds + ((EXP & 1) ? 0 : (kt & 1)) * STG + ((EXP & 4) ? (kt & 0) : 0);
     const float* Bs = As + A_T;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {                          // two 16-wide k steps per 32-wide tile
@@ -138,42 +172,52 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
         }
       }
     }
+    if (EXP & 8) {
+      if (kt + 1 < KT) lwrite((kt + 1) & 1);               // the other buffer: everyone left it at the previous barrier
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue (same staging as the f32 kernel; Ds/M1s carry 1/w_scale), one (row group, channel group) at a time ----
+  // ---- epilogue (Ds/M1s carry 1/w_scale), one (channel group, row group) at a time; staged with sched_barrier so that at most
+  //      the accumulators + one 24-wide batch of loads are live (the staging registers of the K loop are dead here) ----
 #pragma unroll
   for (int c = 0; c < WN; ++c) {
     const int n = 64 * WN * n_tile + 32 * (WN * wn + c) + mi;
-    float dj[kJ], mj[kJ];
-    const float sh = L.shift[n];
+    {
+      float dj[kJ], mj[kJ];
+      const float sh = L.shift[n];
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) { dj[j] = L.Ds[j * N + n]; mj[j] = L.M1s[j * N + n]; }
+      for (int j = 0; j < kJ; ++j) { dj[j] = L.Ds[j * N + n]; mj[j] = L.M1s[j * N + n]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int q = 0; q < 48; ++q) {   // fold modulation / BatchNorm scale into the accumulators in place
+          acc0[a][c][q >> 4][q & 15] = fmaf(dj[q % 24], acc0[a][c][q >> 4][q & 15], sh);
+          acc1[a][c][q >> 4][q & 15] *= mj[q % 24];
+        }
+    }
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
-      const size_t rowb = m0 + 96 * (WM * wm + a) + 48 * g;
-      float res0[kJ], res1[kJ];
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) res0[j] = RES ? split_load_pair(Res, rowb + j, n, N) : 0.f;
+      for (int beta = 0; beta < 2; ++beta) {
+        const size_t rowb = m0 + 96 * (WM * wm + a) + 48 * g + 24 * beta;
+        __builtin_amdgcn_sched_barrier(0);
+        float res[kJ];
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) res1[j] = RES ? split_load_pair(Res, rowb + 24 + j, n, N) : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-      float d0[kJ], g1[kJ];
+        for (int j = 0; j < kJ; ++j) res[j] = RES ? split_load_pair(Res, rowb + j, n, N) : 0.f;
+        float d0[kJ], g1[kJ];
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) {
-        d0[j] = fmaf(dj[j], acc0[a][c][j >> 4][j & 15], sh);
-        g1[j] = acc1[a][c][j >> 4][j & 15] * mj[j];
+        for (int j = 0; j < kJ; ++j) {
+          const int q = 24 * beta + j;
+          d0[j] = acc0[a][c][q >> 4][q & 15];
+          g1[j] = acc1[a][c][q >> 4][q & 15];
+        }
+        gcn_mix_store<OUT_SPLIT>(d0, g1, res, n, N, rowb, L.Aoff, Y, L.relu != 0);
       }
-      gcn_mix_store<OUT_SPLIT>(d0, g1, res0, n, N, rowb, L.Aoff, Y, L.relu != 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < kJ; ++j) {
-        d0[j] = fmaf(dj[j], acc0[a][c][(24 + j) >> 4][(24 + j) & 15], sh);
-        g1[j] = acc1[a][c][(24 + j) >> 4][(24 + j) & 15] * mj[j];
-      }
-      gcn_mix_store<OUT_SPLIT>(d0, g1, res1, n, N, rowb + 24, L.Aoff, Y, L.relu != 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  }   // persistent tile loop
 }
 
 // float32 [rows][K] <-> X2 split format (tests / interop; the sampler never needs them)
@@ -188,21 +232,23 @@ __global__ void unpack_x2_kernel(const half_t* __restrict__ X, float* __restrict
   Y[i] = split_load(X, (size_t)(i / K), (int)(i % K), K);
 }
 
-template <int PASSES, int WM, int WN>
+template <int PASSES, int WM, int WN, int EXP>
 int launch_cfg(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split,
                hipStream_t st) {
   const int m_tiles = (int)(rows_pad / (192 * WM));
-  const int blocks = m_tiles * (h->hid / (64 * WN));
+  const int tiles = m_tiles * (h->hid / (64 * WN));
+  const int slots = ehm_num_cus() * ((WM * WN == 1) ? 2 : 1);      // co-resident blocks (LDS-limited)
+  const int blocks = (tiles < slots || !h->persistent) ? tiles : slots;
   const LayerDev& L = h->hidden[layer];
   const half_t* x = (const half_t*)X;
   const half_t* r = (const half_t*)residual;
   float* y = (float*)out;
   if (residual) {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
   } else {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -214,9 +260,23 @@ int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, voi
   // (1 wave/SIMD) 217 us - halving the L2->LDS traffic does not pay for the lost latency hiding, so the small tile is the
   // default and the big one stays selectable for experiments.
   const int force = h->tile_override;   // 0 / 1 = 192x64, 2 = 192x128
+  if (force >= 3 && force <= 7) {   // timing experiments (results are wrong on purpose): bit0 no DMA in the K loop, bit1 no barrier, bit2 loop-invariant LDS reads
+    const int m_tiles = (int)(rows_pad / 192);
+    const dim3 grid(m_tiles * (h->hid / 64));
+    const half_t* x = (const half_t*)X;
+    const half_t* r0 = nullptr;
+    if (force == 3) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, 1, 1, 1>), grid, dim3(256), 0, st, x, h->hidden[layer], r0, (float*)out, m_tiles);
+    if (force == 4) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, 1, 1, 3>), grid, dim3(256), 0, st, x, h->hidden[layer], r0, (float*)out, m_tiles);
+    if (force == 5) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, 1, 1, 5>), grid, dim3(256), 0, st, x, h->hidden[layer], r0, (float*)out, m_tiles);
+    if (force == 6) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, 1, 1, 7>), grid, dim3(256), 0, st, x, h->hidden[layer], r0, (float*)out, m_tiles);
+    if (force == 7) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, 1, 1, 0>), grid, dim3(256), 0, st, x, h->hidden[layer], r0, (float*)out, m_tiles);   // global_load_lds staging
+    EHM_LAUNCH_CHECK();
+    return 0;
+  }
   if (force == 2 && h->hid % 128 == 0)
-    return launch_cfg<PASSES, 1, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
-  return launch_cfg<PASSES, 1, 1>(h, layer, X, residual, out, rows_pad, out_split, st);
+    return launch_cfg<PASSES, 1, 2, 8>(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (h->reg_staging) return launch_cfg<PASSES, 1, 1, 8>(h, layer, X, residual, out, rows_pad, out_split, st);
+  return launch_cfg<PASSES, 1, 1, 0>(h, layer, X, residual, out, rows_pad, out_split, st);
 }
 
 }  // namespace

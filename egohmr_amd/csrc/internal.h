@@ -15,6 +15,8 @@ int ehm_smpl_num_extra(const ehm_smpl* h);
 // gcn.hip
 int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
+// sampler.hip
+int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 // gcn_f16.hip
 int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
                             bool out_split, hipStream_t st);

@@ -24,6 +24,19 @@ void ehm_set_error(const char* fmt, ...) {
 extern "C" const char* ehm_last_error(void) { return g_err; }
 extern "C" const char* ehm_target_arch(void) { return "gfx950"; }
 
+int ehm_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    else
+      n = 256;   // MI355X
+  }
+  return n;
+}
+
 namespace {
 
 // torch evaluates these chains as separate rounded float32 ops; keep the same roundings (no FMA contraction)

@@ -54,6 +54,45 @@ class ResNet50Features(nn.Module):
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return x.mean(dim=(2, 3))
 
+    # ------------------------------------------------------------------ inference form: BatchNorm folded into the convolutions
+    fold_batchnorm = True
+
+    @torch.no_grad()
+    def folded(self, channels_last: bool = True):
+        """Eval-mode equivalent with every BatchNorm2d folded into its convolution (w' = w * g/sqrt(v+eps),
+        b' = beta - mean * g/sqrt(v+eps); exact up to float re-association) - removes 53 BatchNorm and most ReLU/add passes."""
+        def fold(conv, bn):
+            scale = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+            w = (conv.weight.double() * scale.view(-1, 1, 1, 1)).float()
+            b = (bn.bias.double() - bn.running_mean.double() * scale).float()
+            if channels_last:
+                w = w.contiguous(memory_format=torch.channels_last)
+            return w, b, conv.stride, conv.padding
+
+        stem = fold(self.conv1, self.bn1)
+        blocks = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), fold(blk.conv3, blk.bn3),
+                               fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+
+        def conv(x, p):
+            return F.conv2d(x, p[0], p[1], stride=p[2], padding=p[3])
+
+        def run(x):
+            if channels_last:
+                x = x.contiguous(memory_format=torch.channels_last)
+            x = F.max_pool2d(F.relu_(conv(x, stem)), 3, stride=2, padding=1)
+            for c1, c2, c3, ds in blocks:
+                y = F.relu_(conv(x, c1))
+                y = F.relu_(conv(y, c2))
+                y = conv(y, c3)
+                y += x if ds is None else conv(x, ds)
+                x = F.relu_(y)
+            return x.mean(dim=(2, 3))
+
+        return run
+
 
 class _ResBlockFC(nn.Module):
     def __init__(self, cin, cout, hidden):

@@ -358,6 +358,14 @@ class FusedSampler:
     def __del__(self):
         self._free()
 
+    def _backbone_fn(self):
+        """ResNet-50 with BatchNorm folded into the convolutions, rebuilt when the backbone weights change."""
+        bb = self.model.backbone
+        key = tuple((t.data_ptr(), t._version) for t in list(bb.parameters()) + list(bb.buffers()))
+        if getattr(self, "_bb_key", None) != key:
+            self._bb_fn, self._bb_key = bb.folded(channels_last=False), key
+        return self._bb_fn
+
     # ------------------------------------------------------------------ step-invariant conditioning
     @torch.no_grad()
     def prepare(self, batch) -> _Prepared:
@@ -369,7 +377,7 @@ class FusedSampler:
         self.gcn()
         dev = m.device
         g = lambda k: _lib.f32(batch[k], dev)
-        img_feats = m.backbone(g("img"))                                               # :183
+        img_feats = self._backbone_fn()(g("img"))                                      # :183 (BatchNorm folded into the convs)
         transl = _lib.f32(batch["smpl_params"]["transl"], dev)
         scene = g("scene_pcd_verts_full")
         if m.scene_cano:

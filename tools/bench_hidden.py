@@ -18,6 +18,8 @@ model = build_synthetic_model(dev, 0)
 model.gcn_precision = prec
 L = _lib.lib()
 h = model.fused_sampler.gcn()
+if os.environ.get("EHM_TILE"):
+    _lib.check(L.ehm_gcn_set_tile_override(h, int(os.environ["EHM_TILE"])))
 hid, tile = model.diffusion_model.hid_dim, L.ehm_gcn_row_tile()
 rows_pad = (2 * B * 24 + tile - 1) // tile * tile
 X = torch.randn(rows_pad, hid, device=dev)

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_f16.hip", "linear.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_f16.hip", "linear.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -103,6 +103,7 @@ PROTOTYPES = {
     "ehm_collision_proxy": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "ehm_smpl_backward_rot6d": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "ehm_guidance_grad_finish": (_I, [_P, _P, _P, _I, _F, _P]),
+    "ehm_nn_dist2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ehm_sample_workspace_bytes": (_L, [C.POINTER(SampleDesc), _I, _I]),
     "ehm_sample_loop": (_I, [_P, _P, C.POINTER(SampleDesc), C.POINTER(StepCoefs)] + [_P] * 18 + [_L, _P]),
 }

@@ -1,0 +1,92 @@
+"""Evaluation metrics of the reference's driver, on the device (SURVEY.md section 8f "next" rows 1 and 3).
+
+* chamfer_distance / contact_score   utils/pytorch3d_chamfer_distance.py:70-218, test_egohmr.py:496-505
+  (nearest-neighbour search = HIP kernel ehm_nn_dist2; the reference uses pytorch3d's CUDA knn_points)
+* mpjpe / g_mpjpe / v2v                test_egohmr.py:399-443
+* pa_mpjpe (batched Procrustes)        utils/pose_utils.py:10-66, :109-126 (the reference loops numpy SVDs per sample on the CPU)
+* std_diversity / apd                  test_egohmr.py:453-494
+These are thin post-loop reductions; only the NN search is a hand-written kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def nn_dist2(x: torch.Tensor, y: torch.Tensor, return_idx: bool = False):
+    """Squared distance from every x[b,i] to its nearest y[b,:] (pytorch3d knn_points K=1 'dists')."""
+    x, y = _lib.f32(x), _lib.f32(y)
+    assert x.dim() == 3 and y.dim() == 3 and x.shape[0] == y.shape[0] and x.shape[2] == y.shape[2] == 3
+    B, P1, P2 = x.shape[0], x.shape[1], y.shape[1]
+    d = torch.empty(B, P1, device=x.device, dtype=torch.float32)
+    idx = torch.empty(B, P1, device=x.device, dtype=torch.int32) if return_idx else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ehm_nn_dist2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(d), _lib.ptr(idx), B, P1, P2, _lib.stream_ptr()), "ehm_nn_dist2")
+    return (d, idx) if return_idx else d
+
+
+def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,
+                     batch_reduction=None, point_reduction="mean"):
+    """The reference's (modified) chamfer_distance: returns per-point squared NN distances
+    (cham_x [N,P1], cham_y [N,P2], None) - its point reduction is commented out (pytorch3d_chamfer_distance.py:186-195)."""
+    if x_lengths is not None or y_lengths is not None or x_normals is not None or y_normals is not None:
+        raise NotImplementedError("ragged clouds / normals are not used by the EgoHMR driver")
+    cham_x, cham_y = nn_dist2(x, y), nn_dist2(y, x)
+    if weights is not None:
+        cham_x, cham_y = cham_x * weights.view(-1, 1), cham_y * weights.view(-1, 1)
+    if batch_reduction is not None:
+        cham_x, cham_y = cham_x.sum(), cham_y.sum()
+        if batch_reduction == "mean":
+            div = weights.sum() if weights is not None else x.shape[0]
+            cham_x, cham_y = cham_x / div, cham_y / div
+    return cham_x, cham_y, None
+
+
+def contact_score(pred_vertices_full: torch.Tensor, scene_pcd: torch.Tensor, thres: float = 0.02) -> torch.Tensor:
+    """test_egohmr.py:496-505: a body is 'in contact' when its minimum SQUARED vertex-scene distance is < thres."""
+    return nn_dist2(pred_vertices_full, scene_pcd).min(dim=-1)[0] < thres
+
+
+def mpjpe(pred_joints: torch.Tensor, gt_joints: torch.Tensor) -> torch.Tensor:
+    """test_egohmr.py:409-411: pelvis-aligned mean per-joint error over the first 24 joints -> [...]."""
+    p, g = pred_joints[..., :24, :], gt_joints[..., :24, :]
+    return torch.sqrt((((p - p[..., :1, :]) - (g - g[..., :1, :])) ** 2).sum(dim=-1)).mean(dim=-1)
+
+
+def g_mpjpe(pred_joints_full: torch.Tensor, gt_joints_full: torch.Tensor) -> torch.Tensor:
+    """test_egohmr.py:399-401: error in the camera frame, no alignment."""
+    return torch.sqrt(((pred_joints_full[..., :24, :] - gt_joints_full[..., :24, :]) ** 2).sum(dim=-1)).mean(dim=-1)
+
+
+def v2v(pred_vertices: torch.Tensor, pred_pelvis, gt_vertices: torch.Tensor, gt_pelvis) -> torch.Tensor:
+    """test_egohmr.py:441-443: pelvis-aligned mean vertex-to-vertex error."""
+    return torch.sqrt((((pred_vertices - pred_pelvis) - (gt_vertices - gt_pelvis)) ** 2).sum(dim=-1)).mean(dim=-1)
+
+
+def similarity_align(S1: torch.Tensor, S2: torch.Tensor) -> torch.Tensor:
+    """utils/pose_utils.py:10-66 batched on the device: the similarity transform of S1 [n,J,3] closest to S2."""
+    mu1, mu2 = S1.mean(dim=1, keepdim=True), S2.mean(dim=1, keepdim=True)
+    X1, X2 = S1 - mu1, S2 - mu2
+    var1 = (X1 ** 2).sum(dim=(1, 2))
+    K = X1.transpose(1, 2) @ X2                                          # [n,3,3] = X1^T X2  (pose_utils.py:36 with 3xN layout)
+    U, s, Vh = torch.linalg.svd(K)
+    V = Vh.transpose(1, 2)
+    Z = torch.eye(3, device=S1.device, dtype=S1.dtype).repeat(S1.shape[0], 1, 1)
+    Z[:, -1, -1] = torch.sign(torch.linalg.det(U @ V.transpose(1, 2)))
+    R = V @ Z @ U.transpose(1, 2)
+    scale = (R @ K).diagonal(dim1=1, dim2=2).sum(dim=1) / var1
+    t = mu2.transpose(1, 2) - scale.view(-1, 1, 1) * (R @ mu1.transpose(1, 2))
+    return (scale.view(-1, 1, 1) * (R @ S1.transpose(1, 2)) + t).transpose(1, 2)
+
+
+def pa_mpjpe(pred_joints: torch.Tensor, gt_joints: torch.Tensor) -> torch.Tensor:
+    """utils/pose_utils.py:109-126 (reconstruction_error): Procrustes-aligned mean joint error -> [n]."""
+    p = pred_joints.reshape(-1, pred_joints.shape[-2], 3).double()
+    g = gt_joints.reshape(-1, gt_joints.shape[-2], 3).double()
+    return torch.sqrt(((similarity_align(p, g) - g) ** 2).sum(dim=-1)).mean(dim=-1).float()
+
+
+def std_diversity(pred_joints_aligned: torch.Tensor) -> torch.Tensor:
+    """test_egohmr.py:453-455: std over the sample axis of [B,S,24,3], averaged over joints and coordinates."""
+    return torch.std(pred_joints_aligned, dim=1, unbiased=True).mean(dim=-1).mean(dim=-1)

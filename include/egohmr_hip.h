@@ -200,6 +200,12 @@ int ehm_smpl_backward_rot6d(ehm_smpl* h, const float* betas, const float* x, con
  * joints 3..23 scaled by 2, joints {0,3,6,9,12..23} zeroed; all-zero loss -> zeros. */
 int ehm_guidance_grad_finish(const float* gpose6d, const float* loss, float* grad, int B, float denom, void* stream);
 
+/* ------------------------------------------------------------------ post-loop metric ---------- */
+/* pytorch3d.ops.knn_points(x, y, K=1) as used by utils/pytorch3d_chamfer_distance.py:152-156 (contact score,
+ * test_egohmr.py:496-505): for every x[b,i] the SQUARED distance to its nearest y[b,:] and (optionally) its index.
+ * x [B,P1,3], y [B,P2,3] -> dist2 [B,P1], idx [B,P1] int32 or NULL. */
+int ehm_nn_dist2(const float* x, const float* y, float* dist2, int32_t* idx, int B, int P1, int P2, void* stream);
+
 /* ------------------------------------------------------------------ whole sampling loop ------- */
 /* One executed step of the loop (host-side table lookup already done, float32 like
  * _extract_into_tensor, gaussian_diffusion.py:794). */

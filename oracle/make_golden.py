@@ -320,6 +320,17 @@ def g8_g9_end_to_end(model):
              x_t_trace=np.stack(xs), **_pack_out(o))
 
 
+def g11_procrustes():
+    from utils.pose_utils import reconstruction_error
+    g = np.random.Generator(np.random.PCG64(15))
+    gt = g.normal(scale=0.4, size=(16, 24, 3))
+    th = 0.6
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    pred = 1.3 * gt @ Rz.T + np.array([0.2, -0.1, 0.5]) + g.normal(scale=0.03, size=gt.shape)
+    pred[8:] = g.normal(scale=0.4, size=(8, 24, 3))            # unrelated poses: large residual
+    save("g11_procrustes", pred=pred, gt=gt, pa_mpjpe=reconstruction_error(pred, gt), pa_per_joint=reconstruction_error(pred, gt, avg_joint=False))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
@@ -330,6 +341,9 @@ def main():
     g2_g3_geometry()
     g4_gcn()
     g7_single_steps()
+    g11_procrustes()
+    if os.environ.get("GOLDEN_ONLY") == "g11":
+        return
     sd = syn.make_state_dict(0)
     mean, std = syn.make_body_rep_stats(0)
     model = build_reference_model(sd, asset, mean, std, diffuse_fuse=True)

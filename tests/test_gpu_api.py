@@ -1,0 +1,178 @@
+"""GPU: behaviour of the reference's call surface beyond plain parity - RNG draw order, dump_steps, skip_timesteps /
+init_data, multiple samples per item, error behaviour, konia rotmat->axis-angle, SMPL_*.pkl loading without chumpy."""
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from egohmr_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev, synth_weights, smpl_asset):
+    from egohmr_amd.factory import build_synthetic_model
+    return build_synthetic_model(dev, 0, diffuse_fuse=True, state_dict=synth_weights, smpl_asset=smpl_asset)
+
+
+def _batch(dev, B=3, N=512, seed=9):
+    from egohmr_amd.factory import batch_to_device
+    return batch_to_device(syn.make_batch(B, N, seed=seed), dev)
+
+
+@pytest.mark.parametrize("rs", ["", "ddim5"])
+def test_rng_draw_order_matches_reference(dev, model, rs):
+    """Without an explicit noise stack the sampler must consume torch's generator exactly like the reference:
+    randn(*shape) once, then randn_like once per step including t == 0 (gaussian_diffusion.py:478,331,547)."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=20, timestep_respacing=rs)
+    B = 3
+    torch.manual_seed(1234)
+    rows = [torch.randn(B, 144, device=dev)]
+    for _ in range(d.num_timesteps):
+        rows.append(torch.randn_like(rows[0]))
+    after = torch.randn(4, device=dev)                      # generator position after the loop
+    expect = d.val_losses(model, _batch(dev), shape=[B, 144], timestep_respacing=rs, compute_loss=False, noise_stack=torch.stack(rows))
+    for fused in (True, False):
+        d.allow_fused = fused
+        torch.manual_seed(1234)
+        got = d.val_losses(model, _batch(dev), shape=[B, 144], timestep_respacing=rs, compute_loss=False)
+        assert torch.equal(torch.randn(4, device=dev), after), "generator consumed differently from the reference's loop"
+        np.testing.assert_allclose(got["pred_vertices"].cpu().numpy(), expect["pred_vertices"].cpu().numpy(), atol=2e-6)
+
+
+def test_dump_steps_and_progressive_loop(dev, model):
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=10, timestep_respacing="")
+    B = 2
+    noise = torch.from_numpy(syn.make_noise_stack(10, B, seed=3)).to(dev)
+    b = _batch(dev, B)
+    steps = list(d.p_sample_loop_progressive(model, b, [B, 144], noise_stack=noise))
+    assert len(steps) == 10 and set(steps[0]) == {"sample", "pred_xstart", "other_outputs"}
+    dump = d.p_sample_loop(model, _batch(dev, B), [B, 144], dump_steps=[0, 4, 9], noise_stack=noise)
+    assert isinstance(dump, list) and len(dump) == 3
+    for got, k in zip(dump, (0, 4, 9)):
+        np.testing.assert_allclose(got.cpu().numpy(), steps[k]["sample"].cpu().numpy(), atol=1e-6)
+    fused = model.fused_sampler.run(d, _batch(dev, B), noise, ddim=False)
+    np.testing.assert_allclose(fused["sample"].cpu().numpy(), steps[-1]["sample"].cpu().numpy(), atol=2e-6)
+
+
+def test_skip_timesteps_and_init_data(dev, model):
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=10, timestep_respacing="")
+    B = 2
+    calls = []
+    orig = model.forward
+
+    def spy(batch, t, **kw):
+        calls.append(int(t[0]))
+        return orig(batch, t, **kw)
+
+    model.forward = spy
+    try:
+        torch.manual_seed(0)
+        init = torch.zeros(B, 144, device=dev)
+        out = d.p_sample_loop(model, _batch(dev, B), [B, 144], skip_timesteps=7, init_data=init)
+    finally:
+        model.forward = orig
+    assert calls == [2, 1, 0]                                   # indices T-1-skip .. 0 (gaussian_diffusion.py:483)
+    assert torch.isfinite(out["sample"]).all() and out["sample"].shape == (B, 144)
+
+
+def test_multiple_samples_share_conditioning(dev, model):
+    """test_egohmr.py:251-266: S sequential val_losses calls over the SAME batch object; conditioning is encoded once."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    B, S = 3, 4
+    b = _batch(dev, B)
+    outs = []
+    n_enc = []
+    orig = model.fused_sampler._backbone_fn
+
+    def count():
+        n_enc.append(1)
+        return orig()
+
+    model.fused_sampler._backbone_fn = count
+    try:
+        for s in range(S):
+            outs.append(d.val_losses(model, b, shape=[B, 144], timestep_respacing="ddim5", compute_loss=False,
+                                     noise_stack=torch.from_numpy(syn.make_noise_stack(5, B, seed=100 + s)).to(dev)))
+    finally:
+        model.fused_sampler._backbone_fn = orig
+    assert len(n_enc) == 1
+    poses = torch.stack([o["pred_smpl_params"]["body_pose"] for o in outs], dim=1)       # [B,S,23,3,3]
+    assert poses.shape == (B, S, 23, 3, 3) and float((poses[:, 0] - poses[:, 1]).abs().max()) > 1e-4   # different noise -> different samples
+    betas = torch.stack([o["pred_smpl_params"]["betas"] for o in outs], dim=1)
+    assert float((betas - betas[:, :1]).abs().max()) == 0.0                             # betas do not depend on the sample
+
+
+def test_error_behaviour(dev, model):
+    from egohmr_amd import _lib
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=10, timestep_respacing="")
+    with pytest.raises(SystemExit):                               # gaussian_diffusion.py:774-775 prints and exits
+        d.val_losses(model, _batch(dev), shape=[3, 144], timestep_respacing="bogus", compute_loss=False)
+    with pytest.raises(ValueError):
+        create_gaussian_diffusion(num_diffusion_timesteps=10, timestep_respacing="ddim7")
+    with pytest.raises(_lib.EgoHMRHipError):                      # CPU tensors never fall back to eager
+        model.scene_enc(torch.zeros(1, 128, 3))
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(model, _batch(dev), [3, 144], cond_fn_with_grad=True)
+
+
+def test_rotation_matrix_to_angle_axis_vs_reference_golden(golden_dir, dev):
+    from egohmr_amd.geometry import rotation_matrix_to_angle_axis
+    g = np.load(os.path.join(golden_dir, "g3_rotmat_to_aa.npz"))
+    out = rotation_matrix_to_angle_axis(torch.from_numpy(g["R"]).to(dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["aa"], atol=2e-5)
+
+
+def test_smpl_pkl_loads_without_chumpy(tmp_path, dev, smpl_asset):
+    """official SMPL_*.pkl files are chumpy-pickled; the loader must read them with chumpy absent."""
+    from egohmr_amd import smpl as smpl_mod
+    import scipy.sparse as sp
+    fake = types.ModuleType("chumpy")
+    fake_ch = types.ModuleType("chumpy.ch")
+
+    class Ch:                                   # minimal stand-in that pickles like chumpy.ch.Ch (state dict with the array in 'x')
+        def __init__(self, x):
+            self.x = np.asarray(x)
+
+        def __getstate__(self):
+            return {"x": self.x, "_dirty_vars": set()}
+
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
+    fake_ch.Ch = Ch
+    fake.ch = fake_ch
+    sys.modules["chumpy"], sys.modules["chumpy.ch"] = fake, fake_ch
+    V = 6890
+    a = smpl_asset
+    kin = np.stack([np.concatenate([[2 ** 32 - 1], a["parents"][1:]]), np.arange(24)]).astype(np.uint32)
+    posedirs_pkl = a["posedirs"].T.reshape(V, 3, 207)                      # pkl layout [V,3,207]
+    d = {"v_template": a["v_template"].astype(np.float64), "shapedirs": Ch(np.concatenate([a["shapedirs"], np.zeros((V, 3, 290))], -1)),
+         "posedirs": posedirs_pkl.astype(np.float64), "J_regressor": sp.csc_matrix(a["J_regressor"].astype(np.float64)),
+         "weights": a["lbs_weights"].astype(np.float64), "kintree_table": kin, "f": a["faces"].astype(np.uint32)}
+    os.makedirs(tmp_path / "smpl")
+    with open(tmp_path / "smpl" / "SMPL_NEUTRAL.pkl", "wb") as f:
+        pickle.dump(d, f, protocol=2)
+    del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+    m = smpl_mod.create(str(tmp_path / "smpl"), model_type="smpl", gender="neutral").to(dev)
+    ref = smpl_mod.create(asset=smpl_asset).to(dev)
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+        np.testing.assert_allclose(getattr(m, k).cpu().numpy(), getattr(ref, k).cpu().numpy(), atol=1e-7, err_msg=k)
+    assert m.parents.tolist() == ref.parents.tolist() and m.faces.shape == (13776, 3)
+    betas = torch.zeros(1, 10, device=dev)
+    I = torch.eye(3, device=dev).expand(1, 24, 3, 3).contiguous()
+    np.testing.assert_allclose(m(betas=betas, body_pose=I[:, 1:], global_orient=I[:, :1], pose2rot=False).vertices.cpu().numpy(),
+                               ref(betas=betas, body_pose=I[:, 1:], global_orient=I[:, :1], pose2rot=False).vertices.cpu().numpy(), atol=1e-6)

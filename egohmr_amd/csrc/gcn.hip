@@ -542,7 +542,7 @@ extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
 }
 extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
 extern "C" int ehm_gcn_set_tile_override(ehm_gcn* h, int mode) {
-  EHM_CHECK_ARG(h && mode >= 0 && mode <= 8);
+  EHM_CHECK_ARG(h && mode >= 0 && mode <= 9);
   h->tile_override = mode;
   return 0;
 }

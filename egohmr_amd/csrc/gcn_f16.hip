@@ -26,14 +26,15 @@ namespace {
 //   <1,1>: 192 x 64,  80 KiB LDS, 2 blocks/CU (2 waves/SIMD)          - small launches
 //   <1,2>: 192 x 128, 112 KiB LDS, 1 block/CU (1 wave/SIMD)          - 30 % less L2->LDS traffic, measured slower (see launch())
 //   <2,2>: 384 x 128 would halve the traffic but hipcc spills its 384 accumulator registers inside the K loop.
-template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN, int EXP = 8>
-__global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_kernel(const half_t* __restrict__ X, LayerDev L,
+template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN, int EXP = 8, int NWM = 2>
+__global__ __launch_bounds__(128 * NWM, (NWM == 4 || WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_kernel(const half_t* __restrict__ X, LayerDev L,
                                                                                      const half_t* __restrict__ Res,
                                                                                      float* __restrict__ Y, int m_tiles) {
-  constexpr int BM_ = 192 * WM;              // rows per block
+  constexpr int NW = 2 * NWM;                // waves per block: NWM along rows x 2 along channels
+  constexpr int BM_ = 96 * NWM * WM;         // rows per block
   constexpr int BR_ = 128 * WN;              // weight rows per block (2 branches x 64*WN channels) = WN consecutive packed tiles
   constexpr int A_T = BM_ * BK, B_T = BR_ * BK, STG = A_T + B_T;   // floats
-  constexpr int NLA = BM_ / 32, NLB = BR_ / 32;                    // DMA wave-instructions per wave: A rows/8/4, B rows/8/4
+  constexpr int NLA = BM_ / (8 * NW), NLB = BR_ / (8 * NW);       // staging wave-instructions (8 rows each) per wave
   __shared__ __attribute__((aligned(16))) float lds[2 * STG];
 
   const int K = L.K, N = L.N;
@@ -63,15 +64,15 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
   const int swz = (ld_c ^ ((r0 >> 1) & 7)) << 2;
   const float* pA = Xf + (m0 + r0) * K + swz;
   const float* pB = Wf + ((size_t)n_tile * BR_ + r0) * K + swz;
-  const size_t row32 = (size_t)32 * K;
+  const size_t row32 = (size_t)8 * NW * K;   // rows between consecutive staging instructions of one wave
   auto stage = [&](int buf, int kt) {
     float* base = lds + buf * STG;
 #pragma unroll
     for (int i = 0; i < NLA; ++i)
-      __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * BK), (AS3 void*)(base + (wave + 4 * i) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * BK), (AS3 void*)(base + (wave + NW * i) * 256), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < NLB; ++i)
-      __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * BK), (AS3 void*)(base + A_T + (wave + 4 * i) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * BK), (AS3 void*)(base + A_T + (wave + NW * i) * 256), 16, 0, 0);
   };
 
   // register-staged alternative (EXP & 8): global_load_dwordx4 -> VGPR -> ds_write_b128 to the same LDS image.  Measured
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
   auto lwrite = [&](int buf) {
     float* base = lds + buf * STG + lane * 4;
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) *(f32x4*)(base + (wave + 4 * i) * 256) = sreg[i];
+    for (int i = 0; i < NLA; ++i) *(f32x4*)(base + (wave + NW * i) * 256) = sreg[i];
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) *(f32x4*)(base + A_T + (wave + 4 * i) * 256) = sreg[NLA + i];
+    for (int i = 0; i < NLB; ++i) *(f32x4*)(base + A_T + (wave + NW * i) * 256) = sreg[NLA + i];
   };
 
   // ---- fragments: v_mfma_f32_32x32x16_f16 lane l holds row l&31, k = 8*(l>>5) .. +7 of a 16-wide step
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
             bh[u] = *(const half8*)(Bs + (rB[c] + 64 * u) * BK + ((ch ^ keyB[c]) << 2));
             if (PASSES == 3) bl[u] = *(const half8*)(Bs + (rB[c] + 64 * u) * BK + ((cl ^ keyB[c]) << 2));
           }
+          if (EXP & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             if (PASSES == 3) {                              // small cross terms first, leading term last
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(256, (WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_ke
             acc0[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[0], acc0[a][c][t], 0, 0, 0);
             acc1[a][c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[1], acc1[a][c][t], 0, 0, 0);
           }
+          if (EXP & 16) __builtin_amdgcn_s_setprio(0);
           if (WM * WN > 1) __builtin_amdgcn_sched_barrier(0);   // big tile: keep hipcc from hoisting every fragment load (spills)
         }
       }
@@ -232,23 +235,23 @@ __global__ void unpack_x2_kernel(const half_t* __restrict__ X, float* __restrict
   Y[i] = split_load(X, (size_t)(i / K), (int)(i % K), K);
 }
 
-template <int PASSES, int WM, int WN, int EXP>
+template <int PASSES, int WM, int WN, int EXP, int NWM = 2>
 int launch_cfg(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split,
                hipStream_t st) {
-  const int m_tiles = (int)(rows_pad / (192 * WM));
+  const int m_tiles = (int)(rows_pad / (96 * NWM * WM));
   const int tiles = m_tiles * (h->hid / (64 * WN));
-  const int slots = ehm_num_cus() * ((WM * WN == 1) ? 2 : 1);      // co-resident blocks (LDS-limited)
+  const int slots = ehm_num_cus() * ((WM * WN == 1 && NWM == 2) ? 2 : 1);      // co-resident blocks (LDS-limited)
   const int blocks = (tiles < slots || !h->persistent) ? tiles : slots;
   const LayerDev& L = h->hidden[layer];
   const half_t* x = (const half_t*)X;
   const half_t* r = (const half_t*)residual;
   float* y = (float*)out;
   if (residual) {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
   } else {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN, EXP>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -275,6 +278,9 @@ int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, voi
   }
   if (force == 2 && h->hid % 128 == 0)
     return launch_cfg<PASSES, 1, 2, 8>(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (force == 9) return launch_cfg<PASSES, 1, 1, 16>(h, layer, X, residual, out, rows_pad, out_split, st);   // s_setprio around the MFMA clusters
+  if (force == 8 && h->hid % 128 == 0 && rows_pad % 384 == 0)      // 8 waves: 384 rows x 128 channels, DMA staging
+    return launch_cfg<PASSES, 1, 2, 0, 4>(h, layer, X, residual, out, rows_pad, out_split, st);
   if (h->reg_staging) return launch_cfg<PASSES, 1, 1, 8>(h, layer, X, residual, out, rows_pad, out_split, st);
   return launch_cfg<PASSES, 1, 1, 0>(h, layer, X, residual, out, rows_pad, out_split, st);
 }

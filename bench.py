@@ -65,7 +65,7 @@ def time_dominant_kernel(model, B, passes, reps=5):
     h = model.fused_sampler.gcn()
     if model.gcn_precision != "f32":     # split-f16 modes exchange activations in the X2 format
         X2 = torch.empty_like(X)
-        _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, _lib.stream_ptr()))
+        _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), _lib.stream_ptr()))
         X = X2
     nl = 2 * model.diffusion_model.num_layers
     s = _lib.stream_ptr()

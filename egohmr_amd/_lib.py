@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_f16.hip", "linear.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_f16.hip", "gcn_f16p.hip", "gcn_f16r.hip", "linear.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -35,7 +35,8 @@ def build(verbose: bool = False, force: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS for the in-kernel time stamps (tools/stamp_hidden.py)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}", *extra,
            *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -90,8 +91,9 @@ PROTOTYPES = {
     "ehm_gcn_set_precision": (_I, [_P, _I]),
     "ehm_gcn_get_precision": (_I, [_P]),
     "ehm_gcn_set_tile_override": (_I, [_P, _I]),
-    "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _P]),
-    "ehm_gcn_unpack_activations": (_I, [_P, _P, _L, _I, _P]),
+    "ehm_gcn_activation_group": (_I, [_P]),
+    "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _I, _P]),
+    "ehm_gcn_unpack_activations": (_I, [_P, _P, _L, _I, _I, _P]),
     "ehm_gcn_input_layer": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ehm_gcn_hidden_layer": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),

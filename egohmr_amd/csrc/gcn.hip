@@ -101,10 +101,11 @@ __global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned in
 }
 
 // Wp (f32, packed tiles) -> X2 split-f16 tiles scaled by `scale`; Ds/M1s = D/scale, M1/scale
+template <int G>
 __global__ void pack_ws_kernel(const float* __restrict__ Wp, half_t* __restrict__ Ws, size_t rows, int K, float scale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * K) return;
-  split_store(Ws, i / K, (int)(i % K), K, Wp[i] * scale);
+  split_store<G>(Ws, i / K, (int)(i % K), K, Wp[i] * scale);
 }
 __global__ void scale_epilogue_kernel(const float* __restrict__ D, const float* __restrict__ M1, float* __restrict__ Ds,
                                       float* __restrict__ M1s, int n, float inv_scale) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_kernel(const float* __restr
 // input conv with the step-invariant projections hoisted (see ehm_gcn_input_layer in the header)
 // one wave = one virtual body x 64 channels; 4 waves per block = 4 channel groups
 // ------------------------------------------------------------------------------------------------
-template <bool SPLIT_OUT>
+template <bool SPLIT_OUT, int G>
 __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict__ h_img, const float* __restrict__ h_oth,
                                                         const uint8_t* __restrict__ vis, const float* __restrict__ x,
                                                         const float* __restrict__ Wx, const float* __restrict__ tvec,
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
   float zero[kJ];
 #pragma unroll
   for (int j = 0; j < kJ; ++j) zero[j] = 0.f;
-  gcn_mix_store<SPLIT_OUT>(h0, h1, zero, n, N, (size_t)vb * kJ, L.Aoff, Y, L.relu != 0);
+  gcn_mix_store<SPLIT_OUT, G>(h0, h1, zero, n, N, (size_t)vb * kJ, L.Aoff, Y, L.relu != 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,6 +380,8 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
     cursor += (size_t)2 * K * N;
     L.Ws = (half_t*)cursor;
     cursor += (size_t)2 * K * N;       // X2 format has the same byte size as float32
+    L.Ws16 = (half_t*)cursor;
+    cursor += (size_t)2 * K * N;
     L.Ds = cursor;   cursor += (size_t)kJ * N;
     L.M1s = cursor;  cursor += (size_t)kJ * N;
   }
@@ -412,7 +415,9 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
       if (e < -24) e = -24;
     }
     L.w_scale = ldexpf(1.f, e);
-    hipLaunchKernelGGL(pack_ws_kernel, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws, (size_t)2 * N, K,
+    hipLaunchKernelGGL(pack_ws_kernel<32>, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws, (size_t)2 * N, K,
+                       L.w_scale);
+    hipLaunchKernelGGL(pack_ws_kernel<16>, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws16, (size_t)2 * N, K,
                        L.w_scale);
     hipLaunchKernelGGL(scale_epilogue_kernel, dim3((unsigned)ceil_div(kJ * N, 256)), dim3(256), 0, st, L.D, L.M1, L.Ds, L.M1s, kJ * N,
                        1.f / L.w_scale);
@@ -435,10 +440,11 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   auto* g = new ehm_gcn();
   if (const char* e = getenv("EHM_F16_STAGING")) g->reg_staging = strcmp(e, "reg") == 0;
   if (const char* e = getenv("EHM_F16_PERSISTENT")) g->persistent = atoi(e) != 0;
+  if (const char* e = getenv("EHM_F16_PIPELINED")) g->pipelined = atoi(e);
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
   const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ;
-  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (4 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
+  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (6 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
                   12 * (size_t)hid_dim + kJ * 6 + kJ * kJ + 8 + 64;
   if (hipMalloc(&g->arena, floats * sizeof(float)) != hipSuccess) {
     delete g;
@@ -482,10 +488,13 @@ extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* 
   EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
   dim3 grid((unsigned)(B * passes), (unsigned)ceil_div(h->hid, 256));
   if (h->precision == EHM_PREC_F32)
-    hipLaunchKernelGGL(gcn_input_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
+    hipLaunchKernelGGL((gcn_input_kernel<false, 32>), grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
                        out, B, passes);
-  else   // split-f16 modes: the activation matrices travel in the X2 format (same byte size)
-    hipLaunchKernelGGL(gcn_input_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
+  else if (h->pipelined == 1)   // split-f16 modes: the activation matrices travel in the X2 format (same byte size)
+    hipLaunchKernelGGL((gcn_input_kernel<true, 16>), grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
+                       out, B, passes);
+  else
+    hipLaunchKernelGGL((gcn_input_kernel<true, 32>), grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
                        out, B, passes);
   EHM_LAUNCH_CHECK();
   return 0;
@@ -541,8 +550,9 @@ extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
   return 0;
 }
 extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
+extern "C" int ehm_gcn_activation_group(const ehm_gcn* h) { return h ? (h->pipelined == 1 ? 16 : 32) : EHM_EINVAL; }
 extern "C" int ehm_gcn_set_tile_override(ehm_gcn* h, int mode) {
-  EHM_CHECK_ARG(h && mode >= 0 && mode <= 9);
+  EHM_CHECK_ARG(h && mode >= 0 && mode <= 11);
   h->tile_override = mode;
   return 0;
 }

@@ -14,7 +14,8 @@ constexpr int STAGE = A_TILE + B_TILE; // 10240 floats = 40 KiB
 
 struct LayerDev {
   float* Wp;     // [N/64][128][K]   packed W0|W1 columns, K contiguous
-  half_t* Ws;    // same tiles in split-f16 format (see gcn_f16.hip), values scaled by w_scale
+  half_t* Ws;    // same tiles in split-f16 format X2<32> (see gcn_f16.hip), values scaled by w_scale
+  half_t* Ws16;  // the same in X2<16> for the pipelined kernel (gcn_f16p.hip)
   float* Ds;     // D / w_scale
   float* M1s;    // M1 / w_scale
   float w_scale; // power of two
@@ -43,6 +44,7 @@ struct ehm_gcn {
   int precision = EHM_PREC_F32;
   int reg_staging = 0;     // split-f16 convs: 1 = global_load -> VGPR -> ds_write staging, 0 = global_load_lds DMA
   int persistent = 0;      // split-f16 convs: 1 = grid capped at the co-resident slots, blocks loop over tiles
+  int pipelined = 2;       // split-f16 convs: 2 = register double-buffered fragments + LDS-transposed epilogue (gcn_f16r.hip, default); 0 = 2-stage BK=32 kernel, hipcc-scheduled (gcn_f16.hip); 1 = 4-stage BK=16 (gcn_f16p.hip, X2<16>)
   int tile_override = 0;   // split-f16 convs: 0 = pick by size, 1 = 192x64 tiles, 2 = 384x128 tiles
   LayerDev input{};
   LayerDev hidden[16]{};
@@ -52,43 +54,69 @@ struct ehm_gcn {
   int64_t hs_rows = 0;
 };
 
-// Split-f16 activation / weight format ("X2"): row-major rows of K values, each group of 32 consecutive k stored as
-// 32 f16 "hi" followed by 32 f16 "lo" (128 bytes, value = hi + lo, hi = rn_f16(x), lo = rn_f16(x - hi)).
-// Same bytes per row as float32, and every 32-k tile of a row is one 128-byte line.
+// Split-f16 activation / weight format ("X2<G>"): row-major rows of K values, every group of G consecutive k stored as
+// G f16 "hi" followed by G f16 "lo" (value = hi + lo, hi = rn_f16(x), lo = rn_f16(x - hi)).  Same bytes per row as
+// float32.  G = 32 (one 128-byte line per 32-k tile) for the 32-wide-K kernels, G = 16 (64 bytes per 16-k tile) for the
+// 4-stage pipelined GCN kernel.
+template <int G = 32>
+static __device__ __forceinline__ size_t split_off(size_t row, int n, int N) {
+  return row * (size_t)N * 2 + (size_t)(n / G) * (2 * G) + (n % G);
+}
+template <int G = 32>
 static __device__ __forceinline__ void split_store(half_t* base, size_t row, int n, int N, float v) {
   const float c = fminf(fmaxf(v, -65504.f), 65504.f);
   const half_t hi = (half_t)c;
   const half_t lo = (half_t)(v - (float)hi);
-  half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 31);
+  half_t* p = base + split_off<G>(row, n, N);
   p[0] = hi;
-  p[32] = lo;
+  p[G] = lo;
 }
+template <int G = 32>
 static __device__ __forceinline__ float split_load(const half_t* base, size_t row, int n, int N) {
-  const half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 31);
-  return (float)p[0] + (float)p[32];
+  const half_t* p = base + split_off<G>(row, n, N);
+  return (float)p[0] + (float)p[G];
 }
 
 // Lane-pair versions for epilogues in which adjacent lanes own adjacent columns (lane parity == parity of n): the even
 // lane moves the dword {hi[n], hi[n+1]}, the odd lane the dword {lo[n-1], lo[n]}, halves are exchanged with one
-// cross-lane move.  One 4-byte access per lane and row instead of two 2-byte ones (the store tail is issue-bound).
+// DPP move.  One 4-byte access per lane and row instead of two 2-byte ones (the store tail is issue-bound).
 static __device__ __forceinline__ unsigned int split_pack_bits(float v) {
   const float c = fminf(fmaxf(v, -65504.f), 65504.f);
   const half_t hi = (half_t)c;
   const half_t lo = (half_t)(v - (float)hi);
   return (unsigned int)__builtin_bit_cast(unsigned short, hi) | ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
 }
+static __device__ __forceinline__ unsigned int split_pair_word(float v, bool odd) {   // the dword split_store_pair writes
+  const unsigned int own = split_pack_bits(v);
+  const unsigned int nbr = dpp_xor1_u32(own);
+  return odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
+}
+template <int G = 32>
 static __device__ __forceinline__ void split_store_pair(half_t* base, size_t row, int n, int N, float v) {
   const unsigned int own = split_pack_bits(v);                       // {hi, lo} of my column
   const unsigned int nbr = dpp_xor1_u32(own);                         // {hi, lo} of the neighbouring column
   const bool odd = n & 1;
   // even lane: hi[n] | hi[n+1] << 16  at &hi[n];   odd lane: lo[n-1] | lo[n] << 16  at &lo[n-1]
   const unsigned int word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
-  half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 30) + (odd ? 32 : 0);
+  half_t* p = base + split_off<G>(row, n & ~1, N) + (odd ? G : 0);
   *(unsigned int*)p = word;
 }
+template <int G = 32>
+static __device__ __forceinline__ unsigned int split_load_pair_raw(const half_t* base, size_t row, int n, int N) {
+  const half_t* p = base + split_off<G>(row, n & ~1, N) + ((n & 1) ? G : 0);
+  return *(const unsigned int*)p;                                    // even: {hi[n], hi[n+1]}   odd: {lo[n-1], lo[n]}
+}
+static __device__ __forceinline__ float split_pair_decode(unsigned int own, int n) {
+  const bool odd = n & 1;
+  const unsigned int nbr = dpp_xor1_u32(own);
+  const unsigned short hb = odd ? (unsigned short)(nbr >> 16) : (unsigned short)(own & 0xffffu);
+  const unsigned short lb = odd ? (unsigned short)(own >> 16) : (unsigned short)(nbr & 0xffffu);
+  return (float)__builtin_bit_cast(half_t, hb) + (float)__builtin_bit_cast(half_t, lb);
+}
+template <int G = 32>
 static __device__ __forceinline__ float split_load_pair(const half_t* base, size_t row, int n, int N) {
   const bool odd = n & 1;
-  const half_t* p = base + row * (size_t)N * 2 + (size_t)(n >> 5) * 64 + (n & 30) + (odd ? 32 : 0);
+  const half_t* p = base + split_off<G>(row, n & ~1, N) + (odd ? G : 0);
   const unsigned int own = *(const unsigned int*)p;                  // even: {hi[n], hi[n+1]}   odd: {lo[n-1], lo[n]}
   const unsigned int nbr = dpp_xor1_u32(own);
   const unsigned short hb = odd ? (unsigned short)(nbr >> 16) : (unsigned short)(own & 0xffffu);
@@ -98,17 +126,53 @@ static __device__ __forceinline__ float split_load_pair(const half_t* base, size
 
 // d0[j] = D[j][n]*h0[j] + shift[n] (diagonal branch, bias and BatchNorm folded), g1[j] = M1[j][n]*h1[j];
 // res[j] = residual input (already loaded, zeros when unused).
-template <bool SPLIT_OUT>
+template <bool SPLIT_OUT, int G = 32>
 static __device__ __forceinline__ void gcn_mix_store(const float (&d0)[kJ], const float (&g1)[kJ], const float (&res)[kJ], int n, int N,
                                               size_t row0, const float* __restrict__ Aoff, float* __restrict__ Y, bool relu) {
+  // Aoff is wave-uniform and read-only, but hipcc cannot prove either through the by-value LayerDev and emitted 288
+  // global_load_dwordx4 per wave for it; the constant address space makes them s_load (SGPR operands of the v_fmac).
+  typedef const float __attribute__((address_space(4))) cfloat;
+  const cfloat* Ac = (const cfloat*)(uintptr_t)Aoff;
 #pragma unroll
   for (int j = 0; j < kJ; ++j) {
     float s = d0[j];
 #pragma unroll
-    for (int jp = 0; jp < kJ; ++jp) s = fmaf(Aoff[j * kJ + jp], g1[jp], s);  // Aoff: wave-uniform -> scalar loads
+    for (int jp = 0; jp < kJ; ++jp) s = fmaf(Ac[j * kJ + jp], g1[jp], s);
     if (relu) s = fmaxf(s, 0.f);
-    if (SPLIT_OUT) split_store_pair((half_t*)Y, row0 + j, n, N, s + res[j]);
+    if (SPLIT_OUT) split_store_pair<G>((half_t*)Y, row0 + j, n, N, s + res[j]);
     else Y[(row0 + j) * (size_t)N + n] = s + res[j];
+  }
+}
+
+// Two 24-joint bodies per lane at once (rows rowa.. and rowb..): joint j outermost, so one s_load of Aoff row j (24 SGPRs) feeds
+// both bodies through v_pk_fma_f32 and only a few rows of coefficients are live (with one body per call hipcc kept all 576
+// coefficients of the first call alive for the second and spilled SGPRs into VGPR lanes).  The residual is fetched four joints
+// at a time right before the fmas that hide its latency.  Same fma order per output as gcn_mix_store.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// dp[j] / gp[j] = {body a, body b} values of joint j (diagonal branch incl. shift / off-diagonal branch): one v_pk_fma_f32 per
+// coefficient.  Kernels whose accumulator layout already holds the two bodies in adjacent registers pass sub-vectors of the
+// accumulators and pay no register moves (gcn_f16r.hip).
+template <class Store>
+static __device__ __forceinline__ void gcn_mix2(const f32x2 (&dp)[kJ], const f32x2 (&gp)[kJ], const float* __restrict__ Aoff, bool relu,
+                                                Store store) {
+  typedef const float __attribute__((address_space(4))) cfloat;
+  const cfloat* Ac = (const cfloat*)(uintptr_t)Aoff;
+#pragma unroll
+  for (int j0 = 0; j0 < kJ; j0 += 4) {
+    __builtin_amdgcn_sched_barrier(0);           // bounds the number of coefficient rows hipcc keeps in SGPRs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i;
+      float s0 = dp[j][0], s1 = dp[j][1];
+#pragma unroll
+      for (int jp = 0; jp < kJ; ++jp) {
+        const float a = Ac[j * kJ + jp];
+        s0 = fmaf(a, gp[jp][0], s0);
+        s1 = fmaf(a, gp[jp][1], s1);
+      }
+      if (relu) { s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f); }
+      store(j, s0, s1);                           // (joint, body a value, body b value) before the residual
+    }
   }
 }
 

@@ -26,24 +26,24 @@ namespace {
 //   <1,1>: 192 x 64,  80 KiB LDS, 2 blocks/CU (2 waves/SIMD)          - small launches
 //   <1,2>: 192 x 128, 112 KiB LDS, 1 block/CU (1 wave/SIMD)          - 30 % less L2->LDS traffic, measured slower (see launch())
 //   <2,2>: 384 x 128 would halve the traffic but hipcc spills its 384 accumulator registers inside the K loop.
-template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN, int EXP = 8, int NWM = 2>
-__global__ __launch_bounds__(128 * NWM, (NWM == 4 || WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_kernel(const half_t* __restrict__ X, LayerDev L,
+template <int PASSES, bool RES, bool OUT_SPLIT, int WM, int WN, int EXP = 8, int NWM = 2, int NWN = 2>
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 8 || WM * WN == 1) ? 2 : 1) void gcn_hidden_f16_kernel(const half_t* __restrict__ X, LayerDev L,
                                                                                      const half_t* __restrict__ Res,
                                                                                      float* __restrict__ Y, int m_tiles) {
-  constexpr int NW = 2 * NWM;                // waves per block: NWM along rows x 2 along channels
+  constexpr int NW = NWN * NWM;              // waves per block: NWM along rows x NWN along channels
   constexpr int BM_ = 96 * NWM * WM;         // rows per block
-  constexpr int BR_ = 128 * WN;              // weight rows per block (2 branches x 64*WN channels) = WN consecutive packed tiles
+  constexpr int BR_ = 64 * WN * NWN;         // weight rows per block (2 branches x 32*WN*NWN channels) = consecutive packed 64-channel tiles
   constexpr int A_T = BM_ * BK, B_T = BR_ * BK, STG = A_T + B_T;   // floats
   constexpr int NLA = BM_ / (8 * NW), NLB = BR_ / (8 * NW);       // staging wave-instructions (8 rows each) per wave
   __shared__ __attribute__((aligned(16))) float lds[2 * STG];
 
   const int K = L.K, N = L.N;
-  const int n_tiles = N / (64 * WN);
+  const int n_tiles = N / (32 * WN * NWN);
   const int total = m_tiles * n_tiles;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   // Persistent blocks: the grid is capped at what is co-resident (2 blocks per CU) and every block walks tiles
   // bid, bid + grid, ... .  With 1024 tiles on 512 slots each block does exactly two: no CU ends up with 3 or 5 of the
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 4 || WM * WN == 1) ? 2 : 1) void
   //      the accumulators + one 24-wide batch of loads are live (the staging registers of the K loop are dead here) ----
 #pragma unroll
   for (int c = 0; c < WN; ++c) {
-    const int n = 64 * WN * n_tile + 32 * (WN * wn + c) + mi;
+    const int n = 32 * WN * NWN * n_tile + 32 * (WN * wn + c) + mi;
     {
       float dj[kJ], mj[kJ];
       const float sh = L.shift[n];
@@ -224,34 +224,36 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 4 || WM * WN == 1) ? 2 : 1) void
 }
 
 // float32 [rows][K] <-> X2 split format (tests / interop; the sampler never needs them)
+template <int G>
 __global__ void pack_x2_kernel(const float* __restrict__ X, half_t* __restrict__ Y, int64_t rows, int K) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * K) return;
-  split_store(Y, (size_t)(i / K), (int)(i % K), K, X[i]);
+  split_store<G>(Y, (size_t)(i / K), (int)(i % K), K, X[i]);
 }
+template <int G>
 __global__ void unpack_x2_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int64_t rows, int K) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * K) return;
-  Y[i] = split_load(X, (size_t)(i / K), (int)(i % K), K);
+  Y[i] = split_load<G>(X, (size_t)(i / K), (int)(i % K), K);
 }
 
-template <int PASSES, int WM, int WN, int EXP, int NWM = 2>
+template <int PASSES, int WM, int WN, int EXP, int NWM = 2, int NWN = 2>
 int launch_cfg(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split,
                hipStream_t st) {
   const int m_tiles = (int)(rows_pad / (96 * NWM * WM));
-  const int tiles = m_tiles * (h->hid / (64 * WN));
-  const int slots = ehm_num_cus() * ((WM * WN == 1 && NWM == 2) ? 2 : 1);      // co-resident blocks (LDS-limited)
+  const int tiles = m_tiles * (h->hid / (32 * WN * NWN));
+  const int slots = ehm_num_cus() * ((WM * WN == 1 && NWM * NWN == 4) ? 2 : 1);      // co-resident blocks (LDS-limited)
   const int blocks = (tiles < slots || !h->persistent) ? tiles : slots;
   const LayerDev& L = h->hidden[layer];
   const half_t* x = (const half_t*)X;
   const half_t* r = (const half_t*)residual;
   float* y = (float*)out;
   if (residual) {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, true, WM, WN, EXP, NWM, NWN>), dim3(blocks), dim3(64 * NWM * NWN), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, true, false, WM, WN, EXP, NWM, NWN>), dim3(blocks), dim3(64 * NWM * NWN), 0, st, x, L, r, y, m_tiles);
   } else {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN, EXP, NWM>), dim3(blocks), dim3(128 * NWM), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, true, WM, WN, EXP, NWM, NWN>), dim3(blocks), dim3(64 * NWM * NWN), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16_kernel<PASSES, false, false, WM, WN, EXP, NWM, NWN>), dim3(blocks), dim3(64 * NWM * NWN), 0, st, x, L, r, y, m_tiles);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -278,6 +280,10 @@ int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, voi
   }
   if (force == 2 && h->hid % 128 == 0)
     return launch_cfg<PASSES, 1, 2, 8>(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (force == 10 && h->hid % 128 == 0)    // 8 waves as 2 x 4: 192 rows x 128 channels, 96x32 per wave, 1 block/CU
+    return launch_cfg<PASSES, 1, 1, 0, 2, 4>(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (force == 11 && rows_pad % 384 == 0)   // 8 waves as 4 x 2: 384 rows x 64 channels
+    return launch_cfg<PASSES, 1, 1, 0, 4, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
   if (force == 9) return launch_cfg<PASSES, 1, 1, 16>(h, layer, X, residual, out, rows_pad, out_split, st);   // s_setprio around the MFMA clusters
   if (force == 8 && h->hid % 128 == 0 && rows_pad % 384 == 0)      // 8 waves: 384 rows x 128 channels, DMA staging
     return launch_cfg<PASSES, 1, 2, 0, 4>(h, layer, X, residual, out, rows_pad, out_split, st);
@@ -289,20 +295,26 @@ int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, voi
 
 int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
                             bool out_split, hipStream_t st) {
+  if (h->pipelined == 1) return ehm_gcn_hidden_f16p_impl(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (h->pipelined == 2 && h->tile_override == 0) return ehm_gcn_hidden_f16r_impl(h, layer, X, residual, out, rows_pad, out_split, st);
   if (h->precision == EHM_PREC_F16X3) return launch<3>(h, layer, X, residual, out, rows_pad, out_split, st);
   return launch<1>(h, layer, X, residual, out, rows_pad, out_split, st);
 }
 
-extern "C" int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, void* stream) {
-  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0);
-  hipLaunchKernelGGL(pack_x2_kernel, dim3((unsigned)ceil_div(rows * K, 256)), dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K);
+extern "C" int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, int group, void* stream) {
+  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0 && (group == 16 || group == 32));
+  const dim3 grid((unsigned)ceil_div(rows * K, 256));
+  if (group == 16) hipLaunchKernelGGL(pack_x2_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K);
+  else hipLaunchKernelGGL(pack_x2_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K);
   EHM_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, void* stream) {
-  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0);
-  hipLaunchKernelGGL(unpack_x2_kernel, dim3((unsigned)ceil_div(rows * K, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X2, X, rows, K);
+extern "C" int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, int group, void* stream) {
+  EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0 && (group == 16 || group == 32));
+  const dim3 grid((unsigned)ceil_div(rows * K, 256));
+  if (group == 16) hipLaunchKernelGGL(unpack_x2_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)X2, X, rows, K);
+  else hipLaunchKernelGGL(unpack_x2_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)X2, X, rows, K);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,344 @@
+// Split-f16 Modulated-GCN hidden conv with register double-buffered MFMA fragments (EHM_F16_PIPELINED=2).
+//
+// Same maths, tile (192 rows x 64 channels x 2 branches, 4 waves, 2 blocks/CU), X2<32> operands, LDS image / swizzle and
+// in-register epilogue as gcn_f16.hip.  What changes is the schedule of the K loop.  hipcc's schedule of that kernel keeps the
+// fragment registers minimal: it issues 2-4 ds_read_b128, waits lgkmcnt(0), issues 2-12 MFMAs, and repeats - six exposed LDS
+// round trips per K tile, and the ten global_load_lds of the next tile in one burst right behind the barrier.  Here the loop
+// is written in half-tile phases with TWO fragment sets:
+//   phase A(k): MFMAs of (tile k, k-step 0) from set 0  |  ds_reads of (tile k, k-step 1) into set 1
+//   -- s_waitcnt vmcnt(0) lgkmcnt(0) + barrier: every wave has all of tile k in registers, tile k+1 is complete in LDS --
+//   phase B(k): MFMAs of (tile k, k-step 1) from set 1  |  ds_reads of (tile k+1, k-step 0) into set 0  |  DMA of tile k+2
+// so every LDS read has half a tile (576 MFMA cycles) to land, every DMA a whole tile, and the only exposed wait is the one
+// barrier per tile.  __builtin_amdgcn_sched_group_barrier pins the interleaving (1 MFMA : 1-2 reads : 1 DMA).
+#include "common.h"
+#include "egohmr_hip.h"
+#include "gcn_dev.h"
+#include "internal.h"
+
+namespace {
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+constexpr int RK = 32;                                        // K per tile
+constexpr int RA_T = 192 * RK, RB_T = 128 * RK, RSTG = RA_T + RB_T;   // floats per stage: 10240 = 40 KiB
+
+// Build with EHM_HIPCC_FLAGS=-DEHM_STAMPS to record per-block phase time stamps (tools/stamp_hidden.py): slot i of block b at
+// g_dbg[16 b + i]; STAMP = s_memrealtime (100 MHz), STAMPC = s_memtime (shader clock).
+#ifdef EHM_STAMPS
+__device__ unsigned long long* g_dbg = nullptr;
+#define STAMP(i) do { if (g_dbg && threadIdx.x == 0) g_dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMPC(i) do { if (g_dbg && threadIdx.x == 0) g_dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#define STAMPC(i) do { } while (0)
+#endif
+
+template <int PASSES>
+struct Frags {
+  half8 ah[3], al[3], bh[2], bl[2];
+};
+
+template <int PASSES, bool RES, bool OUT_SPLIT>
+__global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* __restrict__ X, LayerDev L,
+                                                                  const half_t* __restrict__ Res, float* __restrict__ Y,
+                                                                  int m_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * RSTG];   // 80 KiB, the only LDS object
+
+  STAMP(0); STAMPC(4);
+  const int K = L.K, N = L.N;
+  const int n_tiles = N / 64;
+  const int total = m_tiles * n_tiles;
+  const int bid = blockIdx.x;
+  const int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;   // XCD-aware tile order
+  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
+  const size_t m0 = (size_t)m_tile * 192;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- DMA: one wave instruction = 8 rows x 128 B; physical 16-byte chunk c of row r holds logical chunk c ^ ((r>>1)&7)
+  const int ld_r = lane >> 3, ld_c = lane & 7;
+  const int r0 = 8 * wave + ld_r;
+  const int swz = (ld_c ^ ((r0 >> 1) & 7)) << 2;             // r0 + 32 i keeps the key
+  const float* pA = (const float*)X + (m0 + r0) * K + swz;
+  const float* pB = (const float*)L.Ws + ((size_t)n_tile * 128 + r0) * K + swz;
+  const size_t row32 = (size_t)32 * K;
+  auto dma_a = [&](int buf, int kt, int i) {
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+  auto dma_b = [&](int buf, int kt, int i) {
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + RA_T + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
+  };
+
+  // ---- fragments (v_mfma_f32_32x32x16_f16: lane l holds row l&31, k = 8*(l>>5) .. +7 of a 16-wide step)
+  const int mi = lane & 31, g = lane >> 5;
+  // Row permutation of the in-register epilogue: MFMA row i of tile t <-> tile row 48*((i>>2)&1) + 24*(i&1) + ((i>>1)&1) + 2*(i>>3) + 8t
+  // of the wave's 96 rows.  With the C layout (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) lane (mi, g) then owns, for ONE channel, all
+  // 24 joints of bodies 2g and 2g+1, and joint j of the two bodies sits in the ADJACENT registers 2*(j&7), 2*(j&7)+1 of accumulator j>>3:
+  // the 24x24 adjacency mix runs as v_pk_fma_f32 on register pairs without a single move.
+  const int rA = 96 * wm + 48 * ((mi >> 2) & 1) + 24 * (mi & 1) + ((mi >> 1) & 1) + 2 * (mi >> 3);
+  const int rB = 32 * wn + mi;
+  // swizzle key (row>>1)&7: +8t flips bit 2 for t = 1 (12*(mi&1) + (mi>>3) + 4t), +64u leaves it.  Conflict-free for ds_read_b128's
+  // lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: their 16 rows carry every key twice, once on an even and once on an odd row.
+  const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
+  // float offsets inside a stage: [k-step][hi/lo][t odd] for A, [k-step][hi/lo] for B; logical chunk 2s+g (hi), 4+2s+g (lo)
+  int oA[2][2][2], oB[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+      const int c = 4 * hl + 2 * s + g;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) oA[s][hl][o] = rA * RK + (((c ^ keyA) ^ (4 * o)) << 2);
+      oB[s][hl] = RA_T + rB * RK + ((c ^ keyB) << 2);
+    }
+  auto read_frags = [&](Frags<PASSES>& f, int buf, int s) {
+    const float* S = lds + buf * RSTG;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      f.ah[t] = *(const half8*)(S + oA[s][0][t & 1] + 8 * t * RK);
+      if (PASSES == 3) f.al[t] = *(const half8*)(S + oA[s][1][t & 1] + 8 * t * RK);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f.bh[u] = *(const half8*)(S + oB[s][0] + 64 * u * RK);
+      if (PASSES == 3) f.bl[u] = *(const half8*)(S + oB[s][1] + 64 * u * RK);
+    }
+  };
+
+  f32x16 acc0[3], acc1[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[t][r] = 0.f; acc1[t][r] = 0.f; }
+
+  auto mfmas = [&](const Frags<PASSES>& f) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (PASSES == 3) {                                // small cross terms first, leading term last
+        acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[0], acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[1], acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[0], acc0[t], 0, 0, 0);
+        acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[1], acc1[t], 0, 0, 0);
+      }
+      acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[0], acc0[t], 0, 0, 0);
+      acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[1], acc1[t], 0, 0, 0);
+    }
+  };
+  constexpr int NM = PASSES == 3 ? 18 : 6;     // MFMAs per phase
+  constexpr int NR = PASSES == 3 ? 10 : 5;     // ds_read_b128 per phase
+  // sched_group_barrier masks: 0x008 MFMA, 0x100 DS read, 0x010 VMEM
+  auto pin_reads = [&]() {                      // MFMA, read, MFMA, read, ... then the remaining MFMAs
+#pragma unroll
+    for (int i = 0; i < (NR < NM ? NR : NM); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+  };
+  auto pin_reads_dma = [&]() {                  // first the reads (one per MFMA), then the ten DMAs spread over the remaining MFMAs
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (PASSES == 3) {                // 8 MFMAs left: 2,2,1,1,1,1,1,1 DMAs behind them
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 10, 0);
+    }
+  };
+
+  const int KT = K / RK;
+  Frags<PASSES> f0, f1;
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // tile 0 landed (tile 1 may still fly)
+  __syncthreads();
+  read_frags(f0, 0, 0);
+  STAMP(1); STAMPC(5);
+
+  for (int kt = 0; kt < KT - 2; ++kt) {
+    const int buf = kt & 1;
+    // phase A
+    read_frags(f1, buf, 1);
+    mfmas(f0);
+    pin_reads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // tile kt is in everyone's registers; tile kt+1 is complete in LDS
+    // phase B
+    read_frags(f0, buf ^ 1, 0);                        // before the DMA in program order: hipcc cannot tell the two stages apart
+    stage(buf, kt + 2);
+    mfmas(f1);
+    pin_reads_dma();
+  }
+  // ---- the last two tiles: nothing left to fetch; the per-channel epilogue constants are fetched under their MFMAs
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int n = 64 * n_tile + 32 * wn + mi;
+  const unsigned int rowbytes = (unsigned int)N * 4u;               // X2 rows and float rows have the same size
+  const __amdgpu_buffer_rsrc_t resB = ehm_buffer_rsrc((const char*)Res + m0 * rowbytes);
+  const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc((const char*)Y + m0 * rowbytes);
+  const __amdgpu_buffer_rsrc_t dsB = ehm_buffer_rsrc(L.Ds);
+  const __amdgpu_buffer_rsrc_t m1B = ehm_buffer_rsrc(L.M1s);
+  float dj[kJ], mj[kJ], sh;
+  const unsigned int n4 = (unsigned int)n * 4u;
+  {
+    const int buf = (KT - 2) & 1;
+    read_frags(f1, buf, 1);
+    mfmas(f0);
+    pin_reads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_frags(f0, buf ^ 1, 0);
+    mfmas(f1);
+    pin_reads();
+    read_frags(f1, buf ^ 1, 1);
+    mfmas(f0);
+    pin_reads();
+    __builtin_amdgcn_sched_barrier(0);
+    sh = L.shift[n];                                   // fragment set 0 is dead: room for the two tables
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+      dj[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsB, n4, j * rowbytes, 0));
+      mj[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(m1B, n4, j * rowbytes, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f1);
+  }
+
+  STAMP(2); STAMPC(6);
+  // ---- epilogue (Ds/M1s carry 1/w_scale), in two parts around an LDS transposition:
+  //   P1  per lane (one channel, 24 joints of two bodies in adjacent registers): modulation / BatchNorm fold, 24x24 adjacency mix with the coefficients in SGPRs
+  //       (plain v_fmac: v_pk_fma_f32 measured 45 % slower here), ReLU, ds_write_b32 into a float [192][64] tile;
+  //   P2  per thread 6 x (one row, 8 consecutive channels): residual add, hi/lo split, 16-byte stores.
+  // Measured with s_memrealtime stamps: the one-dword-per-lane epilogue (96 loads + 96 stores of 4 B per lane) took 25k cycles of a
+  // 110k-cycle block; 16-byte accesses cut its memory instruction count 8x.  The residual is fetched under the mix.
+  // Addresses = block-uniform buffer descriptor + 32-bit lane offset: a 192-row tile spans < 2 GiB.
+  // P2 work item: rows urow + 32 i (i < 6), channels 64*n_tile + 8*uc .. +7
+  const int urow = tid >> 3, uc = tid & 7;
+  const unsigned int ucolx = (unsigned int)(2 * n_tile + (uc >> 2)) * 128u + (unsigned int)(uc & 3) * 16u;   // X2: 8 hi halves here, 8 lo halves 64 B on
+  const unsigned int ucolf = (unsigned int)(64 * n_tile + 8 * uc) * 4u;
+  f32x2 dp[kJ], gp[kJ];
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) {   // fold modulation / BatchNorm scale
+    const f32x2 a0 = f32x2{acc0[j >> 3][2 * (j & 7)], acc0[j >> 3][2 * (j & 7) + 1]};
+    const f32x2 a1 = f32x2{acc1[j >> 3][2 * (j & 7)], acc1[j >> 3][2 * (j & 7) + 1]};
+    dp[j] = __builtin_elementwise_fma(f32x2{dj[j], dj[j]}, a0, f32x2{sh, sh});
+    gp[j] = a1 * f32x2{mj[j], mj[j]};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 rh[6], rl[6];
+  if (RES) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      rh[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx, 0, 0);
+      rl[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx + 64u, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // transposition tile: element (row, ch) at float row*64 + (((ch>>2) ^ ((row>>1)&1)) << 2) + (ch&3).  The XOR keeps the
+  // ds_read_b128 of P2 conflict-free (lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} cover 4 rows x 4 of the 8 chunks).
+  STAMP(8);
+  __syncthreads();                                                   // every wave is done reading operand fragments
+  STAMP(9);
+  float* T = lds;
+  {
+    const int ch = 32 * wn + mi;
+    const int lrow = 96 * wm + 48 * g;                               // body a = rows lrow.., body b = lrow + 24..; (row>>1)&1 == (j>>1)&1
+    float* t0 = T + lrow * 64 + (((ch >> 2) ^ 0) << 2) + (ch & 3);
+    float* t1 = T + lrow * 64 + (((ch >> 2) ^ 1) << 2) + (ch & 3);
+    gcn_mix2(dp, gp, L.Aoff, L.relu != 0, [&](int j, float s0, float s1) {
+      float* t = ((j >> 1) & 1) ? t1 : t0;
+      t[j * 64] = s0;
+      t[(24 + j) * 64] = s1;
+    });
+  }
+  STAMP(10);
+  __syncthreads();
+  STAMP(11);
+  {
+    const int p = (urow >> 1) & 1;
+    const float* src = T + urow * 64;
+    const int o0 = ((2 * uc) ^ p) << 2, o1 = ((2 * uc + 1) ^ p) << 2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f32x4 v0 = *(const f32x4*)(src + 32 * i * 64 + o0);
+      const f32x4 v1 = *(const f32x4*)(src + 32 * i * 64 + o1);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (RES) {
+        const half8 h = __builtin_bit_cast(half8, rh[i]), l = __builtin_bit_cast(half8, rl[i]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)h[k] + (float)l[k];
+      }
+      const unsigned int rowoff = (unsigned int)(urow + 32 * i) * rowbytes;
+      if (OUT_SPLIT) {
+        half8 h, l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
+          h[k] = (half_t)c;
+          l[k] = (half_t)(v[k] - (float)h[k]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), yB, rowoff + ucolx, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l), yB, rowoff + ucolx + 64u, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), yB, rowoff + ucolf, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), yB, rowoff + ucolf + 16u, 0, 0);
+      }
+    }
+  }
+  STAMP(3); STAMPC(7);
+}
+
+template <int PASSES>
+int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split, hipStream_t st) {
+  const int m_tiles = (int)(rows_pad / 192);
+  const int blocks = m_tiles * (h->hid / 64);
+  const LayerDev& L = h->hidden[layer];
+  const half_t* x = (const half_t*)X;
+  const half_t* r = (const half_t*)residual;
+  float* y = (float*)out;
+  if (residual) {
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, true, true>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, true, false>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+  } else {
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, false, true>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, false, false>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+  }
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+#ifdef EHM_STAMPS
+extern "C" int ehm_dbg_set(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &q, sizeof(q)); }
+#endif
+
+int ehm_gcn_hidden_f16r_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
+                             bool out_split, hipStream_t st) {
+  if (h->hid % 64 != 0 || h->hidden[layer].K % RK != 0 || h->hidden[layer].K / RK < 2) {
+    ehm_set_error("register-pipelined split-f16 conv needs hid %% 64 == 0 and K >= 64");
+    return EHM_EINVAL;
+  }
+  if (h->precision == EHM_PREC_F16X3) return launch<3>(h, layer, X, residual, out, rows_pad, out_split, st);
+  return launch<1>(h, layer, X, residual, out, rows_pad, out_split, st);
+}

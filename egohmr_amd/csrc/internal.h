@@ -20,6 +20,11 @@ int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 // gcn_f16.hip
 int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
                             bool out_split, hipStream_t st);
+// gcn_f16p.hip
+int ehm_gcn_hidden_f16r_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
+                             bool out_split, hipStream_t st);
+int ehm_gcn_hidden_f16p_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
+                             bool out_split, hipStream_t st);
 // guidance.hip
 int64_t ehm_guidance_scratch_bytes(int B, int N);
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,

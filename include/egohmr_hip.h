@@ -109,8 +109,10 @@ int ehm_gcn_set_precision(ehm_gcn* h, int mode);
 int ehm_gcn_get_precision(const ehm_gcn* h);
 /* tuning knob of the split-f16 convs: 0 = tile picked by problem size (default), 1 = 192x64 tiles, 2 = 384x128 tiles */
 int ehm_gcn_set_tile_override(ehm_gcn* h, int mode);
-int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, void* stream);
-int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, void* stream);
+/* group = ehm_gcn_activation_group(h): k-group size of the handle's X2 layout (16 for the pipelined kernel, 32 otherwise) */
+int ehm_gcn_activation_group(const ehm_gcn* h);
+int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, int group, void* stream);
+int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, int group, void* stream);
 
 /* rows of the activation matrices must be padded to a multiple of this many rows (zero-filled) */
 int ehm_gcn_row_tile(void);

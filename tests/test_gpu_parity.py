@@ -166,14 +166,14 @@ def test_gcn_hidden_layer_vs_oracle(L, dev, hid, bodies, prec):
     X[:rows] = x.reshape(rows, hid).to(dev)
     Y1, Y2, T = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
     if prec != "f32":       # activations travel in the X2 split format between convs
-        _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), T.data_ptr(), rows_pad, hid, None))
+        _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), T.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))
         X, T = T, X
     _lib.check(L.ehm_gcn_hidden_layer(h, 0, X.data_ptr(), None, Y1.data_ptr(), rows_pad, None))
     _lib.check(L.ehm_gcn_hidden_layer(h, 1, Y1.data_ptr(), X.data_ptr(), Y2.data_ptr(), rows_pad, None))
     if prec != "f32":
-        _lib.check(L.ehm_gcn_unpack_activations(Y1.data_ptr(), T.data_ptr(), rows_pad, hid, None))
+        _lib.check(L.ehm_gcn_unpack_activations(Y1.data_ptr(), T.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))
         Y1 = T.clone()
-        _lib.check(L.ehm_gcn_unpack_activations(Y2.data_ptr(), T.data_ptr(), rows_pad, hid, None))
+        _lib.check(L.ehm_gcn_unpack_activations(Y2.data_ptr(), T.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))
         Y2 = T.clone()
     torch.cuda.synchronize()
     adj = om.smpl_adjacency()

@@ -25,7 +25,7 @@ rows_pad = (2 * B * 24 + tile - 1) // tile * tile
 X = torch.randn(rows_pad, hid, device=dev)
 X2, Y1, Y2 = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
 if prec != "f32":
-    _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, None))
+    _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))
     X = X2
 for _ in range(2):
     _lib.check(L.ehm_gcn_hidden_layer(h, 0, X.data_ptr(), None, Y1.data_ptr(), rows_pad, None))

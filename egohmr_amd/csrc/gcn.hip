@@ -441,6 +441,7 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   if (const char* e = getenv("EHM_F16_STAGING")) g->reg_staging = strcmp(e, "reg") == 0;
   if (const char* e = getenv("EHM_F16_PERSISTENT")) g->persistent = atoi(e) != 0;
   if (const char* e = getenv("EHM_F16_PIPELINED")) g->pipelined = atoi(e);
+  if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
   const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ;
@@ -464,8 +465,14 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
                        g->out.Wt, g->out.M, g->out.A, g->out.bias);
     if (hipGetLastError() != hipSuccess) rc = EHM_EIO;
   }
+  if (rc == 0 && num_hidden > 0) {
+    if (hipMalloc(&g->hidden_dev, sizeof(LayerDev) * num_hidden) != hipSuccess ||
+        hipMemcpyAsync(g->hidden_dev, g->hidden, sizeof(LayerDev) * num_hidden, hipMemcpyHostToDevice, st) != hipSuccess)
+      rc = EHM_ENOMEM;
+  }
   if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
   if (rc != 0) {
+    if (g->hidden_dev) (void)hipFree(g->hidden_dev);
     (void)hipFree(g->arena);
     delete g;
     ehm_set_error("ehm_gcn_create: packing kernels failed");
@@ -479,6 +486,8 @@ extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
   if (!h) return;
   (void)hipFree(h->arena);
   if (h->hs) (void)hipFree(h->hs);
+  if (h->hidden_dev) (void)hipFree(h->hidden_dev);
+  if (h->chain_sync) (void)hipFree(h->chain_sync);
   delete h;
 }
 
@@ -517,6 +526,37 @@ extern "C" int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const
     hipLaunchKernelGGL(gcn_hidden_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, h->hidden[layer],
                        (const float*)nullptr, out, m_tiles);
   EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t rows_pad, int* result_index, void* stream) {
+  EHM_CHECK_ARG(h && bufs && bufs[0] && bufs[1] && bufs[2] && result_index && rows_pad > 0 && rows_pad % BM == 0);
+  EHM_CHECK_ARG(h->num_hidden % 2 == 0);
+  const int nblk = h->num_hidden / 2;
+  *result_index = (nblk & 1) ? 2 : 0;
+  if (nblk == 0) return 0;
+  if (h->chain && h->precision != EHM_PREC_F32 && h->pipelined == 2 && h->tile_override == 0)
+    return ehm_gcn_hidden_chain_impl(h, (void* const*)bufs, rows_pad, (hipStream_t)stream);
+  int in = 0;
+  for (int blk = 0; blk < nblk; ++blk) {     // the same buffer rotation, one launch per conv
+    const int y2 = in == 0 ? 2 : 0;
+    int rc = ehm_gcn_hidden_layer(h, 2 * blk, bufs[in], nullptr, bufs[1], rows_pad, stream);
+    if (rc == 0) rc = ehm_gcn_hidden_layer(h, 2 * blk + 1, bufs[1], bufs[in], bufs[y2], rows_pad, stream);
+    if (rc != 0) return rc;
+    in = y2;
+  }
+  return 0;
+}
+
+extern "C" int ehm_gcn_stack_status(ehm_gcn* h, void* stream) {
+  EHM_CHECK_ARG(h);
+  unsigned int flag = 0;
+  const int rc = ehm_gcn_chain_error(h, (hipStream_t)stream, &flag);
+  if (rc != 0) return rc;
+  if (flag) {
+    ehm_set_error("ehm_gcn_hidden_stack: a producer wait timed out inside the chained kernel; results are invalid");
+    return EHM_EIO;
+  }
   return 0;
 }
 

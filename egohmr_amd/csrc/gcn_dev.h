@@ -48,6 +48,11 @@ struct ehm_gcn {
   int tile_override = 0;   // split-f16 convs: 0 = pick by size, 1 = 192x64 tiles, 2 = 384x128 tiles
   LayerDev input{};
   LayerDev hidden[16]{};
+  LayerDev* hidden_dev = nullptr;        // device copy of hidden[] for the chained kernel (gcn_f16r.hip)
+  unsigned int* chain_sync = nullptr;    // tickets[8] | done[nl][m_tiles] | err, zeroed before every chained launch
+  size_t chain_sync_words = 0;
+  size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
+  int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (split-f16, pipelined == 2), 0 = one launch per conv
   OutDev out{};
   float* arena = nullptr;
   float* hs = nullptr;      // [hs_rows,12] responses of the output conv (gcn_out_dot_kernel -> gcn_out_mix_kernel)

@@ -45,19 +45,17 @@ struct Frags {
   half8 ah[3], al[3], bh[2], bl[2];
 };
 
-template <int PASSES, bool RES, bool OUT_SPLIT>
-__global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* __restrict__ X, LayerDev L,
-                                                                  const half_t* __restrict__ Res, float* __restrict__ Y,
-                                                                  int m_tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * RSTG];   // 80 KiB, the only LDS object
-
+// One 192-row x 64-channel output tile of one hidden conv.  `lds` = the block's 80 KiB; no barrier at the end (the caller
+// must put one between this tile's last LDS reads and its next use of `lds`).  RES / OUT_SPLIT are compile-time constants in
+// the one-launch-per-conv kernel and runtime (block-uniform) values in the chained kernel.
+// AUX = cache-policy bits of the output stores, IN_AUX = of the activation loads (A-operand DMA, residual); 16 = sc1 = agent scope
+// (stores write through, loads bypass the CU's L1), used by the chained kernel.  `ready()` is called after the weight DMA of
+// the first two K tiles has been issued and before the first activation byte is requested.
+template <int PASSES, int AUX, int IN_AUX, class Ready>
+__device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__ X, const LayerDev& L, const half_t* __restrict__ Res,
+                                          float* __restrict__ Y, int m_tile, int n_tile, const bool RES, const bool OUT_SPLIT, Ready ready) {
   STAMP(0); STAMPC(4);
   const int K = L.K, N = L.N;
-  const int n_tiles = N / 64;
-  const int total = m_tiles * n_tiles;
-  const int bid = blockIdx.x;
-  const int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;   // XCD-aware tile order
-  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
   const size_t m0 = (size_t)m_tile * 192;
 
   const int tid = threadIdx.x;
@@ -73,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* _
   const float* pB = (const float*)L.Ws + ((size_t)n_tile * 128 + r0) * K + swz;
   const size_t row32 = (size_t)32 * K;
   auto dma_a = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + (wave + 4 * i) * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + (wave + 4 * i) * 256), 16, 0, IN_AUX);
   };
   auto dma_b = [&](int buf, int kt, int i) {
     __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + RA_T + (wave + 4 * i) * 256), 16, 0, 0);
@@ -175,9 +173,16 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* _
 
   const int KT = K / RK;
   Frags<PASSES> f0, f1;
-  stage(0, 0);
-  stage(1, 1);
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // tile 0 landed (tile 1 may still fly)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+  ready();
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile 0 landed (the activation half of tile 1 may still fly)
   __syncthreads();
   read_frags(f0, 0, 0);
   STAMP(1); STAMPC(5);
@@ -255,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* _
   if (RES) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      rh[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx, 0, 0);
-      rl[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx + 64u, 0, 0);
+      rh[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx, 0, IN_AUX);
+      rl[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx + 64u, 0, IN_AUX);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -303,15 +308,108 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* _
           h[k] = (half_t)c;
           l[k] = (half_t)(v[k] - (float)h[k]);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), yB, rowoff + ucolx, 0, kStoreAux);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l), yB, rowoff + ucolx + 64u, 0, kStoreAux);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), yB, rowoff + ucolx, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l), yB, rowoff + ucolx + 64u, 0, AUX);
       } else {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), yB, rowoff + ucolf, 0, kStoreAux);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), yB, rowoff + ucolf + 16u, 0, kStoreAux);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), yB, rowoff + ucolf, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), yB, rowoff + ucolf + 16u, 0, AUX);
       }
     }
   }
   STAMP(3); STAMPC(7);
+}
+
+template <int PASSES, bool RES, bool OUT_SPLIT>
+__global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* __restrict__ X, LayerDev L,
+                                                                  const half_t* __restrict__ Res, float* __restrict__ Y,
+                                                                  int m_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * RSTG];   // 80 KiB, the only LDS object
+  const int n_tiles = L.N / 64;
+  const int total = m_tiles * n_tiles;
+  const int bid = blockIdx.x;
+  const int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;   // XCD-aware tile order
+  f16r_tile<PASSES, kStoreAux, 0>(lds, X, L, Res, Y, lin / n_tiles, lin % n_tiles, RES, OUT_SPLIT, [] {});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// All hidden convs of one GCN forward in ONE launch (ehm_gcn_hidden_stack).  Work item = (layer, row tile, channel tile); a
+// conv's tile needs all 16 channel tiles of the previous conv for the SAME 192 rows and nothing else, so the convs are chained
+// per row tile with counters instead of kernel boundaries:
+//   * every XCD owns the row tiles m = xcc (mod 8) for ALL layers (the block reads its own XCC_ID), so producer and consumer of
+//     a row tile share one L2; each XCD has a ticket counter handing out its items in (layer, m, n) order - a consumer's
+//     producers always hold smaller tickets, so waiting cannot deadlock whatever the residency;
+//   * publish = sc1 (write-through) stores -> every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed agent-scope add on
+//     done[layer][m]; consume = one lane polls relaxed until done[layer-1][m] == n_tiles, barrier, agent acquire fence (drops
+//     the CU's stale L1 lines; or, default, agent-scope sc1 loads for the activations, which never hit in L1), then the tile's
+//     activation loads (cdna_hip_programming.md, counter hand-off recipe).  The weight DMA of the first two K tiles and the
+//     next ticket are issued before the poll, so its round trip is covered.  No work stealing across queues: a stolen tile
+//     would put producer and consumer on different L2s.  nq = number of XCDs of the device (CUs / 32).
+// What it buys: no launch ramp / two-round tail / inter-kernel gap per conv, and the blocks drift apart so one block's
+// VALU-bound epilogue overlaps its CU neighbour's MFMA loop.
+struct ChainArgs {
+  const LayerDev* layers;   // device array [nl]
+  half_t* buf[3];           // activation buffers (X2<32>): conv 2b reads cur -> writes buf[1]; conv 2b+1 reads buf[1] (+ residual cur) -> nxt
+  int nl, m_tiles, n_tiles;
+  unsigned int* tickets;    // [8]
+  unsigned int* done;       // [nl][m_tiles]
+  unsigned int* err;        // set when a wait timed out (results invalid)
+  int flags;                // bit 0 = agent acquire fence after the wait (needed only when the loads are not sc1)
+  int nq;                   // queues = XCDs
+};
+
+template <int PASSES, int AUX, int IN_AUX>
+__global__ __launch_bounds__(256, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * RSTG];   // 80 KiB, the only LDS object
+  const int tid = threadIdx.x;
+  const unsigned int q = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (unsigned int)a.nq;   // HW_REG_XCC_ID[3:0] -> my queue
+  const int cm = (a.m_tiles - (int)q + a.nq - 1) / a.nq;   // row tiles of this queue: q, q + nq, ...
+  if (cm <= 0) return;
+  const unsigned int ipl = (unsigned int)(cm * a.n_tiles), total = ipl * (unsigned int)a.nl;
+  volatile unsigned int* slot = (volatile unsigned int*)lds;
+  if (tid == 0) slot[0] = __hip_atomic_fetch_add(&a.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  unsigned int t = __builtin_amdgcn_readfirstlane(slot[0]);
+  while (t < total) {
+    __syncthreads();                                     // everybody has the ticket before this tile's DMA overwrites the slot
+    unsigned int t_next = 0;                             // the next ticket travels under this tile
+    if (tid == 0) t_next = __hip_atomic_fetch_add(&a.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int layer = (int)(t / ipl), r = (int)(t % ipl);
+    const int m_tile = (int)q + a.nq * (r / a.n_tiles), n_tile = r % a.n_tiles;
+    const int blk = layer >> 1, cur = (blk & 1) ? 2 : 0, nxt = (blk & 1) ? 0 : 2;
+    const bool odd = layer & 1;
+    const half_t* X = odd ? a.buf[1] : a.buf[cur];
+    const half_t* Res = odd ? a.buf[cur] : nullptr;
+    float* Y = (float*)(odd ? a.buf[nxt] : a.buf[1]);
+    f16r_tile<PASSES, AUX, IN_AUX>(lds, X, a.layers[layer], Res, Y, m_tile, n_tile, odd, layer != a.nl - 1, [&] {
+      if (layer == 0) return;                            // (block-uniform)
+      if (tid == 0) {
+        const unsigned int* f = a.done + (size_t)(layer - 1) * a.m_tiles + m_tile;
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)a.n_tiles) {
+          __builtin_amdgcn_s_sleep(4);
+          ++spins;                                       // never hang the device: give up after ~1 s (or at once when
+          if (spins > (1 << 22) || ((spins & 255) == 0 &&  // somebody else already has) and flag the launch as failed
+                                    __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+#ifdef EHM_STAMPS
+        if (spins) { __hip_atomic_fetch_add(a.err + 1, (unsigned int)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(a.err + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+      }
+      __syncthreads();
+      if (a.flags & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have reached L2 / memory
+    __syncthreads();                                     // ... everybody's have, and nobody reads LDS any more
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&a.done[(size_t)layer * a.m_tiles + m_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      slot[0] = t_next;
+    }
+    __syncthreads();
+    t = __builtin_amdgcn_readfirstlane(slot[0]);
+  }
 }
 
 template <int PASSES>
@@ -336,8 +434,66 @@ int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, voi
 }  // namespace
 
 #ifdef EHM_STAMPS
+extern "C" int ehm_dbg_chain_stats(ehm_gcn* h, unsigned int* out3) {   // err, total spins, waits that had to spin (last chained launch)
+  if (!h || !h->chain_sync) return EHM_EINVAL;
+  EHM_HIP(hipDeviceSynchronize());
+  EHM_HIP(hipMemcpy(out3, h->chain_sync + h->chain_err_off, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  return 0;
+}
 extern "C" int ehm_dbg_set(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &q, sizeof(q)); }
 #endif
+
+int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st) {
+  const int nl = h->num_hidden;
+  if (h->hid % 64 != 0 || nl < 2 || (nl & 1) || h->hidden[0].K % RK != 0 || h->hidden[0].K / RK < 2 || rows_pad % 192 != 0) {
+    ehm_set_error("chained split-f16 convs need hid %% 64 == 0, K >= 64, an even number of hidden convs and rows_pad %% 192 == 0");
+    return EHM_EINVAL;
+  }
+  const int m_tiles = (int)(rows_pad / 192), n_tiles = h->hid / 64;
+  const size_t need = 8 + (size_t)nl * m_tiles + 8;   // tickets | done | err, (stamps build: total spins, waits that spun)
+  if (h->chain_sync_words < need) {                    // grows on the first call of a new shape; never inside a steady loop
+    if (h->chain_sync) EHM_HIP(hipFree(h->chain_sync));
+    h->chain_sync = nullptr;
+    h->chain_sync_words = 0;
+    EHM_HIP(hipMalloc(&h->chain_sync, need * sizeof(unsigned int)));
+    h->chain_sync_words = need;
+  }
+  EHM_HIP(hipMemsetAsync(h->chain_sync, 0, need * sizeof(unsigned int), st));
+  ChainArgs a;
+  a.layers = h->hidden_dev;
+  for (int i = 0; i < 3; ++i) a.buf[i] = (half_t*)bufs[i];
+  a.nl = nl;
+  a.m_tiles = m_tiles;
+  a.n_tiles = n_tiles;
+  a.tickets = h->chain_sync;
+  a.done = h->chain_sync + 8;
+  h->chain_err_off = 8 + (size_t)nl * m_tiles;
+  a.err = h->chain_sync + h->chain_err_off;
+  const int total = nl * m_tiles * n_tiles;
+  int blocks = 2 * ehm_num_cus();                      // what is co-resident (80 KiB LDS per block)
+  if (blocks > total) blocks = total;
+  a.nq = ehm_num_cus() / 32;
+  if (a.nq < 1) a.nq = 1;
+  if (a.nq > 8) a.nq = 8;
+  const int mode = getenv("EHM_CHAIN_MODE") ? atoi(getenv("EHM_CHAIN_MODE")) : 0;   // 0 = sc1 loads (default), 1 = plain loads + acquire fence, 2 = neither (timing experiment only)
+  a.flags = mode == 1 ? 1 : 0;
+  if (h->precision == EHM_PREC_F16X3) {
+    if (mode == 0) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 16>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 0>), dim3(blocks), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 16, 16>), dim3(blocks), dim3(256), 0, st, a);
+  }
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+int ehm_gcn_chain_error(const ehm_gcn* h, hipStream_t st, unsigned int* flag) {   // debugging aid: did a wait time out in the last chain launch?
+  *flag = 0;
+  if (!h->chain_sync) return 0;
+  EHM_HIP(hipMemcpyAsync(flag, h->chain_sync + h->chain_err_off, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  EHM_HIP(hipStreamSynchronize(st));
+  return 0;
+}
 
 int ehm_gcn_hidden_f16r_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
                              bool out_split, hipStream_t st) {

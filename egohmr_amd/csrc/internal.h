@@ -21,6 +21,8 @@ int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
                             bool out_split, hipStream_t st);
 // gcn_f16p.hip
+int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
+int ehm_gcn_chain_error(const ehm_gcn* h, hipStream_t st, unsigned int* flag);
 int ehm_gcn_hidden_f16r_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
                              bool out_split, hipStream_t st);
 int ehm_gcn_hidden_f16p_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,

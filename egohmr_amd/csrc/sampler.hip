@@ -170,12 +170,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257) ----
     rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
     int in = 0;
-    for (int blk = 0; blk < nh / 2 && rc == 0; ++blk) {
-      const int y1 = 1, y2 = in == 0 ? 2 : 0;
-      rc = ehm_gcn_hidden_layer(gcn, 2 * blk, w.X[in], nullptr, w.X[y1], w.rows_pad, st);
-      if (rc == 0) rc = ehm_gcn_hidden_layer(gcn, 2 * blk + 1, w.X[y1], w.X[in], w.X[y2], w.rows_pad, st);
-      in = y2;
-    }
+    if (rc == 0) rc = ehm_gcn_hidden_stack(gcn, w.X, w.rows_pad, &in, st);
     if (rc == 0) rc = ehm_gcn_output_layer(gcn, w.X[in], vis, x0_final, B, d->passes, st);
     // ---- body decode (egohmr.py:258-278) ----
     if (rc == 0 && (d->lbs_every_step || last))

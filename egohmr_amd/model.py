@@ -430,12 +430,10 @@ class FusedSampler:
         h = self.gcn()
         _lib.check(L.ehm_gcn_input_layer(h, _lib.ptr(st.h_img), _lib.ptr(st.h_oth), _lib.ptr(st.vis), _lib.ptr(x_t), _lib.ptr(self._folded.Wx),
                                          _lib.ptr(tvec), _lib.ptr(X[0]), B, passes, s), "ehm_gcn_input_layer")
-        cur = 0
-        for blk in range(m.diffusion_model.num_layers):
-            y1, y2 = 1, (2 if cur == 0 else 0)
-            _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk, _lib.ptr(X[cur]), None, _lib.ptr(X[y1]), rows_pad, s), "ehm_gcn_hidden_layer")
-            _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk + 1, _lib.ptr(X[y1]), _lib.ptr(X[cur]), _lib.ptr(X[y2]), rows_pad, s), "ehm_gcn_hidden_layer")
-            cur = y2
+        bufs = (C.c_void_p * 3)(*[x.data_ptr() for x in X])
+        res = C.c_int(0)
+        _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), s), "ehm_gcn_hidden_stack")
+        cur = res.value
         x0 = torch.empty(B, 144, device=m.device)
         _lib.check(L.ehm_gcn_output_layer(h, _lib.ptr(X[cur]), _lib.ptr(st.vis), _lib.ptr(x0), B, passes, s), "ehm_gcn_output_layer")
         self.last_hidden = X[cur][:rows]

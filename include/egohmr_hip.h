@@ -132,6 +132,16 @@ int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, cons
 int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const float* residual, float* out,
                          int64_t rows_pad, void* stream);
 
+/* All hidden convs of one ModulatedGCN.forward (the `for i in range(self.num_layers): out = self.gconv_layers[i](out)` loop,
+ * modulated_gcn.py:108-109; each _ResGraphConv = two _GraphConv + residual, :31-43).  bufs[0] holds the input conv's output,
+ * bufs[1] and bufs[2] are scratch of the same size; *result_index says which buffer holds the result (0 or 2).  With the
+ * default split-f16 operands this is ONE chained launch (per-row-tile counters instead of kernel boundaries); otherwise it
+ * loops over ehm_gcn_hidden_layer with the same buffer rotation.  Env EHM_F16_CHAIN=0 forces the loop. */
+int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t rows_pad, int* result_index, void* stream);
+/* Synchronises the stream and reports whether the last chained launch flagged a timed-out producer wait (never expected;
+ * the kernel gives up instead of hanging the device).  0 = fine. */
+int ehm_gcn_stack_status(ehm_gcn* h, void* stream);
+
 /* gconv_output (modulated_gcn.py:113) + the visibility fuse of egohmr.py:247-256:
  *   x0[b, j*6+c] = vis[b,j] ? out_cond[b,j,c] : out_uncond[b,j,c]      (passes == 2)
  *   x0 = out_cond                                                      (passes == 1)

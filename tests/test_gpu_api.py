@@ -176,3 +176,43 @@ def test_smpl_pkl_loads_without_chumpy(tmp_path, dev, smpl_asset):
     I = torch.eye(3, device=dev).expand(1, 24, 3, 3).contiguous()
     np.testing.assert_allclose(m(betas=betas, body_pose=I[:, 1:], global_orient=I[:, :1], pose2rot=False).vertices.cpu().numpy(),
                                ref(betas=betas, body_pose=I[:, 1:], global_orient=I[:, :1], pose2rot=False).vertices.cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,passes", [(8, 2), (256, 2), (21, 1)])
+def test_hidden_stack_chained_equals_layer_by_layer(B, passes):
+    """ehm_gcn_hidden_stack (one chained launch, per-row-tile counters) == the same convs launched one by one:
+    same tile code, so bit-identical; and no producer wait may time out."""
+    import ctypes as C
+    from egohmr_amd import _lib
+    from egohmr_amd.factory import build_synthetic_model
+    dev = torch.device("cuda:0")
+    model = build_synthetic_model(dev, 0)
+    L = _lib.lib()
+    h = model.fused_sampler.gcn()
+    assert L.ehm_gcn_get_precision(h) == 1
+    hid, tile = model.diffusion_model.hid_dim, L.ehm_gcn_row_tile()
+    rows = passes * B * 24
+    rows_pad = (rows + tile - 1) // tile * tile
+    g = torch.Generator(device=dev).manual_seed(3)
+    x0 = torch.relu(torch.randn(rows_pad, hid, device=dev, generator=g)) * 0.5
+    x0[rows:] = 0
+    X0 = torch.empty_like(x0)
+    _lib.check(L.ehm_gcn_pack_activations(x0.data_ptr(), X0.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))
+    # reference: one launch per conv
+    ref = [X0.clone(), torch.zeros_like(X0), torch.zeros_like(X0)]
+    cur = 0
+    for blk in range(model.diffusion_model.num_layers):
+        y2 = 2 if cur == 0 else 0
+        _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk, ref[cur].data_ptr(), None, ref[1].data_ptr(), rows_pad, None))
+        _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk + 1, ref[1].data_ptr(), ref[cur].data_ptr(), ref[y2].data_ptr(), rows_pad, None))
+        cur = y2
+    torch.cuda.synchronize()
+    for rep in range(3):      # repeated launches reuse (and re-zero) the counters
+        bufs_t = [X0.clone(), torch.full_like(X0, float("nan")), torch.full_like(X0, float("nan"))]
+        bufs = (C.c_void_p * 3)(*[t.data_ptr() for t in bufs_t])
+        res = C.c_int(-1)
+        _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), None))
+        _lib.check(L.ehm_gcn_stack_status(h, None))
+        assert res.value == cur
+        assert torch.equal(bufs_t[res.value], ref[cur]), f"rep {rep}"

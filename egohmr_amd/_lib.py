@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "ehm_linear_split": (_I, [C.POINTER(LinearDesc), _P]),
     "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),
+    "ehm_bias_act": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P]),

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
   const int N = L.N;
   const int vb = blockIdx.x;           // virtual body = p*B + b
   const int p = vb / B, b = vb % B;
-  const int n = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
-  if (n >= N) return;
+  const int n_raw = blockIdx.y * 256 + threadIdx.x;
+  const int n = n_raw < N ? n_raw : N - 1;                        // lanes past N recompute the last channel; their stores are dropped
   float base[2], img[2], wx[2][6];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -291,49 +291,92 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
     h0[j] = fmaf(L.D[j * N + n], s0, sh);
     h1[j] = L.M1[j * N + n] * s1;
   }
-  float zero[kJ];
+  // 24x24 adjacency mix per lane (one channel), then through a float [24][256] LDS tile so that the rows leave as 16-byte stores
+  // (one dword per lane and joint is store-issue bound: 30 us for 48 MiB).
+  __shared__ __attribute__((aligned(16))) float T[kJ * 256];
+  {
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* Ac = (const cfloat*)(uintptr_t)L.Aoff;
+    const bool relu = L.relu != 0;
 #pragma unroll
-  for (int j = 0; j < kJ; ++j) zero[j] = 0.f;
-  gcn_mix_store<SPLIT_OUT, G>(h0, h1, zero, n, N, (size_t)vb * kJ, L.Aoff, Y, L.relu != 0);
+    for (int j = 0; j < kJ; ++j) {
+      float sacc = h0[j];
+#pragma unroll
+      for (int jp = 0; jp < kJ; ++jp) sacc = fmaf(Ac[j * kJ + jp], h1[jp], sacc);
+      if (relu) sacc = fmaxf(sacc, 0.f);
+      T[j * 256 + threadIdx.x] = sacc;
+    }
+  }
+  __syncthreads();
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int nb = blockIdx.y * 256;                               // first channel of this block (N % 256 may leave a partial block)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int u = threadIdx.x + 256 * i, j = u >> 5, c8 = (u & 31) * 8;   // (joint, 8 consecutive channels)
+    if (nb + c8 >= N) continue;
+    const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const size_t row = (size_t)vb * kJ + j;
+    if (SPLIT_OUT) {
+      half8 hh, ll;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
+        hh[k] = (half_t)c;
+        ll[k] = (half_t)(v[k] - (float)hh[k]);
+      }
+      half_t* p = (half_t*)Y + split_off<G>(row, nb + c8, N);   // 8 | G: the eight hi halves are contiguous, the lo halves G further
+      *(u32x4*)p = __builtin_bit_cast(u32x4, hh);
+      *(u32x4*)(p + G) = __builtin_bit_cast(u32x4, ll);
+    } else {
+      float* p = Y + row * (size_t)N + nb + c8;
+      *(f32x4*)p = v0;
+      *(f32x4*)(p + 4) = v1;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // output conv (hid -> 6, both branches) + visibility fuse, two kernels:
-//   gcn_out_dot_kernel   HBM-bound: every activation row is read once (float4, coalesced); the 12 x K output weights sit in
-//                        LDS; one wave per row at a time, 8 rows per wave; 12 dot products reduced with wave shuffles.
+//   gcn_out_dot_kernel   HBM-bound: every activation row is read once (float4); [rows,K] x [K,12] on the exact-f32 MFMA.
 //   gcn_out_mix_kernel   per body: modulated adjacency mix of the [24 x 12] responses, bias, pass selection by visibility.
 // ------------------------------------------------------------------------------------------------
-constexpr int OUT_ROWS_PER_BLOCK = 32;
+constexpr int OUT_ROWS_PER_BLOCK = 16;
 
+// [rows, K] x [K, 12] on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32: 16 rows x 16 columns, 12 used).  Block = 16 rows, its 4 waves
+// split K; a wave's lane (row = l&15, q = l>>4) streams float4 X[row][kw + 16 i + 4 q ..+3] - the k order inside an MFMA step is a
+// permutation applied to both operands, which a sum does not see - and the matching float4 of the 12 x K weights (48 KiB, L2 hits).
+// The four partial 16x16 tiles meet in 4 KiB of LDS.  HBM-bound by design: every activation row is read once, 16-byte loads,
+// 4 x 64 B per row and instruction.  (The previous VALU version re-read the weights from LDS for every row: 39 us per launch.)
 __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restrict__ X, OutDev O, float* __restrict__ hs, int64_t rows) {
-  extern __shared__ __attribute__((aligned(16))) float sW[];   // [12][K]
+  __shared__ float part[4][16][16];
   const int K = O.K, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid * 4; i < 12 * K; i += 256 * 4) *(f32x4*)(sW + i) = *(const f32x4*)(O.Wt + i);
+  const int row = lane & 15, q = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK;
+  const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
+  const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: whole 16-k groups)
+  const float* xr = X + r * K + (size_t)wave * kq + 4 * q;
+  const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 4 * q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: the dependent-accumulator latency (40 cyc) exceeds the issue interval
+#pragma unroll 4
+  for (int k = 0; k < kq; k += 16) {                                 // 16 k = four MFMA steps per float4 pair
+    const f32x4 xv = *(const f32x4*)(xr + k);
+    f32x4 wv = *(const f32x4*)(wr + k);
+    if (row >= 12) wv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], wv[c], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], wv[c + 1], acc2, 0, 0, 0);
+    }
+  }
+  acc += acc2;
+  // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int c = 0; c < 4; ++c) part[wave][4 * q + c][row] = acc[c];
   __syncthreads();
-  const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK + wave * (OUT_ROWS_PER_BLOCK / 4);
-  for (int rr = 0; rr < OUT_ROWS_PER_BLOCK / 4; ++rr) {
-    const int64_t r = r0 + rr;
-    if (r >= rows) break;
-    const float* xr = X + r * K;
-    float acc[12];
-#pragma unroll
-    for (int c = 0; c < 12; ++c) acc[c] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-      const f32x4 xv = *(const f32x4*)(xr + k);
-#pragma unroll
-      for (int c = 0; c < 12; ++c) {
-        const f32x4 wv = *(const f32x4*)(sW + c * K + k);
-        acc[c] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[c]))));
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 12; ++c) acc[c] = wave_sum(acc[c]);   // DPP row reduction + 4 readlanes (no LDS crossbar)
-    if (lane < 12) {
-      float v = acc[0];
-#pragma unroll
-      for (int c = 1; c < 12; ++c) v = lane == c ? acc[c] : v;
-      hs[r * 12 + lane] = v;
-    }
+  if (tid < 16 * 12) {
+    const int rr = tid / 12, cc = tid % 12;
+    if (r0 + rr < rows) hs[(r0 + rr) * 12 + cc] = (part[0][rr][cc] + part[1][rr][cc]) + (part[2][rr][cc] + part[3][rr][cc]);
   }
 }
 
@@ -572,9 +615,7 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
     EHM_HIP(hipMalloc(&h->hs, (size_t)round_up(rows, 4096) * 12 * sizeof(float)));
     h->hs_rows = round_up(rows, 4096);
   }
-  const size_t lds = (size_t)12 * h->hid * sizeof(float);
-  if (lds > 64 * 1024) EHM_HIP(hipFuncSetAttribute((const void*)gcn_out_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(gcn_out_dot_kernel, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), lds, (hipStream_t)stream, X,
+  hipLaunchKernelGGL(gcn_out_dot_kernel, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, X,
                      h->out, h->hs, rows);
   hipLaunchKernelGGL(gcn_out_mix_kernel, dim3(B), dim3(192), 0, (hipStream_t)stream, h->hs, h->out, vis, x0, B, passes);
   EHM_LAUNCH_CHECK();

@@ -178,6 +178,12 @@ int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int K_padded, 
 int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
                       int C, void* stream);
 
+/* In place y = act(y + bias[c] (+ residual)) over an NCHW float tensor (c = (i / HW) % C): the BatchNorm-folded bias,
+ * the bottleneck's identity add and the ReLU of torchvision's ResNet-50 (`out = self.bn3(out); out += identity;
+ * out = self.relu(out)`, used as EgoHMR's backbone at models/egohmr/egohmr.py:183) in ONE pass over the activation instead
+ * of the three or four eager passes.  residual may be NULL; relu != 0 applies max(., 0). */
+int ehm_bias_act(float* y, const float* bias, const float* residual, int64_t n, int C, int HW, int relu, void* stream);
+
 /* ------------------------------------------------------------------ sampler steps ------------- */
 /* diffusion/gaussian_diffusion.py:217-220 + :333-336 (p_sample) and :378-385 (p_sample_with_grad):
  *   mean = coef1*x0 + coef2*x  [+ grad_scale * grad]

@@ -38,3 +38,38 @@ with torch.no_grad():
             fb = m.backbone.folded(channels_last=cl)
             t, o = timeit(lambda: fb(img))
             print(f"resnet50 BN-folded cl={cl!s:5s}  : {t:7.2f} ms   max|d| vs shipped {float((o - ref).abs().max()):.2e}")
+
+    # --- experiments: fewer elementwise passes around the convolutions
+    bb = m.backbone
+
+    def fold(conv, bn):
+        scale = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+        return (conv.weight.double() * scale.view(-1, 1, 1, 1)).float(), (bn.bias.double() - bn.running_mean.double() * scale).float(), conv.stride, conv.padding
+
+    stem = fold(bb.conv1, bb.bn1)
+    blocks = []
+    for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
+        for blk in layer:
+            blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), fold(blk.conv3, blk.bn3),
+                           fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+
+    def cr(x, p):      # MIOpen fusion plan: conv + bias + relu
+        return torch.miopen_convolution_relu(x, p[0], p[1], p[2], p[3], (1, 1), 1)
+
+    def car(x, p, z):  # conv + z + bias + relu
+        return torch.miopen_convolution_add_relu(x, p[0], z, 1.0, p[1], p[2], p[3], (1, 1), 1)
+
+    def run_fused(x):
+        x = F.max_pool2d(cr(x, stem), 3, stride=2, padding=1)
+        for c1, c2, c3, ds in blocks:
+            y = cr(x, c1)
+            y = cr(y, c2)
+            sc = x if ds is None else F.conv2d(x, ds[0], ds[1], stride=ds[2], padding=ds[3])
+            x = car(y, c3, sc)
+        return x.mean(dim=(2, 3))
+
+    try:
+        t, o = timeit(lambda: run_fused(img))
+        print(f"resnet50 miopen conv+bias+relu : {t:7.2f} ms   max|d| vs shipped {float((o - ref).abs().max()):.2e}")
+    except Exception as e:  # noqa: BLE001
+        print("miopen fused path failed:", repr(e)[:300])

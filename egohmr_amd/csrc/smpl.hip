@@ -266,6 +266,140 @@ __global__ __launch_bounds__(kVT, 2) void skin_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ skinning on the matrix cores
+// The shape + pose-corrective blend is a GEMM  [bodies, 224] x [224, V*3]  (coefficients = [R[1:] - I | betas]).  On the VALU it
+// was 70 % of skin_kernel (101 us per B=256 launch, 35 TFLOP/s); here it runs as split-f16 MFMA (hi/lo operands, 3 MFMA per
+// product, f32 accumulate - the same f32-grade scheme as the GCN convs): one wave = 32 bodies x 32 vertices, three accumulators
+// (x, y, z) so that afterwards lane (vertex, half) owns the blended position of its vertex for 16 bodies and finishes the
+// skinning (sparse-4 weights, transforms in LDS) without any transposition.  Both operands are stored in fragment order - every
+// load instruction reads 1 KiB contiguous - and go straight from L2 to registers.
+typedef _Float16 sk_half8 __attribute__((ext_vector_type(8)));
+
+__global__ void pd_pack_kernel(const float* __restrict__ posedirs, const float* __restrict__ shapedirs, sk_half8* __restrict__ out,
+                               int V, int v_tiles, float scale) {
+  // one thread per (vertex tile, k-step, coord, lane): writes the hi and the lo fragment
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)v_tiles * kBlendSteps * 3 * 64) return;
+  const int lane = (int)(i & 63), c = (int)((i >> 6) % 3), s = (int)((i / 192) % kBlendSteps), vt = (int)(i / (192 * kBlendSteps));
+  const int v = 32 * vt + (lane & 31);
+  sk_half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * s + 8 * (lane >> 5) + e;
+    float x = 0.f;
+    if (v < V) {
+      if (k < kPoseBasis) x = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + c];
+      else if (k < kPoseBasis + 10) x = shapedirs[((size_t)v * 3 + c) * 10 + (k - kPoseBasis)];
+    }
+    x *= scale;
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+  const size_t base = (((size_t)vt * kBlendSteps + s) * 3 + c) * 2;
+  out[(base + 0) * 64 + lane] = hi;
+  out[(base + 1) * 64 + lane] = lo;
+}
+
+__global__ void pf_pack_kernel(const float* __restrict__ Rws, const float* __restrict__ betas, sk_half8* __restrict__ out, int B, int b_tiles) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b_tiles * kBlendSteps * 64) return;
+  const int lane = i & 63, s = (i >> 6) % kBlendSteps, bt = i / (64 * kBlendSteps);
+  const int b = 32 * bt + (lane & 31);
+  sk_half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * s + 8 * (lane >> 5) + e;
+    float x = 0.f;
+    if (b < B) {
+      if (k < kPoseBasis) x = Rws[((size_t)b * kJ + 1) * 9 + k] - ((k % 9 == 0 || k % 9 == 4 || k % 9 == 8) ? 1.f : 0.f);   // R[1:] - I
+      else if (k < kPoseBasis + 10) x = betas[(size_t)b * 10 + (k - kPoseBasis)];
+    }
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+  const size_t base = ((size_t)bt * kBlendSteps + s) * 2;
+  out[(base + 0) * 64 + lane] = hi;
+  out[(base + 1) * 64 + lane] = lo;
+}
+
+__global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restrict__ PF, const float* __restrict__ A, SmplDev S,
+                                                        float* __restrict__ verts, int B, int v_tiles, int vt_groups) {
+  __shared__ __attribute__((aligned(16))) float sA[32][kJ][12];   // 36 KiB: skinning transforms of the block's 32 bodies
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware order: the blocks of one XCD walk the body tiles of the same vertex-tile group back to back (basis fragments from L2)
+  const int bid = blockIdx.x, xcd = bid & 7, kk = bid >> 3;
+  const int b_tiles = (B + 31) / 32;
+  const int vg = (kk / b_tiles) * 8 + xcd, bt = kk % b_tiles;
+  if (vg >= vt_groups) return;
+  const int b0 = 32 * bt, nb = min(32, B - b0);
+  for (int i = tid; i < 32 * kJ * 12; i += 256) (&sA[0][0][0])[i] = (i / (kJ * 12)) < nb ? A[(size_t)b0 * kJ * 12 + i] : 0.f;
+  __syncthreads();
+  const int vt = 4 * vg + wave;
+  if (vt >= v_tiles) return;
+
+  const sk_half8* pa = PF + ((size_t)bt * kBlendSteps * 2) * 64 + lane;
+  const sk_half8* pb = (const sk_half8*)S.PDf + ((size_t)vt * kBlendSteps * 6) * 64 + lane;
+  f32x16 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  sk_half8 a_hi = pa[0], a_lo = pa[64], b_hi[3], b_lo[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { b_hi[c] = pb[(2 * c) * 64]; b_lo[c] = pb[(2 * c + 1) * 64]; }
+  for (int s = 0; s < kBlendSteps; ++s) {
+    // next step's fragments in flight under this step's nine MFMAs (the last iteration re-reads step 13: harmless)
+    const int sn = s + 1 < kBlendSteps ? s + 1 : s;
+    const sk_half8 na_hi = pa[(2 * sn) * 64], na_lo = pa[(2 * sn + 1) * 64];
+    sk_half8 nb_hi[3], nb_lo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nb_hi[c] = pb[(6 * sn + 2 * c) * 64]; nb_lo[c] = pb[(6 * sn + 2 * c + 1) * 64]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // small cross terms first, leading term last
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi[c], acc[c], 0, 0, 0);
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo[c], acc[c], 0, 0, 0);
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[c], acc[c], 0, 0, 0);
+    }
+    a_hi = na_hi; a_lo = na_lo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { b_hi[c] = nb_hi[c]; b_lo[c] = nb_lo[c]; }
+  }
+
+  // ---- skinning: lane (vertex = lane & 31, half = lane >> 5) holds bodies (r&3) + 8*(r>>2) + 4*half, r = 0..15
+  const int v = 32 * vt + (lane & 31), half = lane >> 5;
+  if (v >= S.V) return;
+  const float inv = 1.f / S.pd_scale;
+  const float t0 = S.v_template[v * 3 + 0], t1 = S.v_template[v * 3 + 1], t2 = S.v_template[v * 3 + 2];
+  float wsp[4];
+  int jsp[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) { wsp[s4] = S.w_val[(size_t)s4 * S.V + v]; jsp[s4] = S.w_idx[(size_t)s4 * S.V + v]; }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int bb = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const float px = fmaf(acc[0][r], inv, t0), py = fmaf(acc[1][r], inv, t1), pz = fmaf(acc[2][r], inv, t2);
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float wj = wsp[s4];
+      const int j = jsp[s4];
+      const f32x4 r0 = *(const f32x4*)&sA[bb][j][0], r1 = *(const f32x4*)&sA[bb][j][4], r2 = *(const f32x4*)&sA[bb][j][8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T[e] = fmaf(wj, r0[e], T[e]); T[4 + e] = fmaf(wj, r1[e], T[4 + e]); T[8 + e] = fmaf(wj, r2[e], T[8 + e]);
+      }
+    }
+    if (bb < nb) {
+      float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
+      o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+      o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+      o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    }
+  }
+}
+
 __global__ void extra_joints_kernel(const float* __restrict__ verts, const int32_t* __restrict__ idx, float* __restrict__ joints,
                                     int B, int V, int n_extra) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,6 +499,34 @@ extern "C" int ehm_smpl_create(ehm_smpl** out, const float* v_template, const fl
                        d.J_shape, (int)V);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
   }
+  if (rc == 0 && d.sparse4) {   // blend basis as split-f16 MFMA fragments (skin_mfma_kernel); scale = power of two that keeps the lo halves normal
+    std::vector<float> hb((size_t)kPoseBasis * V * 3 + V * 30);
+    float amax = 0.f;
+    if (hipMemcpy(hb.data(), posedirs, (size_t)kPoseBasis * V * 3 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(hb.data() + (size_t)kPoseBasis * V * 3, shapedirs, V * 30 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
+      for (float x : hb) amax = fmaxf(amax, fabsf(x));
+      float scale = 1.f;
+      if (amax > 0.f && amax < 1e30f) {
+        int e;
+        frexpf(2048.f / amax, &e);          // 2048/amax = m * 2^e, m in [0.5, 1)  ->  2^(e-1) <= 2048/amax
+        scale = ldexpf(1.f, e - 1);
+      }
+      const int v_tiles = (int)ceil_div(V, 32);
+      const size_t bytes = (size_t)v_tiles * kBlendSteps * 6 * 64 * 16;
+      if (hipMalloc(&h->pdf, bytes) == hipSuccess) {
+        const int64_t n = (int64_t)v_tiles * kBlendSteps * 3 * 64;
+        hipLaunchKernelGGL(pd_pack_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, posedirs, shapedirs, (sk_half8*)h->pdf,
+                           (int)V, v_tiles, scale);
+        if (hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+          d.PDf = h->pdf;
+          d.pd_scale = scale;
+        } else {
+          (void)hipFree(h->pdf);
+          h->pdf = nullptr;
+        }
+      }
+    }
+  }
   if (rc != 0) {
     (void)hipFree(h->arena);
     delete h;
@@ -379,6 +541,8 @@ extern "C" void ehm_smpl_destroy(ehm_smpl* h) {
   if (!h) return;
   (void)hipFree(h->arena);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->pdf) (void)hipFree(h->pdf);
+  if (h->pf) (void)hipFree(h->pf);
   delete h;
 }
 
@@ -394,9 +558,26 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
   else
     hipLaunchKernelGGL(pose_chain_kernel<false>, dim3(B), dim3(64), 0, st, betas, rot_or_x, (const float*)nullptr,
                        (const float*)nullptr, d, Rws, Aws, joints, (float*)nullptr, jstride);
-  const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
-  const int blocks = (int)round_up(v_tiles, 8) * b_groups;
-  hipLaunchKernelGGL(skin_kernel, dim3(blocks), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);
+  static const int mfma_min = getenv("EHM_SKIN_MFMA_MIN_B") ? atoi(getenv("EHM_SKIN_MFMA_MIN_B")) : 24;   // below: the VALU kernel (a 32-body MFMA tile would be mostly padding)
+  if (d.PDf && B >= mfma_min) {
+    const int b_tiles = (int)ceil_div(B, 32);
+    if (32 * b_tiles > h->pf_cap) {                      // grows on the first call with a larger batch only
+      if (h->pf) EHM_HIP(hipFree(h->pf));
+      h->pf = nullptr;
+      h->pf_cap = 0;
+      EHM_HIP(hipMalloc(&h->pf, (size_t)b_tiles * kBlendSteps * 2 * 64 * 16));
+      h->pf_cap = 32 * b_tiles;
+    }
+    hipLaunchKernelGGL(pf_pack_kernel, dim3((unsigned)ceil_div(b_tiles * kBlendSteps * 64, 256)), dim3(256), 0, st, Rws, betas,
+                       (sk_half8*)h->pf, B, b_tiles);
+    const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
+    const int blocks = (int)round_up(vt_groups, 8) * b_tiles;
+    hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const sk_half8*)h->pf, Aws, d, verts, B, v_tiles, vt_groups);
+  } else {
+    const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
+    const int blocks = (int)round_up(v_tiles, 8) * b_groups;
+    hipLaunchKernelGGL(skin_kernel, dim3(blocks), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);
+  }
   if (d.n_extra)
     hipLaunchKernelGGL(extra_joints_kernel, dim3((unsigned)ceil_div((int64_t)B * d.n_extra * 3, 256)), dim3(256), 0, st, verts,
                        d.extra_idx, joints, B, d.V, d.n_extra);

@@ -26,8 +26,15 @@ struct SmplDev {
   float* J_template;   // [24][3]     J_regressor . v_template
   float* J_shape;      // [24][3][10] J_regressor . shapedirs
   int32_t* extra_idx;  // [n_extra]
+  // blend basis [posedirs; shapedirs] (K = 207 + 10 -> 224) as split-f16 MFMA B fragments (skin_mfma_kernel):
+  // PDf[vertex tile of 32][k-step of 16][coord][hi/lo][lane][8 halves], values x pd_scale (power of two)
+  const void* PDf;
+  float pd_scale;
   Tree tree;
 };
+
+constexpr int kBlendK = 224;          // 207 pose-corrective + 10 shape coefficients, padded to 14 MFMA k-steps of 16
+constexpr int kBlendSteps = kBlendK / 16;
 
 
 static __device__ __forceinline__ void rot6d_to_R(float a1x, float a1y, float a1z, float a2x, float a2y, float a2z, float (&R)[9]) {
@@ -54,4 +61,7 @@ struct ehm_smpl {
   float* arena = nullptr;      // packed constants
   float* ws = nullptr;         // per-call scratch: R [cap,24,9] + A [cap,24,12] (+ backward scratch)
   int ws_cap = 0;
+  void* pdf = nullptr;         // SmplDev::PDf storage
+  void* pf = nullptr;          // blend coefficients of the current batch as MFMA A fragments [ceil(B/32)][14][hi/lo][64][8 halves]
+  int pf_cap = 0;              // bodies
 };

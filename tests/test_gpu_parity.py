@@ -75,7 +75,7 @@ def test_rot6d_to_rotmat_vs_reference_golden(golden_dir, dev):
 
 
 # --------------------------------------------------------------------------------------------- SMPL LBS
-@pytest.mark.parametrize("B", [1, 7, 8, 9, 64, 257])
+@pytest.mark.parametrize("B", [1, 7, 8, 9, 23, 24, 33, 64, 257])   # < 24: VALU skinning kernel, >= 24: MFMA kernel (32-body tiles, ragged tails)
 def test_smpl_forward_vs_oracle(dev, smpl_asset, B):
     from egohmr_amd import smpl as smpl_mod
     from oracle import geometry as ogeo

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_f16.hip", "gcn_f16p.hip", "gcn_f16r.hip", "linear.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_f16.hip", "gcn_f16p.hip", "gcn_f16r.hip", "linear.hip", "conv.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -58,6 +58,14 @@ class LinearDesc(C.Structure):
     _fields_ = [("A0", C.c_void_p), ("A1", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("group_bias", C.c_void_p),
                 ("Y", C.c_void_p), ("colmax", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K0", C.c_int), ("K1", C.c_int),
                 ("rows_per_group", C.c_int), ("valid_rows_per_group", C.c_int), ("relu_in0", C.c_int), ("relu_out", C.c_int),
+                ("w_scale", C.c_float)]
+
+
+class ConvDesc(C.Structure):
+    """ehm_conv_desc"""
+    _fields_ = [("x", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
+                ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
                 ("w_scale", C.c_float)]
 
 
@@ -102,6 +110,7 @@ PROTOTYPES = {
     "ehm_linear_split": (_I, [C.POINTER(LinearDesc), _P]),
     "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "ehm_bias_act": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
     "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P]),

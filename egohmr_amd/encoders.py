@@ -58,7 +58,7 @@ class ResNet50Features(nn.Module):
     fold_batchnorm = True
 
     @torch.no_grad()
-    def folded(self, channels_last: bool = True):
+    def folded(self, channels_last: bool = True, matrix_core: bool = True):
         """Eval-mode equivalent with every BatchNorm2d folded into its convolution (w' = w * g/sqrt(v+eps),
         b' = beta - mean * g/sqrt(v+eps); exact up to float re-association) - removes 53 BatchNorm and most ReLU/add passes."""
         def fold(conv, bn):
@@ -108,8 +108,50 @@ class ResNet50Features(nn.Module):
                 x = cba(y, c3, res=x if ds is None else cba(x, ds, relu=False))
             return x.mean(dim=(2, 3))
 
+        # ---- matrix-core path: everything behind the stem as NHWC implicit GEMMs with fused bias / identity / ReLU (csrc/conv.hip)
+        import ctypes as C
+        import math
+        packed = {}
+
+        def pack(p):
+            """weights [Co,Ci,KH,KW] -> tap-major [Co_pad, KH*KW*Ci] X2 split format, scaled by a power of two"""
+            w = p[0]
+            if id(w) in packed:
+                return packed[id(w)]
+            Co, Ci, KH, KW = w.shape
+            K = KH * KW * Ci
+            Co_pad = (Co + 127) // 128 * 128
+            w2 = torch.zeros(Co_pad, K, device=w.device)
+            w2[:Co] = w.permute(0, 2, 3, 1).reshape(Co, K)
+            amax = float(w2.abs().max())
+            scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
+            buf = torch.empty(Co_pad, K, device=w.device)              # X2 rows have the byte size of float rows
+            _lib.check(_lib.lib().ehm_split_pack(w2.data_ptr(), buf.data_ptr(), Co_pad, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
+            packed[id(w)] = (buf, scale, p[1].contiguous(), (Co, Ci, KH, KW), p[2][0], p[3][0])
+            return packed[id(w)]
+
+        def conv_mc(x, p, res=None, relu=True):
+            buf, scale, bias, (Co, Ci, KH, KW), stride, pad = pack(p)
+            N, H, W, _ = x.shape
+            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+            y = torch.empty(N, Ho, Wo, Co, device=x.device)
+            d = _lib.ConvDesc(x.data_ptr(), buf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
+                              N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale)
+            _lib.check(_lib.lib().ehm_conv_nhwc_split(C.byref(d), _lib.stream_ptr()), "ehm_conv_nhwc_split")
+            return y
+
+        def run_mc(x):
+            x = F.max_pool2d(cba(x.contiguous(), stem), 3, stride=2, padding=1)      # stem (Ci = 3) stays on the library conv
+            x = x.permute(0, 2, 3, 1).contiguous()                                  # NHWC from here on
+            for c1, c2, c3, ds in blocks:
+                y = conv_mc(conv_mc(x, c1), c2)
+                x = conv_mc(y, c3, res=x if ds is None else conv_mc(x, ds, relu=False))
+            return x.mean(dim=(1, 2))
+
         def run(x):
-            return run_hip(x) if (x.is_cuda and not channels_last) else run_eager(x)
+            if not x.is_cuda or channels_last:
+                return run_eager(x)
+            return run_mc(x) if matrix_core else run_hip(x)
 
         return run
 

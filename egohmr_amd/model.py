@@ -190,6 +190,7 @@ class EgoHMR(nn.Module):
         self.collision_tau = 0.05
         self.guide_reduction = "mean"          # COAP variant: -loss.mean() (egohmr.py:562); 'sum' = VolSMPL variant
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        self.backbone_matrix_core = True   # ResNet-50 blocks as split-f16 implicit GEMMs (csrc/conv.hip); False = library convs + ehm_bias_act
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
         self.fused_sampler = FusedSampler(self)
@@ -363,7 +364,7 @@ class FusedSampler:
         bb = self.model.backbone
         key = tuple((t.data_ptr(), t._version) for t in list(bb.parameters()) + list(bb.buffers()))
         if getattr(self, "_bb_key", None) != key:
-            self._bb_fn, self._bb_key = bb.folded(channels_last=False), key
+            self._bb_fn, self._bb_key = bb.folded(channels_last=False, matrix_core=self.model.backbone_matrix_core), key
         return self._bb_fn
 
     # ------------------------------------------------------------------ step-invariant conditioning

@@ -184,6 +184,21 @@ int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, vo
  * of the three or four eager passes.  residual may be NULL; relu != 0 applies max(., 0). */
 int ehm_bias_act(float* y, const float* bias, const float* residual, int64_t n, int C, int HW, int relu, void* stream);
 
+/* NHWC convolution + bias (+ identity) + ReLU as an implicit GEMM on the f16 matrix cores with f32-grade accuracy (hi/lo split
+ * operands, f32 accumulate): y[n,ho,wo,co] = act(sum x[n, ho*s-p+kh, wo*s-p+kw, ci] w[co,kh,kw,ci] + bias[co] (+ residual)).
+ * Stands in for torchvision's Bottleneck conv1/conv2/conv3/downsample + BatchNorm(eval, folded by the caller) + ReLU of the
+ * ResNet-50 backbone (models/egohmr/egohmr.py:183).
+ *   x [N,H,W,Ci] float32, Ci % 32 == 0;   y [N,Ho,Wo,Co] float32, Co % 8 == 0;   residual NULL or like y;   bias NULL or [Co]
+ *   W: the weights as [Co_pad][KH*KW*Ci] (tap-major: k = (kh*KW + kw)*Ci + ci), Co_pad = Co rounded up to 128 with zero rows,
+ *      multiplied by w_scale (a power of two) and packed with ehm_split_pack(..., K, K, w_scale, ...);  KH*KW <= 32 */
+typedef struct ehm_conv_desc {
+  const float* x; const void* W; const float* bias; const float* residual; float* y;
+  int N, H, Wd, Ci, Co;
+  int KH, KW, stride, pad, relu;
+  float w_scale;
+} ehm_conv_desc;
+int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream);
+
 /* ------------------------------------------------------------------ sampler steps ------------- */
 /* diffusion/gaussian_diffusion.py:217-220 + :333-336 (p_sample) and :378-385 (p_sample_with_grad):
  *   mean = coef1*x0 + coef2*x  [+ grad_scale * grad]

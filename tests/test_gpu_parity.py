@@ -362,3 +362,30 @@ def test_pointnet_vs_oracle(dev, model, synth_weights, B, N):
     err = (out.cpu().double() - ref).abs().max().item()
     print(f"[pointnet B={B} N={N}] max|err| vs fp64 oracle = {err:.3e} (|feat|max = {ref.abs().max().item():.2f})")
     assert err < 2e-5
+
+
+# --------------------------------------------------------------------------------------------- ResNet-50 backbone
+@pytest.mark.gpu
+@pytest.mark.parametrize("matrix_core", [True, False])
+def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, matrix_core):
+    """The BatchNorm-folded backbone (split-f16 implicit-GEMM convs of csrc/conv.hip, or library convs + ehm_bias_act) against the
+    reference's own ResNet-50 output (G6, generated by oracle/make_golden.py from models/egohmr/egohmr.py's backbone)."""
+    from egohmr_amd import synthetic as syn
+    from egohmr_amd.encoders import ResNet50Features
+    g = np.load(os.path.join(golden_dir, "g6_resnet50.npz"))
+    sd = syn.make_state_dict(seed=int(g["weight_seed"]))
+    net = ResNet50Features()
+    net.load_state_dict({k[len("backbone."):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if k.startswith("backbone.")})
+    net = net.to(dev).eval()
+    rng = np.random.Generator(np.random.PCG64(int(g["img_seed"])))
+    rng.uniform(-1, 1, size=(2, 257, 3))          # same stream position as the generator script
+    img = torch.from_numpy(rng.normal(size=(2, 3, 224, 224)).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        out = net.folded(channels_last=False, matrix_core=matrix_core)(img)
+    np.testing.assert_allclose(out.cpu().numpy(), g["feat"], atol=3e-5)
+    # ragged row count (M = 3*56*56 ... 3*7*7 is not a multiple of the 128-row tile) and batch consistency
+    img3 = torch.cat([img, img[:1]], 0)
+    with torch.no_grad():
+        out3 = net.folded(channels_last=False, matrix_core=matrix_core)(img3)
+    np.testing.assert_allclose(out3[:2].cpu().numpy(), out.cpu().numpy(), atol=5e-6)   # the library convs pick batch-dependent algorithms
+    np.testing.assert_allclose(out3[2].cpu().numpy(), out[0].cpu().numpy(), atol=5e-6)

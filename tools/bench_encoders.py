@@ -34,8 +34,11 @@ with torch.no_grad():
     t, _ = timeit(lambda: m.scene_enc(pts))
     print(f"pointnet (HIP split-f16)      : {t:7.2f} ms")
     if hasattr(m.backbone, "fold_batchnorm"):
+        fb = m.backbone.folded(channels_last=False, matrix_core=True)
+        t, o = timeit(lambda: fb(img))
+        print(f"resnet50 split-f16 implicit GEMM : {t:7.2f} ms   max|d| vs shipped {float((o - ref).abs().max()):.2e}")
         for cl in (False, True):
-            fb = m.backbone.folded(channels_last=cl)
+            fb = m.backbone.folded(channels_last=cl, matrix_core=False)
             t, o = timeit(lambda: fb(img))
             print(f"resnet50 BN-folded cl={cl!s:5s}  : {t:7.2f} ms   max|d| vs shipped {float((o - ref).abs().max()):.2e}")
 

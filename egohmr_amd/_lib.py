@@ -18,7 +18,7 @@ import sys
 import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libegohmr_hip.so")
+LIB_PATH = os.environ.get("EHM_LIB_PATH") or os.path.join(_HERE, "libegohmr_hip.so")   # EHM_LIB_PATH: A/B a second build (experiments)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 SOURCES = ["gcn.hip", "gcn_f16.hip", "gcn_f16p.hip", "gcn_f16r.hip", "linear.hip", "conv.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]

@@ -413,6 +413,39 @@ __global__ __launch_bounds__(192) void gcn_out_mix_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// [S*Aoff | S*I] (rows = output joint, 48 columns: 24 neighbour joints of the off-diagonal branch, then the identity that
+// carries the diagonal branch through the same MFMA) as v_mfma_f32_32x32x16_f16 A fragments: lane l holds row l&31 (zero for
+// rows >= 24), columns 16 s + 8 (l>>5) .. +7 of k-step s; hi and lo halves; S = power of two with max|Aoff| * S in [512, 1024].
+__global__ void pack_aoff_frag_kernel(const float* __restrict__ Aoff, half8* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float amax = 0.f;
+  for (int i = 0; i < kJ * kJ; ++i) amax = fmaxf(amax, fabsf(Aoff[i]));
+  int e = 0;
+  if (amax > 0.f && amax < 3.0e38f) {
+    (void)frexpf(amax, &e);     // amax = m * 2^e, m in [0.5, 1)
+    e = 10 - e;
+    if (e > 15) e = 15;         // S itself is an operand (the identity block): keep it a normal f16
+    if (e < -14) e = -14;
+  }
+  const float S = ldexpf(1.f, e);
+  const int i = lane & 31;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    half8 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int kk = 16 * s + 8 * (lane >> 5) + c;
+      float v = 0.f;
+      if (i < kJ) v = kk < kJ ? Aoff[i * kJ + kk] * S : (kk - kJ == i ? S : 0.f);
+      hi[c] = (half_t)v;
+      lo[c] = (half_t)(v - (float)hi[c]);
+    }
+    out[(2 * s + 0) * 64 + lane] = hi;
+    out[(2 * s + 1) * 64 + lane] = lo;
+  }
+  if (lane == 0) ((float*)(out + 6 * 64))[0] = 1.f / S;
+}
+
 static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, float*& cursor, bool with_w, hipStream_t st) {
   const int N = p.out_dim, K = p.in_dim;
   L.K = K;
@@ -432,6 +465,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   L.M1 = cursor;     cursor += (size_t)kJ * N;
   L.shift = cursor;  cursor += N;
   L.Aoff = cursor;   cursor += kJ * kJ;
+  L.AoffF = cursor;  cursor += 1600;
   if (with_w) {
     dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(K, 32), 2);
     hipLaunchKernelGGL(pack_w_kernel, grid, dim3(256), 0, st, p.W, L.Wp, K, N);
@@ -439,6 +473,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   const int threads = 1024;  // block 0 also fills the 24x24 adjacency (576 <= 1024 threads)
   hipLaunchKernelGGL(pack_epilogue_kernel, dim3((unsigned)ceil_div(N, threads)), dim3(threads), 0, st, adj, p, L.D, L.M1,
                      L.shift, L.Aoff);
+  hipLaunchKernelGGL(pack_aoff_frag_kernel, dim3(1), dim3(64), 0, st, L.Aoff, (half8*)L.AoffF);
   EHM_LAUNCH_CHECK();
   if (with_w) {
     // power-of-two weight scale that keeps |W|*scale well inside f16 and pushes the lo parts out of the subnormal range
@@ -487,7 +522,7 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
-  const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ;
+  const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ + 1600;   // + Aoff MFMA fragments (6 KiB) and 1/S
   size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (6 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
                   12 * (size_t)hid_dim + kJ * 6 + kJ * kJ + 8 + 64;
   if (hipMalloc(&g->arena, floats * sizeof(float)) != hipSuccess) {

@@ -23,6 +23,7 @@ struct LayerDev {
   float* M1;     // [24][N]  M[j][n] * scale[n]
   float* shift;  // [N]      (bias - mean) * scale + beta      (bias when no BN)
   float* Aoff;   // [24][24] symmetrised adjacency, zero diagonal
+  const void* AoffF;  // [Aoff*S | S*I] (24 x 48, rows padded to 32) as split-f16 MFMA A fragments [k-step 3][hi/lo][lane 64][8 halves], then float 1/S
   int K, N;
   int relu;
 };

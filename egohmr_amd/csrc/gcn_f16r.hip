@@ -26,6 +26,11 @@ namespace {
 #define EHM_STORE_AUX 0
 #endif
 constexpr int kStoreAux = EHM_STORE_AUX;
+#ifndef EHM_MIX_MFMA
+#define EHM_MIX_MFMA 0   // 1: the 24x24 adjacency mix of the epilogue as split-f16 MFMA with v_permlane32_swap-built operands instead of
+                         // 1152 v_fmac per wave.  Parity-green, but measured neutral (144.5 vs 144.9 ms per DDPM-100 call, A/B in one
+                         // session): the epilogue is bound by load latency behind the other block's DMA stream, not by VALU issue
+#endif
 constexpr int RK = 32;                                        // K per tile
 constexpr int RA_T = 192 * RK, RB_T = 128 * RK, RSTG = RA_T + RB_T;   // floats per stage: 10240 = 40 KiB
 
@@ -247,6 +252,16 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   const int urow = tid >> 3, uc = tid & 7;
   const unsigned int ucolx = (unsigned int)(2 * n_tile + (uc >> 2)) * 128u + (unsigned int)(uc & 3) * 16u;   // X2: 8 hi halves here, 8 lo halves 64 B on
   const unsigned int ucolf = (unsigned int)(64 * n_tile + 8 * uc) * 4u;
+  // The mix's coefficient fragments are requested NOW, behind the last MFMA: an epilogue load queues behind the DMA stream of the
+  // CU's other block and takes 1-3 us to come back (stamps).  (Requesting the residual here as well spills ~25 registers: slower.)
+#if EHM_MIX_MFMA
+  const half8* AF = (const half8*)L.AoffF + lane;
+  const float invS = ((const float*)((const half8*)L.AoffF + 6 * 64))[0];
+  half8 a_hi[3], a_lo[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) { a_hi[s3] = AF[(2 * s3) * 64]; a_lo[s3] = AF[(2 * s3 + 1) * 64]; }
+#endif
+  __builtin_amdgcn_sched_barrier(0);
   f32x2 dp[kJ], gp[kJ];
 #pragma unroll
   for (int j = 0; j < kJ; ++j) {   // fold modulation / BatchNorm scale
@@ -256,14 +271,6 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
     gp[j] = a1 * f32x2{mj[j], mj[j]};
   }
   __builtin_amdgcn_sched_barrier(0);
-  u32x4 rh[6], rl[6];
-  if (RES) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      rh[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx, 0, IN_AUX);
-      rl[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx + 64u, 0, IN_AUX);
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);
   // transposition tile: element (row, ch) at float row*64 + (((ch>>2) ^ ((row>>1)&1)) << 2) + (ch&3).  The XOR keeps the
   // ds_read_b128 of P2 conflict-free (lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} cover 4 rows x 4 of the 8 chunks).
@@ -271,6 +278,67 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   __syncthreads();                                                   // every wave is done reading operand fragments
   STAMP(9);
   float* T = lds;
+#if EHM_MIX_MFMA
+  {
+    // 24x24 adjacency mix on the matrix cores.  Per body: out[j][ch] = sum_k Aoff[j][k] gp[k][ch] + dp[j][ch] = [S Aoff | S I] (24 x 48)
+    // times [gp; dp] (48 x 32 channels), split-f16 (3 MFMA per product), K = 48 = three k-steps.  B fragments: a lane owns, for
+    // ITS channel, all 24 joints of the two bodies of its half-wave, but the MFMA wants lanes 0-31 to carry k-block 2s and lanes 32-63
+    // k-block 2s+1 of ONE body: v_permlane32_swap exchanges the upper half of P (= both lane halves' block 2s) with the lower half
+    // of Q (= block 2s+1), leaving P = body of the lower half-wave, Q = body of the upper one.  The VALU version was 1152 v_fmac
+    // per wave (~4.4 us per tile, measured); this is 36 MFMA + ~400 VALU.
+    const int ch = 32 * wn + mi;
+    const bool relu = L.relu != 0;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int beta = 0; beta < 2; ++beta) {
+      f32x16 dA, dB;                               // body (half-wave 0, beta) and body (half-wave 1, beta)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dA[r] = 0.f; dB[r] = 0.f; }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        half8 ph, pl, qh, ql;                      // own k-blocks 2 s3 (P) and 2 s3 + 1 (Q), hi / lo
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kp = 16 * s3 + e, kq = kp + 8;   // < 24: gp[k], else dp[k - 24]
+          const float vp = kp < kJ ? gp[kp][beta] : dp[kp - kJ][beta];
+          const float vq = kq < kJ ? gp[kq][beta] : dp[kq - kJ][beta];
+          const float cp = fminf(fmaxf(vp, -65504.f), 65504.f), cq = fminf(fmaxf(vq, -65504.f), 65504.f);
+          ph[e] = (half_t)cp; pl[e] = (half_t)(vp - (float)ph[e]);
+          qh[e] = (half_t)cq; ql[e] = (half_t)(vq - (float)qh[e]);
+        }
+        u32x4 Ph = __builtin_bit_cast(u32x4, ph), Pl = __builtin_bit_cast(u32x4, pl);
+        u32x4 Qh = __builtin_bit_cast(u32x4, qh), Ql = __builtin_bit_cast(u32x4, ql);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const auto sh = __builtin_amdgcn_permlane32_swap(Ph[w], Qh[w], false, false);
+          Ph[w] = sh[0]; Qh[w] = sh[1];
+          const auto sl = __builtin_amdgcn_permlane32_swap(Pl[w], Ql[w], false, false);
+          Pl[w] = sl[0]; Ql[w] = sl[1];
+        }
+        const half8 bAh = __builtin_bit_cast(half8, Ph), bAl = __builtin_bit_cast(half8, Pl);
+        const half8 bBh = __builtin_bit_cast(half8, Qh), bBl = __builtin_bit_cast(half8, Ql);
+        dA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[s3], bAh, dA, 0, 0, 0);
+        dB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[s3], bBh, dB, 0, 0, 0);
+        dA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[s3], bAl, dA, 0, 0, 0);
+        dB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[s3], bBl, dB, 0, 0, 0);
+        dA = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[s3], bAh, dA, 0, 0, 0);
+        dB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[s3], bBh, dB, 0, 0, 0);
+      }
+      // D: column = my channel, rows = joints (r&3) + 8 (r>>2) + 4 g (g = lane half; r >> 2 == 3 is padding)
+      float* ta = T + (96 * wm + 24 * beta) * 64;        // body of half-wave 0;   + 48 rows: body of half-wave 1
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        const int j0 = (r & 3) + 8 * (r >> 2);             // + 4 g
+        const int sw = (j0 >> 1) & 1;                       // (row >> 1) & 1 of the transposition tile's swizzle: 4 g, 24 beta, 48, 96 wm leave it
+        float va = dA[r] * invS, vb = dB[r] * invS;
+        if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+        float* t = ta + (j0 + 4 * g) * 64 + (((ch >> 2) ^ sw) << 2) + (ch & 3);
+        t[0] = va;
+        t[48 * 64] = vb;
+      }
+    }
+  }
+#else
   {
     const int ch = 32 * wn + mi;
     const int lrow = 96 * wm + 48 * g;                               // body a = rows lrow.., body b = lrow + 24..; (row>>1)&1 == (j>>1)&1
@@ -281,6 +349,16 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
       t[j * 64] = s0;
       t[(24 + j) * 64] = s1;
     });
+  }
+#endif
+  __builtin_amdgcn_sched_barrier(0);     // the mix needs the registers; the residual travels under the LDS writes and the barrier
+  u32x4 rh[6], rl[6];
+  if (RES) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      rh[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx, 0, IN_AUX);
+      rl[i] = __builtin_amdgcn_raw_buffer_load_b128(resB, (urow + 32 * i) * rowbytes + ucolx + 64u, 0, IN_AUX);
+    }
   }
   STAMP(10);
   __syncthreads();
@@ -355,6 +433,7 @@ struct ChainArgs {
   unsigned int* err;        // set when a wait timed out (results invalid)
   int flags;                // bit 0 = agent acquire fence after the wait (needed only when the loads are not sc1)
   int nq;                   // queues = XCDs
+  int stagger_ticks;        // experiment (EHM_CHAIN_STAGGER, 100 MHz ticks): delay of the upper half of the grid at start
 };
 
 template <int PASSES, int AUX, int IN_AUX>
@@ -366,6 +445,10 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
   if (cm <= 0) return;
   const unsigned int ipl = (unsigned int)(cm * a.n_tiles), total = ipl * (unsigned int)a.nl;
   volatile unsigned int* slot = (volatile unsigned int*)lds;
+  if (a.stagger_ticks > 0 && blockIdx.x >= gridDim.x / 2) {   // experiment: start the second block of every CU half a tile late
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+  }
   if (tid == 0) slot[0] = __hip_atomic_fetch_add(&a.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   unsigned int t = __builtin_amdgcn_readfirstlane(slot[0]);
@@ -477,6 +560,7 @@ int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad,
   if (a.nq > 8) a.nq = 8;
   const int mode = getenv("EHM_CHAIN_MODE") ? atoi(getenv("EHM_CHAIN_MODE")) : 0;   // 0 = sc1 loads (default), 1 = plain loads + acquire fence, 2 = neither (timing experiment only)
   a.flags = mode == 1 ? 1 : 0;
+  a.stagger_ticks = getenv("EHM_CHAIN_STAGGER") ? atoi(getenv("EHM_CHAIN_STAGGER")) : 0;
   if (h->precision == EHM_PREC_F16X3) {
     if (mode == 0) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 16>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 0>), dim3(blocks), dim3(256), 0, st, a);

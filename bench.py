@@ -189,23 +189,41 @@ def main():
     assert torch.isfinite(res["other_outputs"]["pred_vertices"]).all()
     assert gathered.shape == (world * B, edist.PACKED_WIDTH)
 
-    # reference leg: the same job with the hidden convs on the f32-input MFMA (exact f32 products), one call, rank-local
-    f32_leg = None
-    if args.precision != "f32" and world == 1:
-        model.gcn_precision = "f32"
-        one_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        one_step()
-        torch.cuda.synchronize()
-        f32_dt = time.perf_counter() - t1
-        kd, _ = time_dominant_kernel(model, B, 2)
+    # comparison legs (rank-local, N=1 only): the same job, same noise, with the hidden convs (a) on the f32-input MFMA (exact f32
+    # products) and (b) on plain f16 operands (one MFMA per product - the "fp16 denoiser" of BASELINE config 5; NOT parity-grade),
+    # each with its distance to the default path's vertices / joints
+    f32_leg = f16_leg = None
+    if args.precision == "f16x3" and world == 1:
+        ref_v = res["other_outputs"]["pred_vertices"].float().clone()
+        ref_j = res["other_outputs"]["pred_keypoints_3d"].float().clone() if "pred_keypoints_3d" in res["other_outputs"] else None
+
+        def leg(prec):
+            model.gcn_precision = prec
+            one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, r = one_step()
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t1
+            kd, _ = time_dominant_kernel(model, B, 2)
+            v = r["other_outputs"]["pred_vertices"].float()
+            dv = (v - ref_v).norm(dim=-1)                                  # per-vertex distance [B, V], metres
+            o = {"value": B / d, "unit": "bodies/s", "ms_per_step": d * 1e3, "hidden_conv_avg_launch_ms": kd * 1e3,
+                 "vs_default_path": {"max_vertex_dist_mm": float(dv.max()) * 1e3, "mean_v2v_mm": float(dv.mean()) * 1e3}}
+            if ref_j is not None:
+                o["vs_default_path"]["mpjpe_mm"] = float((r["other_outputs"]["pred_keypoints_3d"].float() - ref_j).norm(dim=-1).mean()) * 1e3
+            model.gcn_precision = args.precision
+            return o, kd
+
+        f32_leg, kd = leg("f32")
         fl = hidden_layer_flops(2 * B, model.diffusion_model.hid_dim)
-        f32_leg = {"value": B / f32_dt, "unit": "bodies/s", "ms_per_step": f32_dt * 1e3,
-                   "roofline": {"bound": "mfma", "kernel": "gcn_hidden_kernel (f32-input MFMA)", "achieved": fl / kd / 1e12,
-                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / kd / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                "avg_launch_ms": kd * 1e3}}
-        model.gcn_precision = args.precision
+        f32_leg["roofline"] = {"bound": "mfma", "kernel": "gcn_hidden_kernel (f32-input MFMA)", "achieved": fl / kd / 1e12,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / kd / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                               "avg_launch_ms": kd * 1e3}
+        f16_leg, kd = leg("f16")
+        f16_leg["note"] = "plain f16 operands in the hidden convs (f32 accumulate, everything else f32): reported for BASELINE config 5, not the parity path"
+        f16_leg["roofline"] = {"bound": "mfma", "achieved": fl / kd / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl / kd / 1e12 / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": kd * 1e3}
 
     # split of one call (rank 0, informative)
     torch.cuda.synchronize()
@@ -252,6 +270,7 @@ def main():
                              "hidden_convs_est": k_dur * 1e3 * 2 * model.diffusion_model.num_layers * T},
         }
         out["f32_mfma_path"] = f32_leg
+        out["f16_denoiser_path"] = f16_leg
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, rs, N, args.cpu_seconds)
         else:

@@ -75,13 +75,12 @@ def time_dominant_kernel(model, B, passes, reps=5):
     s = _lib.stream_ptr()
 
     X0 = X.clone()
+    import ctypes as C
+    bufs = (C.c_void_p * 3)(X.data_ptr(), Y1.data_ptr(), Y2.data_ptr())
+    res = C.c_int(0)
 
-    def sweep():
-        x, y1, y2 = X, Y1, Y2
-        for l in range(0, nl, 2):
-            _lib.check(L.ehm_gcn_hidden_layer(h, l, x.data_ptr(), None, y1.data_ptr(), rows_pad, s))
-            _lib.check(L.ehm_gcn_hidden_layer(h, l + 1, y1.data_ptr(), x.data_ptr(), y2.data_ptr(), rows_pad, s))
-            x, y2 = y2, x
+    def sweep():    # the sampler's own call: all hidden convs of one GCN forward (one chained launch on the split-f16 path)
+        _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), s))
 
     sweep()
     torch.cuda.synchronize()
@@ -241,8 +240,8 @@ def main():
         achieved = flops / k_dur / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
         kname = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue)",
-                 "f16x3": "gcn_hidden_f16r_kernel<3> (split-f16 MFMA, 3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue)",
-                 "f16": "gcn_hidden_f16r_kernel<1> (plain f16 MFMA, f32 accumulate, same fused epilogue)"}[args.precision]
+                 "f16x3": "gcn_hidden_chain_kernel<3> = 8 chained hidden convs per launch, tile code of gcn_hidden_f16r_kernel (split-f16 MFMA, 3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue); avg_launch_ms is per conv",
+                 "f16": "gcn_hidden_chain_kernel<1> (plain f16 MFMA, f32 accumulate, same fused epilogue); avg_launch_ms is per conv"}[args.precision]
         out = {
             "metric": "sampled bodies/sec (100-step DDPM, batch 256)" if args.workload == "ddpm100" else f"sampled bodies/sec ({args.workload})",
             "value": world * B * args.steps / dt,

@@ -183,10 +183,22 @@ class GaussianDiffusion:
         if noise is None:
             noise = th.randn_like(xc)                                                 # :331 / :547 (drawn even at t == 0)
         noise = _lib.f32(noise, x.device)
-        c = self.step_coefs(i, ddim, eta, cond_grad_weight, guided)
+        c = self.step_coefs(i, ddim, eta, cond_grad_weight, guided and not ddim)
         grad = None
         if c.grad_scale != 0.0:
             grad = _lib.f32(model.guide_coll(batch, mo, t, compute_grad="x_t"), x.device)   # :379
+        if ddim and guided and i <= 3:
+            # ddim_sample_with_grad, gaussian_diffusion.py:580-592: on the last four respaced steps the collision gradient is
+            # subtracted from eps (scale 1.0) and x0 re-derived from it; the plain DDIM update then runs on that x0.  The
+            # reference's float32 scalar broadcasts (`_extract_into_tensor`) are mirrored with float32 tensors.
+            g = _lib.f32(model.guide_coll(batch, mo, t, compute_grad="x_t"), x.device)       # :584
+            f = lambda v: th.tensor(v, dtype=th.float64).float().to(x.device)
+            ab, sr, srm1 = f(self.alphas_cumprod[i]), f(self.sqrt_recip_alphas_cumprod[i]), f(self.sqrt_recipm1_alphas_cumprod[i])
+            eps = (sr * xc - x0) / srm1                                                      # :582
+            eps = eps - (1 - ab).sqrt() * g * 1.0                                            # :585-586
+            x0 = (sr * xc - srm1 * eps).contiguous()                                         # :587
+            mo = dict(mo)
+            mo["pred_x_start_guided"] = x0
         out = th.empty_like(xc)
         L, n, st = _lib.lib(), xc.numel(), _lib.stream_ptr()
         if ddim:
@@ -195,7 +207,7 @@ class GaussianDiffusion:
         else:
             _lib.check(L.ehm_ddpm_step(_lib.ptr(xc), _lib.ptr(x0), _lib.ptr(noise), _lib.ptr(grad), _lib.ptr(out), c.coef1, c.coef2,
                                        c.log_variance, c.nonzero, c.grad_scale, n, st), "ehm_ddpm_step")
-        return {"sample": out, "pred_xstart": mo["pred_x_start"], "other_outputs": mo}
+        return {"sample": out, "pred_xstart": mo.get("pred_x_start_guided", mo["pred_x_start"]), "other_outputs": mo}
 
     def p_sample(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, cond_grad_weight=0.0, noise=None):
         return self._step(model, batch, x, t, False, False, cond_grad_weight, 0.0, noise)
@@ -206,9 +218,10 @@ class GaussianDiffusion:
     def ddim_sample(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, eta=0.0, noise=None):
         return self._step(model, batch, x, t, True, False, 0.0, eta, noise)
 
-    def ddim_sample_with_grad(self, *a, **k):
-        raise NotImplementedError("ddim_sample_with_grad (gaussian_diffusion.py:559-614) is flagged 'does not work well' by the "
-                                  "reference (:579) and is not part of the MI355X path; use the DDPM sampler for guided sampling")
+    def ddim_sample_with_grad(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, eta=0.0, noise=None):
+        """gaussian_diffusion.py:559-614 (the reference notes at :579 that DDIM "does not work well" with the collision guidance;
+        built for completeness of the call surface, generic route only)."""
+        return self._step(model, batch, x, t, True, True, 1.0, eta, noise)
 
     # ------------------------------------------------------------------ loops
     def _device_of(self, model, device):
@@ -235,8 +248,6 @@ class GaussianDiffusion:
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
-        if ddim and cond_fn_with_grad:
-            self.ddim_sample_with_grad()
         for k, i in enumerate(indices):
             t = th.tensor([i] * shape[0], device=device)                              # :495
             with th.no_grad():

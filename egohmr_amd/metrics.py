@@ -90,3 +90,28 @@ def pa_mpjpe(pred_joints: torch.Tensor, gt_joints: torch.Tensor) -> torch.Tensor
 def std_diversity(pred_joints_aligned: torch.Tensor) -> torch.Tensor:
     """test_egohmr.py:453-455: std over the sample axis of [B,S,24,3], averaged over joints and coordinates."""
     return torch.std(pred_joints_aligned, dim=1, unbiased=True).mean(dim=-1).mean(dim=-1)
+
+
+def _masked_rows(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """[B,S,J,3] with a [B,J] bool mask -> the same tensor with unselected joints zeroed, plus the counts [B]."""
+    return x * mask[:, None, :, None].to(x.dtype)
+
+
+def std_diversity_masked(pred_joints_aligned: torch.Tensor, joint_mask: torch.Tensor) -> torch.Tensor:
+    """test_egohmr.py:457-470 (std-joints-vis / -invis): the per-item loop `pred[k, :, mask[k]]` batched - std over samples,
+    mean over the selected joints and the 3 coordinates.  Items without a selected joint give NaN like the reference."""
+    sd = torch.std(pred_joints_aligned, dim=1, unbiased=True).mean(dim=-1)            # [B,J]
+    m = joint_mask.to(sd.dtype)
+    return (sd * m).sum(dim=-1) / m.sum(dim=-1)                                       # 0/0 -> nan
+
+
+def apd_diversity(pred_joints_aligned: torch.Tensor, joint_mask: torch.Tensor | None = None) -> torch.Tensor:
+    """test_egohmr.py:471-494 (apd-joints, -vis, -invis): sum over ordered sample pairs and (selected) joints of the joint
+    distance, divided by n_joints * S * (S-1) * 2 - the reference's normalisation, kept as is."""
+    a = pred_joints_aligned
+    S = a.shape[1]
+    d = (a[:, None] - a[:, :, None]).norm(dim=-1)                                      # [B,S,S,J]
+    if joint_mask is None:
+        return d.sum(dim=(-1, -2, -3)) / a.shape[-2] / S / (S - 1) / 2
+    m = joint_mask.to(d.dtype)
+    return (d * m[:, None, None, :]).sum(dim=(-1, -2, -3)) / m.sum(dim=-1) / S / (S - 1) / 2

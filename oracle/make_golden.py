@@ -293,12 +293,19 @@ def g10_forward(model_fuse, model_nofuse):
     save("g10_forward", batch_seed=21, num_scene_points=512, **arrs)
 
 
-def g8_g9_end_to_end(model):
+E2E_CASES = [("g8_e2e_ddim5", 50, "ddim5", 4, 4096, False, 0.0),
+             ("g9_e2e_ddpm50", 50, "", 2, 1024, False, 0.0),
+             ("g9_e2e_ddpm50_guided", 50, "", 2, 1024, True, 2.0),
+             # ddim_sample_with_grad (gaussian_diffusion.py:559-614): guidance enters through eps on the last four respaced steps
+             ("g12_e2e_ddim10_guided", 50, "ddim10", 2, 1024, True, 1.0)]
+
+
+def g8_g9_end_to_end(model, only=None):
     from diffusion.model_util import create_gaussian_diffusion
     # G8: BASELINE config 1 - B=4, DDIM-5 of 50, N=4096
-    for name, n, rs, B, N, guided, w in [("g8_e2e_ddim5", 50, "ddim5", 4, 4096, False, 0.0),
-                                         ("g9_e2e_ddpm50", 50, "", 2, 1024, False, 0.0),
-                                         ("g9_e2e_ddpm50_guided", 50, "", 2, 1024, True, 2.0)]:
+    for name, n, rs, B, N, guided, w in E2E_CASES:
+        if only is not None and name not in only:
+            continue
         d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
         b = to_torch_batch(syn.make_batch(B, num_scene_points=N, seed=31))
         if guided:  # put the scene floor through the body so the proxy has something to push against
@@ -337,6 +344,11 @@ def main():
     asset = syn.make_smpl_asset(0)
     install_shims(asset)
     print("reference-driven goldens ->", OUT)
+    if os.environ.get("GOLDEN_ONLY") == "g12":
+        sd = syn.make_state_dict(0)
+        mean, std = syn.make_body_rep_stats(0)
+        g8_g9_end_to_end(build_reference_model(sd, asset, mean, std, diffuse_fuse=True), only=("g12_e2e_ddim10_guided",))
+        return
     g1_schedules()
     g2_g3_geometry()
     g4_gcn()
@@ -348,6 +360,9 @@ def main():
     mean, std = syn.make_body_rep_stats(0)
     model = build_reference_model(sd, asset, mean, std, diffuse_fuse=True)
     model_nofuse = build_reference_model(sd, asset, mean, std, diffuse_fuse=False)
+    if os.environ.get("GOLDEN_ONLY") == "g12":
+        g8_g9_end_to_end(model, only=("g12_e2e_ddim10_guided",))
+        return
     g5_g6_small_modules(model, sd)
     g10_forward(model, model_nofuse)
     g8_g9_end_to_end(model)

@@ -54,8 +54,11 @@ def p_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, cond_fn_wit
     return out
 
 
-def ddim_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, eta: float = 0.0, trace=None):
-    """gaussian_diffusion.py:618-718 with ddim_sample :511-556."""
+def ddim_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, eta: float = 0.0, trace=None, cond_fn_with_grad=False,
+                     guide_reduction="mean"):
+    """gaussian_diffusion.py:618-718 with ddim_sample :511-556, or ddim_sample_with_grad :559-614 when cond_fn_with_grad
+    (the loop picks it at :700-703): on the last four respaced steps (t <= 3) the collision gradient is subtracted from eps,
+    x0 is re-derived from that eps, and the plain DDIM update continues from there."""
     dt = noise.dtype
     x = noise[0]
     B = x.shape[0]
@@ -67,6 +70,12 @@ def ddim_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, eta: flo
         with torch.no_grad():
             mo = model(batch, t_model)
         x0 = mo["pred_x_start"]
+        if cond_fn_with_grad and i <= 3:                                               # :580 (respaced index)
+            ab_ = _coef(tables.alphas_cumprod, i, dt)
+            eps_ = (_coef(tables.sqrt_recip_alphas_cumprod, i, dt) * x - x0) / _coef(tables.sqrt_recipm1_alphas_cumprod, i, dt)
+            g, _ = model.guide_coll(batch, mo, t_model, compute_grad="x_t", reduction=guide_reduction)   # :584
+            eps_ = eps_ - (1 - ab_).sqrt() * g.to(dt) * 1.0                            # :585-586, scale = 1.0
+            x0 = _coef(tables.sqrt_recip_alphas_cumprod, i, dt) * x - _coef(tables.sqrt_recipm1_alphas_cumprod, i, dt) * eps_   # :587
         eps = (_coef(tables.sqrt_recip_alphas_cumprod, i, dt) * x - x0) / _coef(tables.sqrt_recipm1_alphas_cumprod, i, dt)  # :286-290
         ab = _coef(tables.alphas_cumprod, i, dt)
         abp = _coef(tables.alphas_cumprod_prev, i, dt)
@@ -87,7 +96,7 @@ def val_losses(model, batch, tables: Tables, noise, timestep_respacing="", cond_
     if timestep_respacing == "":
         o = p_sample_loop(model, batch, tables, noise, cond_fn_with_grad, cond_grad_weight, guide_reduction, trace)
     elif timestep_respacing[0:4] == "ddim":
-        o = ddim_sample_loop(model, batch, tables, noise, 0.0, trace)
+        o = ddim_sample_loop(model, batch, tables, noise, 0.0, trace, cond_fn_with_grad, guide_reduction)
     else:
         raise SystemExit("timestep_respacing_eval not setup correctly")                # :774-775
     return o["other_outputs"]

@@ -155,3 +155,30 @@ def test_guided_ddpm_vs_reference_golden(golden_dir, dev, model, route):
     np.testing.assert_allclose(c(o["pred_x_start"]), g["pred_x_start"], atol=2e-4)
     np.testing.assert_allclose(c(o["pred_vertices"][:, :64]), g["verts_head"], atol=1e-4)
     np.testing.assert_allclose(c(o["pred_keypoints_3d"]), g["joints"], atol=1e-4)
+
+
+def test_guided_ddim_vs_reference_golden(golden_dir, dev, model):
+    """ddim_sample_with_grad (gaussian_diffusion.py:559-614: collision gradient through eps on the last four respaced steps)
+    against the reference's own run, golden g12; and `val_losses(..., 'ddim10', cond_fn_with_grad=True)` routes to it."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device
+    g = np.load(os.path.join(golden_dir, "g12_e2e_ddim10_guided.npz"))
+    B, N, n, rs = int(g["B"]), int(g["N"]), int(g["n"]), str(g["respacing"])
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+    bnp = syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"]))
+    bnp["scene_pcd_verts_full"][:, : N // 3, 1] = bnp["smpl_params"]["transl"][:, None, 1] - 0.6
+    b = batch_to_device(bnp, dev)
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=int(g["noise_seed"]))).to(dev)
+    xs = [noise[0].cpu().numpy()]
+    for out in d.ddim_sample_loop_progressive(model, b, [B, 144], cond_fn_with_grad=True, noise_stack=noise):
+        xs.append(out["sample"].cpu().numpy())
+    np.testing.assert_allclose(np.stack(xs[:-1]), g["x_t_trace"], atol=2e-4)
+    o = d.val_losses(model, b, shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False,
+                     cond_fn_with_grad=True, noise_stack=noise)
+    c = lambda t: t.detach().cpu().numpy()
+    np.testing.assert_allclose(c(o["pred_x_start"]), g["pred_x_start"], atol=2e-4)
+    np.testing.assert_allclose(c(o["pred_vertices"][:, :64]), g["verts_head"], atol=1e-4)
+    np.testing.assert_allclose(c(o["pred_keypoints_3d"]), g["joints"], atol=1e-4)
+    # the guidance was live on the last steps only
+    xs0 = [out["sample"].cpu().numpy() for out in d.ddim_sample_loop_progressive(model, b, [B, 144], cond_fn_with_grad=False, noise_stack=noise)]
+    assert np.abs(xs0[-1] - xs[-1]).max() > 2e-5 and np.abs(xs0[5] - xs[6]).max() == 0.0

@@ -65,3 +65,82 @@ def test_mpjpe_v2v_formulas():
     assert torch.allclose(metrics.mpjpe(p + 5.0, q), ref, atol=1e-5)       # translation invariant (pelvis aligned)
     assert torch.allclose(metrics.g_mpjpe(p, p), torch.zeros(4, 3, device=dev))
     assert metrics.std_diversity(p[..., :24, :]).shape == (4,)
+
+
+def test_diversity_metrics_match_reference_loops():
+    """std / apd diversity incl. the visible / invisible joint splits against a literal restatement of the per-item numpy
+    loops of test_egohmr.py:453-494."""
+    import numpy as np
+    import torch
+    from egohmr_amd import metrics
+    g = np.random.Generator(np.random.PCG64(7))
+    B, S = 5, 4
+    a = g.normal(size=(B, S, 24, 3)).astype(np.float32)
+    mask = g.random((B, 24)) < 0.6
+    mask[0] = True            # nothing invisible for item 0 -> NaN in the invisible split, like the reference
+    t, m = torch.from_numpy(a), torch.from_numpy(mask)
+    # reference-style loops
+    std_all = a.std(axis=1, ddof=1).mean(-1).mean(-1)
+    pd = np.linalg.norm(a[:, None] - a[:, :, None], axis=-1)
+    apd_all = pd.sum(axis=(-1, -2, -3)) / 24 / S / (S - 1) / 2
+    np.testing.assert_allclose(metrics.std_diversity(t).numpy(), std_all, rtol=1e-5)
+    np.testing.assert_allclose(metrics.apd_diversity(t).numpy(), apd_all, rtol=1e-5)
+    for sel in (mask, ~mask):
+        std_ref, apd_ref = [], []
+        for k in range(B):
+            tmp = a[k][:, sel[k]]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                std_ref.append(tmp.std(axis=0, ddof=1).mean(-1).mean(-1) if tmp.shape[1] else np.nan)
+                d = np.linalg.norm(tmp[None] - tmp[:, None], axis=-1)
+                apd_ref.append(d.sum() / tmp.shape[-2] / S / (S - 1) / 2 if tmp.shape[1] else np.nan)
+        np.testing.assert_allclose(metrics.std_diversity_masked(t, torch.from_numpy(sel)).numpy(), np.array(std_ref, np.float32), rtol=1e-5)
+        np.testing.assert_allclose(metrics.apd_diversity(t, torch.from_numpy(sel)).numpy(), np.array(apd_ref, np.float32), rtol=1e-5)
+
+
+def test_results_wire_format_roundtrip(tmp_path):
+    """results_seed_*.pkl: the reference's keys, numpy payloads, pickle protocol 2 (test_egohmr.py:672-695); stage-1 cam file;
+    preprocess stats / mean-params loaders and their shape checks."""
+    import pickle
+    import numpy as np
+    import pytest
+    import torch
+    from egohmr_amd import io as eio
+    n, S = 6, 3
+    g = np.random.Generator(np.random.PCG64(3))
+    res = eio.results_dict(torch.from_numpy(g.normal(size=(n, S, 10)).astype(np.float32)), g.normal(size=(n, S, 1, 3, 3)).astype(np.float32),
+                           g.normal(size=(n, S, 23, 3, 3)).astype(np.float32), g.random((n, S)), g.random((n, S)),
+                           g.normal(size=(n, 3)).astype(np.float32))
+    assert list(res.keys()) == ["pred_betas_list", "pred_global_orient_list", "pred_body_pose_list", "collision_ratio_list",
+                                "contact_ratio_list", "gt_cam_full_list"]
+    path = eio.save_results(str(tmp_path), "53618", 0, res)
+    assert path.endswith("output_egohmr_53618/results_seed_0.pkl")
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"\x80\x02"                               # protocol 2 header
+    back = eio.load_results(path)
+    for k, v in res.items():
+        assert isinstance(back[k], np.ndarray)
+        np.testing.assert_array_equal(back[k], v)
+    with pytest.raises(KeyError):
+        eio.save_results(str(tmp_path), "x", 1, {"pred_betas_list": res["pred_betas_list"]})
+    # two-stage: the stage-1 file and the extra key
+    s1 = tmp_path / "results.pkl"
+    with open(s1, "wb") as f:
+        pickle.dump({"pred_cam_full_list": g.normal(size=(n, 3))}, f, protocol=2)
+    cam = eio.load_stage1_cam(str(s1))
+    assert cam.shape == (n, 3) and cam.dtype == np.float32
+    res2 = eio.results_dict(res["pred_betas_list"], res["pred_global_orient_list"], res["pred_body_pose_list"], res["collision_ratio_list"],
+                            res["contact_ratio_list"], res["gt_cam_full_list"], pred_cam_full=cam)
+    assert list(res2.keys())[-2:] == ["pred_cam_full_list", "gt_cam_full_list"]   # the reference's insertion order
+    with open(tmp_path / "bad.pkl", "wb") as f:
+        pickle.dump({"something": 1}, f, protocol=2)
+    with pytest.raises(KeyError):
+        eio.load_stage1_cam(str(tmp_path / "bad.pkl"))
+    # statistics files
+    np.savez(tmp_path / "preprocess_stats.npz", Xmean=np.arange(144, dtype=np.float64), Xstd=np.ones(144))
+    mean, std = eio.load_preprocess_stats(str(tmp_path / "preprocess_stats.npz"))
+    assert mean.dtype == np.float32 and mean.shape == (144,) and std.shape == (144,)
+    np.savez(tmp_path / "smpl_mean_params.npz", shape=np.arange(10, dtype=np.float64), pose=np.zeros(144), cam=np.zeros(3))
+    assert eio.load_smpl_mean_params(str(tmp_path / "smpl_mean_params.npz")).shape == (1, 10)
+    np.savez(tmp_path / "short.npz", Xmean=np.zeros(10), Xstd=np.zeros(10))
+    with pytest.raises(ValueError):
+        eio.load_preprocess_stats(str(tmp_path / "short.npz"))

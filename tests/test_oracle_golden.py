@@ -145,7 +145,7 @@ def test_g10_forward(golden_dir, synth_weights, smpl_asset):
         np.testing.assert_array_equal(tb["vis_mask_smpl"].numpy(), g[tag + "vis_mask_smpl"])
 
 
-@pytest.mark.parametrize("name", ["g8_e2e_ddim5", "g9_e2e_ddpm50", "g9_e2e_ddpm50_guided"])
+@pytest.mark.parametrize("name", ["g8_e2e_ddim5", "g9_e2e_ddpm50", "g9_e2e_ddpm50_guided", "g12_e2e_ddim10_guided"])
 @pytest.mark.parametrize("faithful", [True, False])
 def test_g8_g9_end_to_end(golden_dir, synth_weights, smpl_asset, name, faithful):
     if faithful and name != "g8_e2e_ddim5":
@@ -164,3 +164,8 @@ def test_g8_g9_end_to_end(golden_dir, synth_weights, smpl_asset, name, faithful)
     xs = np.stack([noise[0].numpy()] + [t[0].numpy() for t in tr[:-1]])
     np.testing.assert_allclose(xs, g["x_t_trace"], atol=2e-5)
     _check_out(o, g)
+    if name == "g12_e2e_ddim10_guided":       # the guidance must have been live: the unguided trajectory differs on the last steps
+        tr0 = []
+        sampler.val_losses(m, b, tab, noise, rs, cond_fn_with_grad=False, trace=tr0)
+        assert float((tr0[-1][0] - tr[-1][0]).abs().max()) > 2e-5   # (small: scale 1.0 x sqrt(1 - abar) on the last steps)
+        assert float((tr0[5][0] - tr[5][0]).abs().max()) == 0.0   # ... and only there (t <= 3 of 10)

@@ -263,6 +263,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "mfma_flops_per_algorithmic_flop": 3 if args.precision == "f16x3" else 1,
+                         "issued_mfma_frac": achieved * (3 if args.precision == "f16x3" else 1) / peak,   # MFMA work actually issued / peak
                          "traffic": pmc_traffic(args.precision), "avg_launch_ms": k_dur * 1e3, "flops_per_launch": flops,
                          "formula": "virtual_bodies*(24*2*hid^2 + 24*24*hid)*2, virtual_bodies = passes*B (SURVEY 8d, hoisted)"},
             "breakdown_ms": {"encoders_and_projections_once": t_enc * 1e3, "per_call_total": dt / args.steps * 1e3,

@@ -23,7 +23,6 @@ namespace {
 #define AS3 __attribute__((address_space(3)))
 
 constexpr int PK = 16;                       // K per pipeline stage
-constexpr int NST = 4;                       // stages
 constexpr int PA_T = 192 * PK, PB_T = 128 * PK, PSTG = PA_T + PB_T;   // floats per stage: 5120 = 20 KiB
 
 template <int N>
@@ -33,8 +32,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
 
-template <int PASSES, bool RES, bool OUT_SPLIT>
-__global__ __launch_bounds__(256, 2) void gcn_hidden_f16p_kernel(const half_t* __restrict__ X, LayerDev L,
+template <int PASSES, bool RES, bool OUT_SPLIT, int NST, int OCC>
+__global__ __launch_bounds__(256, OCC) void gcn_hidden_f16p_kernel(const half_t* __restrict__ X, LayerDev L,
                                                                   const half_t* __restrict__ Res, float* __restrict__ Y,
                                                                   int m_tiles) {
   __shared__ __attribute__((aligned(16))) float lds[NST * PSTG];   // 80 KiB, the only LDS object
@@ -60,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16p_kernel(const half_t* _
   const float* pB = (const float*)L.Ws16 + ((size_t)n_tile * 128 + 16 * wave + ld_r) * K + swz;
   const size_t row64 = (size_t)64 * K;                                // 4 waves x 16 rows between a wave's consecutive instructions
   auto stage = [&](int kt) {
-    float* base = lds + (kt & (NST - 1)) * PSTG;
+    float* base = lds + (kt % NST) * PSTG;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row64 + kt * PK), (AS3 void*)(base + (wave + 4 * i) * 256), 16, 0, 0);
@@ -85,17 +84,21 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16p_kernel(const half_t* _
 
   const int KT = K / PK;
   stage(0);
-  stage(1);
-  stage(2);
+  if (NST == 4) { stage(1); stage(2); }
   for (int kt = 0; kt < KT; ++kt) {
-    // my DMA of tile kt has landed (two younger tiles = 10 instructions may still fly; fewer at the tail)
-    if (kt + 2 < KT) wait_vmcnt<10>();
-    else if (kt + 1 < KT) wait_vmcnt<5>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                      // everyone's tile kt is in LDS; everyone left stage (kt-1)%4
+    if (NST == 4) {
+      // my DMA of tile kt has landed (two younger tiles = 10 instructions may still fly; fewer at the tail)
+      if (kt + 2 < KT) wait_vmcnt<10>();
+      else if (kt + 1 < KT) wait_vmcnt<5>();
+      else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();                      // everyone's tile kt is in LDS; everyone left stage (kt-1)%NST
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 3 < KT) stage(kt + 3);                    // refills stage (kt-1)%4
-    const float* S = lds + (kt & (NST - 1)) * PSTG;
+    if (NST == 4) { if (kt + 3 < KT) stage(kt + 3); }  // refills stage (kt-1)%4
+    else if (kt + 1 < KT) stage(kt + 1);               // 2 stages (20 KiB each, 3 blocks per CU): refills the stage everyone just left
+    const float* S = lds + (kt % NST) * PSTG;
     half8 ah[3], al[3], bh[2], bl[2];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_f16p_kernel(const half_t* _
   }
 }
 
-template <int PASSES>
+template <int PASSES, int NST, int OCC>
 int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split, hipStream_t st) {
   const int m_tiles = (int)(rows_pad / 192);
   const int blocks = m_tiles * (h->hid / 64);
@@ -162,11 +165,11 @@ int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, voi
   const half_t* r = (const half_t*)residual;
   float* y = (float*)out;
   if (residual) {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, true, true>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, true, false>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, true, true, NST, OCC>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, true, false, NST, OCC>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
   } else {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, false, true>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, false, false>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, false, true, NST, OCC>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16p_kernel<PASSES, false, false, NST, OCC>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -180,6 +183,10 @@ int ehm_gcn_hidden_f16p_impl(const ehm_gcn* h, int layer, const void* X, const v
     ehm_set_error("pipelined split-f16 conv needs hid %% 64 == 0 and K >= 48");
     return EHM_EINVAL;
   }
-  if (h->precision == EHM_PREC_F16X3) return launch<3>(h, layer, X, residual, out, rows_pad, out_split, st);
-  return launch<1>(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (h->tile_override == 3) {   // experiment: 2 stages of 20 KiB, 3 blocks per CU (3 waves per SIMD, <= 168 VGPRs)
+    if (h->precision == EHM_PREC_F16X3) return launch<3, 2, 3>(h, layer, X, residual, out, rows_pad, out_split, st);
+    return launch<1, 2, 3>(h, layer, X, residual, out, rows_pad, out_split, st);
+  }
+  if (h->precision == EHM_PREC_F16X3) return launch<3, 4, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
+  return launch<1, 4, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
 }

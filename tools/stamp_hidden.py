@@ -25,7 +25,10 @@ dbg = torch.zeros(1024 * 16, dtype=torch.int64, device=dev)
 fn = L.ehm_dbg_set
 fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
 assert fn(dbg.data_ptr()) == 0
-_lib.check(L.ehm_gcn_hidden_layer(h, 1, Y1.data_ptr(), X2.data_ptr(), Y2.data_ptr(), rows_pad, None))
+if len(sys.argv) > 2 and sys.argv[2] == "nores":
+    _lib.check(L.ehm_gcn_hidden_layer(h, 0, X2.data_ptr(), None, Y2.data_ptr(), rows_pad, None))
+else:
+    _lib.check(L.ehm_gcn_hidden_layer(h, 1, Y1.data_ptr(), X2.data_ptr(), Y2.data_ptr(), rows_pad, None))
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(1024, 16).astype(np.int64)
 t0 = d[:, 0].min()
@@ -42,4 +45,8 @@ for name, a, b in (("prologue", 4, 5), ("loop", 5, 6), ("epilogue", 6, 7)):
 e = (d[:, 8:12] - t0) / 100.0
 print("epi: loads+fold %.2f  barrier1 %.2f  mix+ldswrite %.2f  barrier2 %.2f  P2 %.2f (means, us)" % ((e[:,0]-rt[:,2]).mean(), (e[:,1]-e[:,0]).mean(), (e[:,2]-e[:,1]).mean(), (e[:,3]-e[:,2]).mean(), (rt[:,3]-e[:,3]).mean()))
 print("epi p50: loads+fold %.2f  barrier1 %.2f  mix+ldswrite %.2f  barrier2 %.2f  P2 %.2f" % (np.median(e[:,0]-rt[:,2]), np.median(e[:,1]-e[:,0]), np.median(e[:,2]-e[:,1]), np.median(e[:,3]-e[:,2]), np.median(rt[:,3]-e[:,3])))
+if d[:, 12].any():
+    m = (d[:, 12:16] - t0) / 100.0
+    print("mix detail (means, us): build+mfma b0 %.2f  scale+ldswrite b0 %.2f  build+mfma b1 %.2f  scale+ldswrite b1 %.2f  rest %.2f" % (
+        (m[:, 0] - e[:, 1]).mean(), (m[:, 1] - m[:, 0]).mean(), (m[:, 2] - m[:, 1]).mean(), (m[:, 3] - m[:, 2]).mean(), (e[:, 2] - m[:, 3]).mean()))
 first = rt[:, 0] < 5; print("blocks starting <5us:", first.sum(), " second-round start p50:", np.median(rt[~first, 0]) if (~first).any() else None)

@@ -111,6 +111,7 @@ PROTOTYPES = {
     "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "ehm_bias_act": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
+    "ehm_nonlocal_attention": (_I, [_P, _P, _L, _I, _P]),
     "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P]),

@@ -193,6 +193,59 @@ __global__ void pack_scaled_kernel(const float* __restrict__ X, half_t* __restri
   split_store(Y, r, k, Kpad, k < K ? X[r * K + k] * scale : 0.f);
 }
 
+// Embedded-Gaussian attention over the 24 joints of one body (NONLocalBlock2D, nets/non_local_embedded_gaussian.py:68-79):
+// qkv [bodies*24, 3*Ci] = [theta | phi | g] rows -> y [bodies*24, Ci] = softmax(theta phi^T) g.  One block per body; the 24 x 24
+// logits are accumulated over 64-channel slabs staged in LDS.  (The block is off in every shipped config: correctness first.)
+__global__ __launch_bounds__(256) void nonlocal_attention_kernel(const float* __restrict__ qkv, float* __restrict__ y, int Ci) {
+  __shared__ float sT[kJ][65], sP[kJ][65], sF[kJ][kJ + 1];
+  const int tid = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * kJ;
+  const int ld = 3 * Ci;
+  float f[3] = {0.f, 0.f, 0.f};                      // logits of pairs tid, tid + 256, tid + 512 (< 576)
+  for (int c0 = 0; c0 < Ci; c0 += 64) {
+    for (int i = tid; i < kJ * 64; i += 256) {
+      const int j = i >> 6, c = i & 63;
+      const bool ok = c0 + c < Ci;
+      sT[j][c] = ok ? qkv[(row0 + j) * ld + c0 + c] : 0.f;
+      sP[j][c] = ok ? qkv[(row0 + j) * ld + Ci + c0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int pr = tid + 256 * k;
+      if (pr < kJ * kJ) {
+        const int a = pr / kJ, b = pr % kJ;
+        float s = f[k];
+        for (int c = 0; c < 64; ++c) s = fmaf(sT[a][c], sP[b][c], s);
+        f[k] = s;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pr = tid + 256 * k;
+    if (pr < kJ * kJ) sF[pr / kJ][pr % kJ] = f[k];
+  }
+  __syncthreads();
+  if (tid < kJ) {                                     // softmax over the key joints (dim = -1)
+    float m = -3.4e38f;
+    for (int b = 0; b < kJ; ++b) m = fmaxf(m, sF[tid][b]);
+    float z = 0.f;
+    for (int b = 0; b < kJ; ++b) { const float e = expf(sF[tid][b] - m); sF[tid][b] = e; z += e; }
+    const float inv = 1.f / z;
+    for (int b = 0; b < kJ; ++b) sF[tid][b] *= inv;
+  }
+  __syncthreads();
+  for (int i = tid; i < kJ * Ci; i += 256) {
+    const int a = i / Ci, c = i % Ci;
+    float s = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < kJ; ++b) s = fmaf(sF[a][b], qkv[(row0 + b) * ld + 2 * Ci + c], s);
+    y[(row0 + a) * Ci + c] = s;
+  }
+}
+
 // y = act(y + bias[c] (+ residual)), NCHW, in place; float4 when a quad never straddles a channel (HW % 4 == 0).
 template <bool VEC>
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res,
@@ -266,6 +319,14 @@ extern "C" int ehm_bias_act(float* y, const float* bias, const float* residual, 
   if (blocks > cap) blocks = cap;
   if (vec) hipLaunchKernelGGL((bias_act_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, n, C, HW, relu);
   else hipLaunchKernelGGL((bias_act_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, n, C, HW, relu);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_nonlocal_attention(const float* qkv, float* y, int64_t bodies, int Ci, void* stream) {
+  if (bodies == 0) return 0;
+  EHM_CHECK_ARG(qkv && y && bodies > 0 && bodies < (1ll << 31) && Ci > 0);
+  hipLaunchKernelGGL(nonlocal_attention_kernel, dim3((unsigned)bodies), dim3(256), 0, (hipStream_t)stream, qkv, y, Ci);
   EHM_LAUNCH_CHECK();
   return 0;
 }

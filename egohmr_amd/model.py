@@ -82,18 +82,36 @@ class _ResGraphConv(nn.Module):
         self.gconv2 = _GraphConv(adj, dim, dim)
 
 
+class _NonLocalBlock(nn.Module):
+    """Parameter tree of NONLocalBlock2D(in_channels=hid, sub_sample=False, bn_layer=True)
+    (nets/non_local_embedded_gaussian.py:6-58): g / theta / phi 1x1 convs hid -> hid/2, W = Sequential(conv hid/2 -> hid, BatchNorm2d)
+    with the reference's zero-initialised BatchNorm affine (identity block until trained)."""
+
+    def __init__(self, hid_dim):
+        super().__init__()
+        ci = max(hid_dim // 2, 1)
+        self.inter_channels = ci
+        self.g = nn.Conv2d(hid_dim, ci, 1)
+        self.theta = nn.Conv2d(hid_dim, ci, 1)
+        self.phi = nn.Conv2d(hid_dim, ci, 1)
+        self.W = nn.Sequential(nn.Conv2d(ci, hid_dim, 1), nn.BatchNorm2d(hid_dim))
+        nn.init.constant_(self.W[1].weight, 0)
+        nn.init.constant_(self.W[1].bias, 0)
+
+
 class ModulatedGCN(nn.Module):
     """modulated_gcn.py:60-97 parameter tree: gconv_input.0, gconv_layers.{b}.gconv{1,2}, gconv_output."""
 
     def __init__(self, adj, in_dim, out_dim=6, hid_dim=1024, num_layers=4, nonlocal_layer=False, p_dropout=0.0):
         super().__init__()
-        if nonlocal_layer:
-            raise NotImplementedError("gcn_nonlocal_layer=True is off in every shipped reference config and not built here yet")
         self.register_buffer("adj", adj.clone(), persistent=False)
         self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
         self.gconv_input = nn.Sequential(_GraphConv(adj, in_dim, hid_dim))
         self.gconv_layers = nn.Sequential(*[_ResGraphConv(adj, hid_dim) for _ in range(num_layers)])
         self.gconv_output = ModulatedGraphConv(hid_dim, out_dim, adj)
+        self.nonlocal_layer = bool(nonlocal_layer)
+        if self.nonlocal_layer:                                     # modulated_gcn.py:93-94, reference parameter names
+            self.non_local = _NonLocalBlock(hid_dim)
 
     def forward(self, x):
         raise NotImplementedError("the denoiser runs through EgoHMR.forward / EgoHMR.fused_sampler (hoisted input conv)")
@@ -435,10 +453,53 @@ class FusedSampler:
         res = C.c_int(0)
         _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), s), "ehm_gcn_hidden_stack")
         cur = res.value
+        feat = X[cur]
+        if m.diffusion_model.nonlocal_layer:
+            feat = self._non_local(feat, rows, rows_pad)
         x0 = torch.empty(B, 144, device=m.device)
-        _lib.check(L.ehm_gcn_output_layer(h, _lib.ptr(X[cur]), _lib.ptr(st.vis), _lib.ptr(x0), B, passes, s), "ehm_gcn_output_layer")
-        self.last_hidden = X[cur][:rows]
+        _lib.check(L.ehm_gcn_output_layer(h, _lib.ptr(feat), _lib.ptr(st.vis), _lib.ptr(x0), B, passes, s), "ehm_gcn_output_layer")
+        self.last_hidden = feat[:rows]
         return x0
+
+    @torch.no_grad()
+    def _non_local(self, X, rows, rows_pad):
+        """NONLocalBlock2D on the joint axis (modulated_gcn.py:104-110): [theta|phi|g] as ONE 1x1-conv GEMM and W + BatchNorm(eval,
+        folded) + residual as another, both on ehm_conv_nhwc_split (rows = N, H = W = 1); the 24 x 24 softmax attention per body
+        in ehm_nonlocal_attention."""
+        import math
+        m, L = self.model, _lib.lib()
+        nl = m.diffusion_model.non_local
+        hid, ci = m.diffusion_model.hid_dim, nl.inter_channels
+        key = tuple((p.data_ptr(), p._version) for p in list(nl.parameters()) + list(nl.buffers()))
+        if getattr(self, "_nl_key", None) != key:
+            def pack(w2, bias):                                   # [Co, K] float32 -> X2 split weights for the conv kernel
+                Co, K = w2.shape
+                Co_pad = (Co + 127) // 128 * 128
+                wp = torch.zeros(Co_pad, K, device=m.device)
+                wp[:Co] = w2
+                amax = float(wp.abs().max())
+                scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
+                buf = torch.empty(Co_pad, K, device=m.device)
+                _lib.check(L.ehm_split_pack(wp.data_ptr(), buf.data_ptr(), Co_pad, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
+                return buf, scale, bias.float().contiguous()
+            wqkv = torch.cat([nl.theta.weight, nl.phi.weight, nl.g.weight], 0).flatten(1).float()
+            bqkv = torch.cat([nl.theta.bias, nl.phi.bias, nl.g.bias], 0)
+            bn = nl.W[1]
+            sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            ww = (nl.W[0].weight.flatten(1).double() * sc[:, None]).float()
+            bw = ((nl.W[0].bias.double() - bn.running_mean.double()) * sc + bn.bias.double()).float()
+            self._nl_packed, self._nl_key = (pack(wqkv, bqkv), pack(ww, bw)), key
+        (wq, sq, bq), (wo, so, bo) = self._nl_packed
+        s = _lib.stream_ptr()
+        qkv = torch.empty(rows, 3 * ci, device=m.device)
+        d = _lib.ConvDesc(X.data_ptr(), wq.data_ptr(), bq.data_ptr(), None, qkv.data_ptr(), rows, 1, 1, hid, 3 * ci, 1, 1, 1, 0, 0, sq)
+        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
+        y = torch.empty(rows, ci, device=m.device)
+        _lib.check(L.ehm_nonlocal_attention(qkv.data_ptr(), y.data_ptr(), rows // 24, ci, s), "ehm_nonlocal_attention")
+        Z = torch.zeros(rows_pad, hid, device=m.device)
+        d = _lib.ConvDesc(y.data_ptr(), wo.data_ptr(), bo.data_ptr(), X.data_ptr(), Z.data_ptr(), rows, 1, 1, ci, hid, 1, 1, 1, 0, 0, so)
+        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
+        return Z
 
     # ------------------------------------------------------------------ guidance pieces
     @torch.no_grad()
@@ -486,6 +547,9 @@ class FusedSampler:
         """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
         Returns the reference's dict(sample, pred_xstart, other_outputs)."""
         m, L = self.model, _lib.lib()
+        if m.diffusion_model.nonlocal_layer:
+            raise _lib.EgoHMRHipError("the one-call sampling loop does not carry the optional non-local GCN block; "
+                                      "use GaussianDiffusion.p_sample_loop / ddim_sample_loop (they take the step-wise route for such a model)")
         st = prepared if prepared is not None else self.prepare(batch)
         B, T, hid, V = st.B, diffusion.num_timesteps, m.diffusion_model.hid_dim, m.smpl.num_verts
         noise = _lib.f32(noise_stack, m.device)

@@ -147,8 +147,23 @@ def _resnet50_manifest(prefix: str) -> list:
     return out
 
 
+def nonlocal_manifest(hid_dim: int = 1024, prefix: str = "diffusion_model.non_local.") -> list:
+    """NONLocalBlock2D(in_channels=hid, sub_sample=False, bn_layer=True) of ModulatedGCN(nonlocal_layer=True)
+    (modulated_gcn.py:93-94, nets/non_local_embedded_gaussian.py:6-58): g / theta / phi 1x1 convs hid -> hid/2, W = conv hid/2 -> hid
+    + BatchNorm2d.  Listed apart from egohmr_manifest (the shipped configs leave the block off) and always drawn AFTER it, so the
+    seeded values of every other tensor do not move."""
+    ci = max(hid_dim // 2, 1)
+    m = []
+    for n in ("g", "theta", "phi"):
+        m += [(prefix + n + ".weight", (ci, hid_dim, 1, 1)), (prefix + n + ".bias", (ci,))]
+    m += [(prefix + "W.0.weight", (hid_dim, ci, 1, 1)), (prefix + "W.0.bias", (hid_dim,)),
+          (prefix + "W.1.weight", (hid_dim,)), (prefix + "W.1.bias", (hid_dim,)), (prefix + "W.1.running_mean", (hid_dim,)),
+          (prefix + "W.1.running_var", (hid_dim,)), (prefix + "W.1.num_batches_tracked", ())]
+    return m
+
+
 def egohmr_manifest(hid_dim: int = 1024, num_blocks: int = 4, scene_feat_dim: int = 512,
-                    img_feat_dim: int = 2048, with_backbone: bool = True) -> list:
+                    img_feat_dim: int = 2048, with_backbone: bool = True, nonlocal_layer: bool = False) -> list:
     """(name, shape) of every learnable tensor / buffer of the stage-2 model, reference names.
 
     Conditioning width = img 2048 + scene 512 + transl 128 + cam (2+3+1) = 2694
@@ -198,6 +213,8 @@ def egohmr_manifest(hid_dim: int = 1024, num_blocks: int = 4, scene_feat_dim: in
     m += [("beta_layer.layers.0.weight", (1024, ctx)), ("beta_layer.layers.0.bias", (1024,)),
           ("beta_layer.layers.2.weight", (10, 1024)), ("beta_layer.layers.2.bias", (10,)),
           ("beta_layer.init_betas", (1, 10))]
+    if nonlocal_layer:
+        m += nonlocal_manifest(hid_dim)
     return m
 
 

@@ -199,6 +199,12 @@ typedef struct ehm_conv_desc {
 } ehm_conv_desc;
 int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream);
 
+/* Attention core of the optional non-local block of ModulatedGCN (nonlocal_layer=True, modulated_gcn.py:93-110;
+ * nets/non_local_embedded_gaussian.py:68-79): per body, y = softmax(theta phi^T, dim=-1) g over the 24 joints.
+ *   qkv [bodies*24, 3*Ci] float32 rows = [theta | phi | g] (one 1x1-conv GEMM, e.g. ehm_conv_nhwc_split with H = W = 1);
+ *   y [bodies*24, Ci].  The W conv + BatchNorm + residual that follow are another ehm_conv_nhwc_split call. */
+int ehm_nonlocal_attention(const float* qkv, float* y, int64_t bodies, int Ci, void* stream);
+
 /* ------------------------------------------------------------------ sampler steps ------------- */
 /* diffusion/gaussian_diffusion.py:217-220 + :333-336 (p_sample) and :378-385 (p_sample_with_grad):
  *   mean = coef1*x0 + coef2*x  [+ grad_scale * grad]

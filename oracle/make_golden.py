@@ -327,6 +327,25 @@ def g8_g9_end_to_end(model, only=None):
              x_t_trace=np.stack(xs), **_pack_out(o))
 
 
+def g13_gcn_nonlocal():
+    """ModulatedGCN(nonlocal_layer=True) (modulated_gcn.py:93-110): the reference module itself, synthetic weights with a
+    non-trivial W.1 BatchNorm (the reference initialises it to zero = identity block)."""
+    from models.egohmr.modulated_gcn.modulated_gcn import ModulatedGCN
+    from oracle import model as om
+    hid, in_dim, B = 128, 96, 3
+    man = [(n, sh) for n, sh in syn.egohmr_manifest(hid_dim=hid, num_blocks=1, with_backbone=False, nonlocal_layer=True)
+           if n.startswith("diffusion_model.")]
+    man = [(n, ((2, in_dim, hid) if n == "diffusion_model.gconv_input.0.gconv.W" else sh)) for n, sh in man]
+    sd = syn.make_state_dict(seed=13, manifest=man)
+    net = ModulatedGCN(om.smpl_adjacency(), in_dim=in_dim, out_dim=6, hid_dim=hid, num_layers=1, nonlocal_layer=True).eval()
+    missing, unexpected = net.load_state_dict({k[len("diffusion_model."):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all("adj" in m for m in missing), (missing, unexpected)
+    x = np.random.Generator(np.random.PCG64(13)).normal(size=(B, 24, in_dim)).astype(np.float32)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x))
+    save("g13_gcn_nonlocal", weight_seed=13, hid=hid, in_dim=in_dim, x=x, y=y.numpy())
+
+
 def g11_procrustes():
     from utils.pose_utils import reconstruction_error
     g = np.random.Generator(np.random.PCG64(15))
@@ -344,6 +363,9 @@ def main():
     asset = syn.make_smpl_asset(0)
     install_shims(asset)
     print("reference-driven goldens ->", OUT)
+    if os.environ.get("GOLDEN_ONLY") == "g13":
+        g13_gcn_nonlocal()
+        return
     if os.environ.get("GOLDEN_ONLY") == "g12":
         sd = syn.make_state_dict(0)
         mean, std = syn.make_body_rep_stats(0)
@@ -354,6 +376,7 @@ def main():
     g4_gcn()
     g7_single_steps()
     g11_procrustes()
+    g13_gcn_nonlocal()
     if os.environ.get("GOLDEN_ONLY") == "g11":
         return
     sd = syn.make_state_dict(0)

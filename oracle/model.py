@@ -110,14 +110,30 @@ def _graph_conv(sd, p, x, adj):
     return F.relu(_bn(y, sd, p + ".bn").transpose(1, 2))
 
 
-def modulated_gcn(sd, x, adj, p="diffusion_model.", num_blocks=4):
-    """modulated_gcn.py:99-116 with nonlocal_layer=False (every shipped config)."""
+def non_local_block(sd, p, x):
+    """NONLocalBlock2D(hid, sub_sample=False, bn_layer=True) applied to the joint axis (modulated_gcn.py:105-110 wraps [B,24,C]
+    into [B,C,1,24]; nets/non_local_embedded_gaussian.py:60-85): embedded-Gaussian attention over the 24 joints,
+    z = BN(W (softmax(theta phi^T) g)) + x.  x [B,24,C]; the 1x1 convolutions are per-joint linear maps."""
+    lin = lambda n, v: F.linear(v, sd[p + n + ".weight"].flatten(1), sd[p + n + ".bias"])
+    g_x, th, ph = lin("g", x), lin("theta", x), lin("phi", x)                     # [B,24,C/2]   :68-74
+    f = torch.matmul(th, ph.transpose(1, 2))                                       # [B,24,24]   :75
+    y = torch.matmul(F.softmax(f, dim=-1), g_x)                                    # :76-78
+    w_y = lin("W.0", y)                                                            # :81 conv
+    scale = sd[p + "W.1.weight"] / torch.sqrt(sd[p + "W.1.running_var"] + 1e-5)   # BatchNorm2d, eval
+    w_y = (w_y - sd[p + "W.1.running_mean"]) * scale + sd[p + "W.1.bias"]
+    return w_y + x                                                                 # :82
+
+
+def modulated_gcn(sd, x, adj, p="diffusion_model.", num_blocks=4, nonlocal_layer=False):
+    """modulated_gcn.py:99-116; nonlocal_layer=False in every shipped config."""
     out = _graph_conv(sd, p + "gconv_input.0", x, adj)
     for b in range(num_blocks):
         res = out
         out = _graph_conv(sd, f"{p}gconv_layers.{b}.gconv1", out, adj)
         out = _graph_conv(sd, f"{p}gconv_layers.{b}.gconv2", out, adj)
         out = res + out
+    if nonlocal_layer:
+        out = non_local_block(sd, p + "non_local.", out)                            # :104-110
     return modulated_graph_conv(sd, p + "gconv_output", out, adj)
 
 
@@ -139,7 +155,7 @@ class EgoHMROracle:
 
     def __init__(self, state_dict: dict, smpl_asset: dict, body_rep_mean, body_rep_std,
                  diffuse_fuse=True, pelvis_vis_loosen=True, dtype=torch.float32, faithful=True,
-                 num_blocks=4, collision_loss=None):
+                 num_blocks=4, collision_loss=None, gcn_nonlocal_layer=False):
         self.dtype = dtype
         self.sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v))
                    for k, v in state_dict.items()}
@@ -151,6 +167,7 @@ class EgoHMROracle:
         self.adj = smpl_adjacency(dtype)
         self.faithful = faithful
         self.num_blocks = num_blocks
+        self.nonlocal_layer = gcn_nonlocal_layer                                      # egohmr.py:37,:99
         self.collision_loss = collision_loss
         self._cache_key = None
         self._cache = None
@@ -204,11 +221,11 @@ class EgoHMROracle:
         cond = torch.cat([img24, other.unsqueeze(1).repeat(1, 24, 1)], dim=-1)          # :222-223  [B,24,2694]
         x_t = batch["x_t"].to(dt).reshape(B, 24, -1)
         x_feat = F.linear(x_t, sd["input_process.poseEmbedding.weight"], sd["input_process.poseEmbedding.bias"])
-        out = modulated_gcn(sd, torch.cat([cond, x_feat, temb], dim=-1), self.adj, num_blocks=self.num_blocks)  # :236-237
+        out = modulated_gcn(sd, torch.cat([cond, x_feat, temb], dim=-1), self.adj, num_blocks=self.num_blocks, nonlocal_layer=self.nonlocal_layer)  # :236-237
         if self.diffuse_fuse:                                                          # :239-254
             cond_u = cond.clone()
             cond_u[:, :, 0:2048] = 0
-            out_u = modulated_gcn(sd, torch.cat([cond_u, x_feat, temb], dim=-1), self.adj, num_blocks=self.num_blocks)
+            out_u = modulated_gcn(sd, torch.cat([cond_u, x_feat, temb], dim=-1), self.adj, num_blocks=self.num_blocks, nonlocal_layer=self.nonlocal_layer)
             out_c = out
             out = out_u + 0 * (out_c - out_u)                                          # guidance_param = 0
             m = vis.unsqueeze(-1).repeat(1, 1, 6).reshape(B, -1)

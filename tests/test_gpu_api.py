@@ -216,3 +216,56 @@ def test_hidden_stack_chained_equals_layer_by_layer(B, passes):
         _lib.check(L.ehm_gcn_stack_status(h, None))
         assert res.value == cur
         assert torch.equal(bufs_t[res.value], ref[cur]), f"rep {rep}"
+
+
+@pytest.mark.gpu
+def test_non_local_gcn_block_vs_oracle():
+    """gcn_nonlocal_layer=True (ModulatedGCN + NONLocalBlock2D, modulated_gcn.py:93-110; the oracle's block is pinned by the
+    reference golden G13): EgoHMR.forward and a short DDIM loop against the oracle; the one-call loop refuses such a model and
+    the diffusion API falls back to the step-wise (still all-HIP) route."""
+    from egohmr_amd import _lib, synthetic as syn
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    from oracle import model as om, sampler as osampler, schedule as osched
+    dev = torch.device("cuda:0")
+    B, N = 3, 512
+    sd, asset = syn.make_state_dict(0, nonlocal_layer=True), syn.make_smpl_asset(0)
+    assert any(k.startswith("diffusion_model.non_local.W.1.") for k in sd)
+    mean, std = syn.make_body_rep_stats(0)
+    model = build_synthetic_model(dev, 0, gcn_nonlocal_layer=True)
+    ref = om.EgoHMROracle(sd, asset, mean, std, faithful=False, gcn_nonlocal_layer=True)
+    ref0 = om.EgoHMROracle(sd, asset, mean, std, faithful=False, gcn_nonlocal_layer=False)
+    bnp = syn.make_batch(B, num_scene_points=N, seed=5)
+    x_t = np.random.Generator(np.random.PCG64(5)).normal(size=(B, 144)).astype(np.float32)
+    t = torch.full((B,), 17, dtype=torch.long)
+    tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in bnp.items()}
+    tb["x_t"] = torch.from_numpy(x_t)
+    ref.validation_setup(); ref0.validation_setup()
+    o_ref = ref(tb, t)
+    o_ref0 = ref0(dict(tb), t)
+    assert float((o_ref["pred_x_start"] - o_ref0["pred_x_start"]).abs().max()) > 1e-3          # the block matters with these weights
+    b = batch_to_device(bnp, dev)
+    b["x_t"] = torch.from_numpy(x_t).to(dev)
+    o = model(b, t.to(dev))
+    # the attention logits are O(50) with these weights, so float32 rounding of a 512-term dot product is amplified by the softmax:
+    # judge both float32 implementations against the float64 oracle
+    ref64 = om.EgoHMROracle(sd, asset, mean, std, faithful=False, gcn_nonlocal_layer=True, dtype=torch.float64)
+    ref64.validation_setup()
+    tb64 = {k: ({kk: vv.double() for kk, vv in v.items()} if isinstance(v, dict) else (v.double() if v.dtype == torch.float32 else v)) for k, v in tb.items()}
+    o64 = ref64(tb64, t)
+    e_hip = float((o["pred_x_start"].cpu().double() - o64["pred_x_start"]).abs().max())
+    e_f32 = float((o_ref["pred_x_start"].double() - o64["pred_x_start"]).abs().max())
+    print(f"non-local forward: max|x0 - fp64| hip {e_hip:.2e}, float32 oracle {e_f32:.2e}")
+    assert e_hip <= max(3.0 * e_f32, 5e-5)
+    np.testing.assert_allclose(o["pred_vertices"].cpu().numpy(), o64["pred_vertices"].float().numpy(), atol=1e-4)
+    # sampling: API routes step-wise, the fused loop refuses
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=9))
+    out = d.val_losses(model, batch_to_device(bnp, dev), shape=[B, 144], clip_denoised=False, timestep_respacing="ddim5", compute_loss=False,
+                       noise_stack=noise.to(dev))
+    tab = osched.make_tables(50, "ddim5")
+    tb2 = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in bnp.items()}
+    o2 = osampler.val_losses(ref, tb2, tab, noise, "ddim5")
+    np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), o2["pred_vertices"].numpy(), atol=1e-4)
+    with pytest.raises(_lib.EgoHMRHipError):
+        model.fused_sampler.run(d, batch_to_device(bnp, dev), noise.to(dev), ddim=True)

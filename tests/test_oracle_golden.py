@@ -169,3 +169,18 @@ def test_g8_g9_end_to_end(golden_dir, synth_weights, smpl_asset, name, faithful)
         sampler.val_losses(m, b, tab, noise, rs, cond_fn_with_grad=False, trace=tr0)
         assert float((tr0[-1][0] - tr[-1][0]).abs().max()) > 2e-5   # (small: scale 1.0 x sqrt(1 - abar) on the last steps)
         assert float((tr0[5][0] - tr[5][0]).abs().max()) == 0.0   # ... and only there (t <= 3 of 10)
+
+
+def test_g13_gcn_with_non_local_block(golden_dir):
+    """oracle ModulatedGCN + NONLocalBlock2D against the reference module (nonlocal_layer=True, modulated_gcn.py:93-110)."""
+    g = _load(golden_dir, "g13_gcn_nonlocal")
+    hid, in_dim = int(g["hid"]), int(g["in_dim"])
+    man = [(n, sh) for n, sh in syn.egohmr_manifest(hid_dim=hid, num_blocks=1, with_backbone=False, nonlocal_layer=True)
+           if n.startswith("diffusion_model.")]
+    man = [(n, ((2, in_dim, hid) if n == "diffusion_model.gconv_input.0.gconv.W" else sh)) for n, sh in man]
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_state_dict(seed=int(g["weight_seed"]), manifest=man).items()}
+    x = torch.from_numpy(g["x"])
+    y = om.modulated_gcn(sd, x, om.smpl_adjacency(), num_blocks=1, nonlocal_layer=True)
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=1e-5)
+    y0 = om.modulated_gcn(sd, x, om.smpl_adjacency(), num_blocks=1, nonlocal_layer=False)
+    assert float((y - y0).abs().max()) > 1e-2          # the block is not an identity with these weights

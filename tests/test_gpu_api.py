@@ -127,8 +127,10 @@ def test_error_behaviour(dev, model):
         create_gaussian_diffusion(num_diffusion_timesteps=10, timestep_respacing="ddim7")
     with pytest.raises(_lib.EgoHMRHipError):                      # CPU tensors never fall back to eager
         model.scene_enc(torch.zeros(1, 128, 3))
+    out = d.ddim_sample_loop(model, _batch(dev), [3, 144], cond_fn_with_grad=True)     # ddim_sample_with_grad exists (golden G12)
+    assert torch.isfinite(out["sample"]).all()
     with pytest.raises(NotImplementedError):
-        d.ddim_sample_loop(model, _batch(dev), [3, 144], cond_fn_with_grad=True)
+        d.training_losses(model, _batch(dev), torch.zeros(3, dtype=torch.long))           # training is out of scope
 
 
 def test_rotation_matrix_to_angle_axis_vs_reference_golden(golden_dir, dev):

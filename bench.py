@@ -31,6 +31,9 @@ WORKLOADS = {
     "ddpm100": (100, "", "B256 S1 DDPM-100 N4096 ResNet50+PointNet cond, diffuse_fuse(2 GCN passes), LBS every step, unguided"),
     "c2_ddim10": (100, "ddim10", "BASELINE config 2: B256 S1 DDIM-10 N4096 ResNet50+PointNet cond, diffuse_fuse, LBS every step"),
     "c1_ddim5": (50, "ddim5", "BASELINE config 1 shape: DDIM-5 of 50"),
+    # BASELINE config 3: B128 items x 10 samples, full 100-step DDPM, collision guidance on the last 11 steps (proxy loss);
+    # a "step" = one batch of items = 10 guided sampling loops over ONE conditioning pass (the reference re-encodes per sample)
+    "c3_guided": (100, "", "BASELINE config 3: B128 x S10 DDPM-100, collision-guided (last 11 steps), conditioning encoded once per item"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (~2.5 PFLOP/s)
@@ -157,6 +160,11 @@ def main():
 
     n, rs, desc = WORKLOADS[args.workload]
     B, N = args.batch, args.scene_points
+    S, guided = 1, False
+    if args.workload == "c3_guided":
+        S, guided = 10, True
+        if args.batch == 256:
+            B = 128
     model = build_synthetic_model(dev, 0, diffuse_fuse=True)
     model.lbs_every_step = not args.no_lbs_every_step
     model.gcn_precision = args.precision
@@ -164,14 +172,19 @@ def main():
     T = diffusion.num_timesteps
     batch = batch_to_device(syn.make_batch(B, N, seed=100 + rank), dev)            # inputs resident in HBM before timing
     noise = torch.from_numpy(syn.make_noise_stack(T, B, seed=100 + rank)).to(dev)
+    noises = [noise] + [torch.from_numpy(syn.make_noise_stack(T, B, seed=100 + rank + 1000 * k)).to(dev) for k in range(1, S)]
+    if guided:   # put the floor through the bodies so that the collision term is live (as in the guided golden)
+        batch["scene_pcd_verts_full"][:, : N // 3, 1] = batch["smpl_params"]["transl"][:, None, 1] - 0.6
     fs = model.fused_sampler
     ddim = bool(rs)
 
     def one_step():
         fs._prep = None                                                              # conditioning is part of the job: re-encode
-        res = fs.run(diffusion, batch, noise, ddim=ddim)
-        packed = edist.pack_params(res["other_outputs"]["pred_smpl_params"])
-        return edist.gather_packed(packed), res
+        packs = []
+        for k in range(S):                                                           # samples of one item share its conditioning
+            res = fs.run(diffusion, batch, noises[k], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0)
+            packs.append(edist.pack_params(res["other_outputs"]["pred_smpl_params"]))
+        return edist.gather_packed(torch.cat(packs, 0)), res
 
     for _ in range(args.warmup):
         one_step()
@@ -186,13 +199,13 @@ def main():
     torch.cuda.synchronize()
     dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(res["other_outputs"]["pred_vertices"]).all()
-    assert gathered.shape == (world * B, edist.PACKED_WIDTH)
+    assert gathered.shape == (world * B * S, edist.PACKED_WIDTH)
 
     # comparison legs (rank-local, N=1 only): the same job, same noise, with the hidden convs (a) on the f32-input MFMA (exact f32
     # products) and (b) on plain f16 operands (one MFMA per product - the "fp16 denoiser" of BASELINE config 5; NOT parity-grade),
     # each with its distance to the default path's vertices / joints
     f32_leg = f16_leg = None
-    if args.precision == "f16x3" and world == 1:
+    if args.precision == "f16x3" and world == 1 and S == 1:
         ref_v = res["other_outputs"]["pred_vertices"].float().clone()
         ref_j = res["other_outputs"]["pred_keypoints_3d"].float().clone() if "pred_keypoints_3d" in res["other_outputs"] else None
 
@@ -244,7 +257,7 @@ def main():
                  "f16": "gcn_hidden_chain_kernel<1> (plain f16 MFMA, f32 accumulate, same fused epilogue); avg_launch_ms is per conv"}[args.precision]
         out = {
             "metric": "sampled bodies/sec (100-step DDPM, batch 256)" if args.workload == "ddpm100" else f"sampled bodies/sec ({args.workload})",
-            "value": world * B * args.steps / dt,
+            "value": world * B * S * args.steps / dt,
             "unit": "bodies/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -256,7 +269,7 @@ def main():
             "dtype": {"f32": "f32", "f16x3": "f32 (denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands, f32 accumulate)",
                       "f16": "f16 denoiser GEMMs (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": 1, "denoising_steps": T,
+            "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": S, "collision_guided": guided, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
                        "gcn_precision": args.precision, "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
                        "parallelism": f"items sharded x{world}, one RCCL all-gather of [B,226] at the end"},

@@ -82,10 +82,14 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
     __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + RA_T + (wave + 4 * i) * 256), 16, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
+#ifndef EHM_EXP_NO_A_DMA      // timing experiments only (wrong results): how much of the K loop is DMA issue?
 #pragma unroll
     for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+#endif
+#ifndef EHM_EXP_NO_B_DMA
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
+#endif
   };
 
   // ---- fragments (v_mfma_f32_32x32x16_f16: lane l holds row l&31, k = 8*(l>>5) .. +7 of a 16-wide step)

@@ -267,7 +267,10 @@ def make_state_dict(seed: int = 0, manifest: list | None = None, **manifest_kw) 
             sd[name] = g.normal(scale=0.05, size=shape).astype(np.float32)
         elif leaf == "weight" and len(shape) == 4:  # conv
             fan_in = shape[1] * shape[2] * shape[3]
-            sd[name] = g.normal(scale=np.sqrt(2.0 / fan_in), size=shape).astype(np.float32)
+            scale = np.sqrt(2.0 / fan_in)
+            if ".non_local.theta." in name or ".non_local.phi." in name:
+                scale *= 0.25          # attention logits O(3) instead of O(50): a trained block is not one-hot, and parity tests stay well-conditioned
+            sd[name] = g.normal(scale=scale, size=shape).astype(np.float32)
         elif leaf == "weight" and len(shape) == 2:  # linear [out, in]
             scale = np.sqrt(1.0 / shape[1])
             if name.startswith("beta_layer.layers.2"):

@@ -155,6 +155,7 @@ def main():
     rank, world, local = edist.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    local %= torch.cuda.device_count()          # (functional 2-rank runs on a 1-GPU box share the device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -25,7 +25,7 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("EGOHMR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -55,6 +55,8 @@ def gather_packed(packed: torch.Tensor, counts: list[int] | None = None) -> torc
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return packed
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and packed.is_cuda:             # functional multi-rank runs on one GPU box: stage through the host
+        return gather_packed(packed.cpu(), counts).to(packed.device)
     if counts is None or len(set(counts)) == 1:
         out = torch.empty(world * packed.shape[0], packed.shape[1], dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(out, packed)
@@ -75,6 +77,6 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -22,7 +22,7 @@ if os.environ.get("EHM_TILE"):
     _lib.check(L.ehm_gcn_set_tile_override(h, int(os.environ["EHM_TILE"])))
 hid, tile = model.diffusion_model.hid_dim, L.ehm_gcn_row_tile()
 rows_pad = (2 * B * 24 + tile - 1) // tile * tile
-X = torch.randn(rows_pad, hid, device=dev)
+X = torch.randn(rows_pad, hid, device=dev) * float(os.environ.get("EHM_X_SCALE", "1"))   # EHM_X_SCALE=0: zero operands (clock / power probe)
 X2, Y1, Y2 = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
 if prec != "f32":
     _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))

@@ -520,6 +520,7 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   if (const char* e = getenv("EHM_F16_PERSISTENT")) g->persistent = atoi(e) != 0;
   if (const char* e = getenv("EHM_F16_PIPELINED")) g->pipelined = atoi(e);
   if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);
+  if (const char* e = getenv("EHM_F16R_WIDE")) g->wide_tile = atoi(e);
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
   const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ + 1600;   // + Aoff MFMA fragments (6 KiB) and 1/S

@@ -53,6 +53,7 @@ struct ehm_gcn {
   unsigned int* chain_sync = nullptr;    // tickets[8] | done[nl][m_tiles] | err, zeroed before every chained launch
   size_t chain_sync_words = 0;
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
+  int wide_tile = 0;                     // gcn_f16r.hip: 1 = 8-wave 192 x 128 blocks (EHM_F16R_WIDE), 0 = 4-wave 192 x 64 blocks
   int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (split-f16, pipelined == 2), 0 = one launch per conv
   OutDev out{};
   float* arena = nullptr;

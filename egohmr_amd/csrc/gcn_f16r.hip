@@ -32,7 +32,17 @@ constexpr int kStoreAux = EHM_STORE_AUX;
                          // session): the epilogue is bound by load latency behind the other block's DMA stream, not by VALU issue
 #endif
 constexpr int RK = 32;                                        // K per tile
-constexpr int RA_T = 192 * RK, RB_T = 128 * RK, RSTG = RA_T + RB_T;   // floats per stage: 10240 = 40 KiB
+// Block shape: NWN = waves along the channel axis.  2: 4 waves, 192 rows x 64 channels, 40 KiB per stage, 2 blocks per CU (default);
+// 4: 8 waves, 192 rows x 128 channels, 56 KiB per stage, 1 block per CU - 30 % fewer DMA bytes and instructions per MFMA.
+template <int NWN>
+struct Shape {
+  static constexpr int NW = 2 * NWN;              // waves per block (2 along rows x NWN along channels, 96 x 32 per wave)
+  static constexpr int CH = 32 * NWN;             // channels per block
+  static constexpr int BROWS = 2 * CH;            // weight rows per block (both branches)
+  static constexpr int A_T = 192 * RK, B_T = BROWS * RK, STG = A_T + B_T;   // floats
+  static constexpr int NA = 24 / NW, NB = 4;      // DMA instructions per wave and K tile (8 rows each)
+  static constexpr int UPR = CH / 8;              // epilogue work items (8 channels) per row
+};
 
 // Build with EHM_HIPCC_FLAGS=-DEHM_STAMPS to record per-block phase time stamps (tools/stamp_hidden.py): slot i of block b at
 // g_dbg[16 b + i]; STAMP = s_memrealtime (100 MHz), STAMPC = s_memtime (shader clock).
@@ -56,35 +66,37 @@ struct Frags {
 // AUX = cache-policy bits of the output stores, IN_AUX = of the activation loads (A-operand DMA, residual); 16 = sc1 = agent scope
 // (stores write through, loads bypass the CU's L1), used by the chained kernel.  `ready()` is called after the weight DMA of
 // the first two K tiles has been issued and before the first activation byte is requested.
-template <int PASSES, int AUX, int IN_AUX, class Ready>
+template <int PASSES, int AUX, int IN_AUX, int NWN, class Ready>
 __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__ X, const LayerDev& L, const half_t* __restrict__ Res,
                                           float* __restrict__ Y, int m_tile, int n_tile, const bool RES, const bool OUT_SPLIT, Ready ready) {
   STAMP(0); STAMPC(4);
+  typedef Shape<NWN> SH;
+  constexpr int NW = SH::NW, CH = SH::CH, RA_T = SH::A_T, RSTG = SH::STG, NA = SH::NA;
   const int K = L.K, N = L.N;
   const size_t m0 = (size_t)m_tile * 192;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   // ---- DMA: one wave instruction = 8 rows x 128 B; physical 16-byte chunk c of row r holds logical chunk c ^ ((r>>1)&7)
   const int ld_r = lane >> 3, ld_c = lane & 7;
   const int r0 = 8 * wave + ld_r;
   const int swz = (ld_c ^ ((r0 >> 1) & 7)) << 2;             // r0 + 32 i keeps the key
   const float* pA = (const float*)X + (m0 + r0) * K + swz;
-  const float* pB = (const float*)L.Ws + ((size_t)n_tile * 128 + r0) * K + swz;
-  const size_t row32 = (size_t)32 * K;
+  const float* pB = (const float*)L.Ws + ((size_t)n_tile * SH::BROWS + r0) * K + swz;
+  const size_t row32 = (size_t)8 * NW * K;            // rows between a wave's consecutive DMA instructions (keeps the swizzle key: multiple of 16)
   auto dma_a = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + (wave + 4 * i) * 256), 16, 0, IN_AUX);
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + (wave + NW * i) * 256), 16, 0, IN_AUX);
   };
   auto dma_b = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + RA_T + (wave + 4 * i) * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * RSTG + RA_T + (wave + NW * i) * 256), 16, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
 #ifndef EHM_EXP_NO_A_DMA      // timing experiments only (wrong results): how much of the K loop is DMA issue?
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+    for (int i = 0; i < NA; ++i) dma_a(buf, kt, i);
 #endif
 #ifndef EHM_EXP_NO_B_DMA
 #pragma unroll
@@ -99,7 +111,7 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   // 24 joints of bodies 2g and 2g+1, and joint j of the two bodies sits in the ADJACENT registers 2*(j&7), 2*(j&7)+1 of accumulator j>>3:
   // the 24x24 adjacency mix runs as v_pk_fma_f32 on register pairs without a single move.
   const int rA = 96 * wm + 48 * ((mi >> 2) & 1) + 24 * (mi & 1) + ((mi >> 1) & 1) + 2 * (mi >> 3);
-  const int rB = 32 * wn + mi;
+  const int rB = ((32 * wn) >> 6) * 128 + ((32 * wn) & 63) + mi;   // packed weights: per 64 channels, 64 rows of W0 then 64 rows of W1
   // swizzle key (row>>1)&7: +8t flips bit 2 for t = 1 (12*(mi&1) + (mi>>3) + 4t), +64u leaves it.  Conflict-free for ds_read_b128's
   // lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: their 16 rows carry every key twice, once on an even and once on an odd row.
   const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
@@ -164,7 +176,7 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    if constexpr (PASSES == 3) {                // 8 MFMAs left: 2,2,1,1,1,1,1,1 DMAs behind them
+    if constexpr (PASSES == 3 && NA == 6) {     // 8 MFMAs left: 2,2,1,1,1,1,1,1 DMAs behind them
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -174,6 +186,13 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
+    } else if constexpr (PASSES == 3) {         // wide tile: 7 DMAs, one behind each of the next 7 MFMAs
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     } else {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x010, 10, 0);
@@ -188,10 +207,11 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
   ready();
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+  for (int i = 0; i < NA; ++i) dma_a(0, 0, i);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile 0 landed (the activation half of tile 1 may still fly)
+  for (int i = 0; i < NA; ++i) dma_a(1, 1, i);
+  if constexpr (NA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile 0 landed (the activation half of tile 1 may still fly)
+  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   __syncthreads();
   read_frags(f0, 0, 0);
   STAMP(1); STAMPC(5);
@@ -212,7 +232,7 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   }
   // ---- the last two tiles: nothing left to fetch; the per-channel epilogue constants are fetched under their MFMAs
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int n = 64 * n_tile + 32 * wn + mi;
+  const int n = CH * n_tile + 32 * wn + mi;
   const unsigned int rowbytes = (unsigned int)N * 4u;               // X2 rows and float rows have the same size
   const __amdgpu_buffer_rsrc_t resB = ehm_buffer_rsrc((const char*)Res + m0 * rowbytes);
   const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc((const char*)Y + m0 * rowbytes);
@@ -253,9 +273,10 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   // 110k-cycle block; 16-byte accesses cut its memory instruction count 8x.  The residual is fetched under the mix.
   // Addresses = block-uniform buffer descriptor + 32-bit lane offset: a 192-row tile spans < 2 GiB.
   // P2 work item: rows urow + 32 i (i < 6), channels 64*n_tile + 8*uc .. +7
-  const int urow = tid >> 3, uc = tid & 7;
-  const unsigned int ucolx = (unsigned int)(2 * n_tile + (uc >> 2)) * 128u + (unsigned int)(uc & 3) * 16u;   // X2: 8 hi halves here, 8 lo halves 64 B on
-  const unsigned int ucolf = (unsigned int)(64 * n_tile + 8 * uc) * 4u;
+  const int urow = tid / SH::UPR, uc = tid % SH::UPR;
+  const int uc0 = CH * n_tile + 8 * uc;                                                    // first channel of the work item
+  const unsigned int ucolx = (unsigned int)(uc0 >> 5) * 128u + (unsigned int)(uc0 & 31) * 2u;   // X2: 8 hi halves here, 8 lo halves 64 B on
+  const unsigned int ucolf = (unsigned int)uc0 * 4u;
   // The mix's coefficient fragments are requested NOW, behind the last MFMA: an epilogue load queues behind the DMA stream of the
   // CU's other block and takes 1-3 us to come back (stamps).  (Requesting the residual here as well spills ~25 registers: slower.)
 #if EHM_MIX_MFMA
@@ -329,16 +350,16 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
         dB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[s3], bBh, dB, 0, 0, 0);
       }
       // D: column = my channel, rows = joints (r&3) + 8 (r>>2) + 4 g (g = lane half; r >> 2 == 3 is padding)
-      float* ta = T + (96 * wm + 24 * beta) * 64;        // body of half-wave 0;   + 48 rows: body of half-wave 1
+      float* ta = T + (96 * wm + 24 * beta) * CH;        // body of half-wave 0;   + 48 rows: body of half-wave 1
 #pragma unroll
       for (int r = 0; r < 12; ++r) {
         const int j0 = (r & 3) + 8 * (r >> 2);             // + 4 g
         const int sw = (j0 >> 1) & 1;                       // (row >> 1) & 1 of the transposition tile's swizzle: 4 g, 24 beta, 48, 96 wm leave it
         float va = dA[r] * invS, vb = dB[r] * invS;
         if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
-        float* t = ta + (j0 + 4 * g) * 64 + (((ch >> 2) ^ sw) << 2) + (ch & 3);
+        float* t = ta + (j0 + 4 * g) * CH + (((ch >> 2) ^ sw) << 2) + (ch & 3);
         t[0] = va;
-        t[48 * 64] = vb;
+        t[48 * CH] = vb;
       }
     }
   }
@@ -346,12 +367,12 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   {
     const int ch = 32 * wn + mi;
     const int lrow = 96 * wm + 48 * g;                               // body a = rows lrow.., body b = lrow + 24..; (row>>1)&1 == (j>>1)&1
-    float* t0 = T + lrow * 64 + (((ch >> 2) ^ 0) << 2) + (ch & 3);
-    float* t1 = T + lrow * 64 + (((ch >> 2) ^ 1) << 2) + (ch & 3);
+    float* t0 = T + lrow * CH + (((ch >> 2) ^ 0) << 2) + (ch & 3);
+    float* t1 = T + lrow * CH + (((ch >> 2) ^ 1) << 2) + (ch & 3);
     gcn_mix2(dp, gp, L.Aoff, L.relu != 0, [&](int j, float s0, float s1) {
       float* t = ((j >> 1) & 1) ? t1 : t0;
-      t[j * 64] = s0;
-      t[(24 + j) * 64] = s1;
+      t[j * CH] = s0;
+      t[(24 + j) * CH] = s1;
     });
   }
 #endif
@@ -369,12 +390,16 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   STAMP(11);
   {
     const int p = (urow >> 1) & 1;
-    const float* src = T + urow * 64;
+    const float* src = T + urow * CH;
     const int o0 = ((2 * uc) ^ p) << 2, o1 = ((2 * uc + 1) ^ p) << 2;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const f32x4 v0 = *(const f32x4*)(src + 32 * i * 64 + o0);
-      const f32x4 v1 = *(const f32x4*)(src + 32 * i * 64 + o1);
+      // (wide tile: 16 work items per row span two 256-byte bank windows; items 8..15 read their halves in the opposite order so
+      //  that a ds_read_b128 lane group still touches 16 distinct 16-byte slots)
+      const bool flip = (CH == 128) && (uc & 8);
+      const f32x4 va = *(const f32x4*)(src + 32 * i * CH + (flip ? o1 : o0));
+      const f32x4 vb = *(const f32x4*)(src + 32 * i * CH + (flip ? o0 : o1));
+      const f32x4 v0 = flip ? vb : va, v1 = flip ? va : vb;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (RES) {
         const half8 h = __builtin_bit_cast(half8, rh[i]), l = __builtin_bit_cast(half8, rl[i]);
@@ -401,16 +426,16 @@ __device__ __forceinline__ void f16r_tile(float* lds, const half_t* __restrict__
   STAMP(3); STAMPC(7);
 }
 
-template <int PASSES, bool RES, bool OUT_SPLIT>
-__global__ __launch_bounds__(256, 2) void gcn_hidden_f16r_kernel(const half_t* __restrict__ X, LayerDev L,
-                                                                  const half_t* __restrict__ Res, float* __restrict__ Y,
-                                                                  int m_tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * RSTG];   // 80 KiB, the only LDS object
-  const int n_tiles = L.N / 64;
+template <int PASSES, bool RES, bool OUT_SPLIT, int NWN>
+__global__ __launch_bounds__(128 * NWN, 2) void gcn_hidden_f16r_kernel(const half_t* __restrict__ X, LayerDev L,
+                                                                        const half_t* __restrict__ Res, float* __restrict__ Y,
+                                                                        int m_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Shape<NWN>::STG];   // 80 KiB (112 KiB wide), the only LDS object
+  const int n_tiles = L.N / Shape<NWN>::CH;
   const int total = m_tiles * n_tiles;
   const int bid = blockIdx.x;
   const int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;   // XCD-aware tile order
-  f16r_tile<PASSES, kStoreAux, 0>(lds, X, L, Res, Y, lin / n_tiles, lin % n_tiles, RES, OUT_SPLIT, [] {});
+  f16r_tile<PASSES, kStoreAux, 0, NWN>(lds, X, L, Res, Y, lin / n_tiles, lin % n_tiles, RES, OUT_SPLIT, [] {});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -440,9 +465,9 @@ struct ChainArgs {
   int stagger_ticks;        // experiment (EHM_CHAIN_STAGGER, 100 MHz ticks): delay of the upper half of the grid at start
 };
 
-template <int PASSES, int AUX, int IN_AUX>
-__global__ __launch_bounds__(256, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * RSTG];   // 80 KiB, the only LDS object
+template <int PASSES, int AUX, int IN_AUX, int NWN>
+__global__ __launch_bounds__(128 * NWN, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Shape<NWN>::STG];   // 80 KiB (112 KiB wide), the only LDS object
   const int tid = threadIdx.x;
   const unsigned int q = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (unsigned int)a.nq;   // HW_REG_XCC_ID[3:0] -> my queue
   const int cm = (a.m_tiles - (int)q + a.nq - 1) / a.nq;   // row tiles of this queue: q, q + nq, ...
@@ -467,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
     const half_t* X = odd ? a.buf[1] : a.buf[cur];
     const half_t* Res = odd ? a.buf[cur] : nullptr;
     float* Y = (float*)(odd ? a.buf[nxt] : a.buf[1]);
-    f16r_tile<PASSES, AUX, IN_AUX>(lds, X, a.layers[layer], Res, Y, m_tile, n_tile, odd, layer != a.nl - 1, [&] {
+    f16r_tile<PASSES, AUX, IN_AUX, NWN>(lds, X, a.layers[layer], Res, Y, m_tile, n_tile, odd, layer != a.nl - 1, [&] {
       if (layer == 0) return;                            // (block-uniform)
       if (tid == 0) {
         const unsigned int* f = a.done + (size_t)(layer - 1) * a.m_tiles + m_tile;
@@ -499,20 +524,20 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
   }
 }
 
-template <int PASSES>
+template <int PASSES, int NWN>
 int launch(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_split, hipStream_t st) {
   const int m_tiles = (int)(rows_pad / 192);
-  const int blocks = m_tiles * (h->hid / 64);
+  const int blocks = m_tiles * (h->hid / Shape<NWN>::CH);
   const LayerDev& L = h->hidden[layer];
   const half_t* x = (const half_t*)X;
   const half_t* r = (const half_t*)residual;
   float* y = (float*)out;
   if (residual) {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, true, true>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, true, false>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, true, true, NWN>), dim3(blocks), dim3(128 * NWN), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, true, false, NWN>), dim3(blocks), dim3(128 * NWN), 0, st, x, L, r, y, m_tiles);
   } else {
-    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, false, true>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
-    else hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, false, false>), dim3(blocks), dim3(256), 0, st, x, L, r, y, m_tiles);
+    if (out_split) hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, false, true, NWN>), dim3(blocks), dim3(128 * NWN), 0, st, x, L, r, y, m_tiles);
+    else hipLaunchKernelGGL((gcn_hidden_f16r_kernel<PASSES, false, false, NWN>), dim3(blocks), dim3(128 * NWN), 0, st, x, L, r, y, m_tiles);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -536,7 +561,8 @@ int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad,
     ehm_set_error("chained split-f16 convs need hid %% 64 == 0, K >= 64, an even number of hidden convs and rows_pad %% 192 == 0");
     return EHM_EINVAL;
   }
-  const int m_tiles = (int)(rows_pad / 192), n_tiles = h->hid / 64;
+  const bool wide = h->wide_tile && h->hid % 128 == 0;            // 8-wave 192 x 128 blocks, one per CU
+  const int m_tiles = (int)(rows_pad / 192), n_tiles = h->hid / (wide ? 128 : 64);
   const size_t need = 8 + (size_t)nl * m_tiles + 8;   // tickets | done | err, (stamps build: total spins, waits that spun)
   if (h->chain_sync_words < need) {                    // grows on the first call of a new shape; never inside a steady loop
     if (h->chain_sync) EHM_HIP(hipFree(h->chain_sync));
@@ -557,7 +583,7 @@ int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad,
   h->chain_err_off = 8 + (size_t)nl * m_tiles;
   a.err = h->chain_sync + h->chain_err_off;
   const int total = nl * m_tiles * n_tiles;
-  int blocks = 2 * ehm_num_cus();                      // what is co-resident (80 KiB LDS per block)
+  int blocks = (wide ? 1 : 2) * ehm_num_cus();         // what is co-resident (80 KiB LDS per block, 112 KiB wide)
   if (blocks > total) blocks = total;
   a.nq = ehm_num_cus() / 32;
   if (a.nq < 1) a.nq = 1;
@@ -566,10 +592,12 @@ int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad,
   a.flags = mode == 1 ? 1 : 0;
   a.stagger_ticks = getenv("EHM_CHAIN_STAGGER") ? atoi(getenv("EHM_CHAIN_STAGGER")) : 0;
   if (h->precision == EHM_PREC_F16X3) {
-    if (mode == 0) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 16>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 0>), dim3(blocks), dim3(256), 0, st, a);
+    if (wide) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 16, 4>), dim3(blocks), dim3(512), 0, st, a);
+    else if (mode == 0) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 16, 2>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 16, 0, 2>), dim3(blocks), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 16, 16>), dim3(blocks), dim3(256), 0, st, a);
+    if (wide) hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 16, 16, 4>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 16, 16, 2>), dim3(blocks), dim3(256), 0, st, a);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -589,6 +617,10 @@ int ehm_gcn_hidden_f16r_impl(const ehm_gcn* h, int layer, const void* X, const v
     ehm_set_error("register-pipelined split-f16 conv needs hid %% 64 == 0 and K >= 64");
     return EHM_EINVAL;
   }
-  if (h->precision == EHM_PREC_F16X3) return launch<3>(h, layer, X, residual, out, rows_pad, out_split, st);
-  return launch<1>(h, layer, X, residual, out, rows_pad, out_split, st);
+  if (h->wide_tile && h->hid % 128 == 0) {
+    if (h->precision == EHM_PREC_F16X3) return launch<3, 4>(h, layer, X, residual, out, rows_pad, out_split, st);
+    return launch<1, 4>(h, layer, X, residual, out, rows_pad, out_split, st);
+  }
+  if (h->precision == EHM_PREC_F16X3) return launch<3, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
+  return launch<1, 2>(h, layer, X, residual, out, rows_pad, out_split, st);
 }

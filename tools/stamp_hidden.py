@@ -13,7 +13,7 @@ prec = sys.argv[1]
 dev = torch.device("cuda:0")
 model = build_synthetic_model(dev, 0); model.gcn_precision = prec
 L = _lib.lib(); h = model.fused_sampler.gcn()
-B = 256; hid = 1024; tile = 192
+B = int(os.environ.get("EHM_B", "256")); hid = 1024; tile = 192
 rows_pad = (2 * B * 24 + tile - 1) // tile * tile
 X = torch.randn(rows_pad, hid, device=dev); X2 = torch.empty_like(X); Y1 = torch.empty_like(X); Y2 = torch.empty_like(X)
 _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, 32, None))
@@ -21,7 +21,8 @@ for _ in range(5):
     _lib.check(L.ehm_gcn_hidden_layer(h, 0, X2.data_ptr(), None, Y1.data_ptr(), rows_pad, None))
     _lib.check(L.ehm_gcn_hidden_layer(h, 1, Y1.data_ptr(), X2.data_ptr(), Y2.data_ptr(), rows_pad, None))
 torch.cuda.synchronize()
-dbg = torch.zeros(1024 * 16, dtype=torch.int64, device=dev)
+nblk = rows_pad // 192 * 16
+dbg = torch.zeros(max(nblk, 1024) * 16, dtype=torch.int64, device=dev)
 fn = L.ehm_dbg_set
 fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
 assert fn(dbg.data_ptr()) == 0
@@ -30,7 +31,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "nores":
 else:
     _lib.check(L.ehm_gcn_hidden_layer(h, 1, Y1.data_ptr(), X2.data_ptr(), Y2.data_ptr(), rows_pad, None))
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(1024, 16).astype(np.int64)
+d = dbg.cpu().numpy().reshape(-1, 16)[:nblk].astype(np.int64)
 t0 = d[:, 0].min()
 rt = (d[:, :4] - t0) / 100.0   # us (100 MHz)
 print("kernel span us:", rt[:, 3].max())

@@ -132,14 +132,18 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinArgs p) {
     }
   }
 
-  // ---- epilogue: lane = output column, registers = rows ----
-  float (*smax)[LBN] = (float (*)[LBN])lds;          // column-max exchange re-uses the staging buffers
-  if (p.colmax) __syncthreads();                      // every wave is done reading the last K tile
+  // ---- epilogue.  Accumulator layout: lane = output column, registers = rows.  Bias / ReLU / the per-group column maximum are
+  //      taken there; the values then cross a float [128][128] LDS tile so that the rows leave as 16-byte X2 stores (8 hi halves,
+  //      8 lo halves) - with K = 256..512 a block has only 8-16 K tiles, and 64 dword stores per lane were most of its life time.
+  __syncthreads();                                    // every wave is done reading the last K tile: the stages become the tile
+  float* T = lds;
   const int group = (int)(m0 / p.rows_per_group);
   const int row_in_group0 = (int)(m0 % p.rows_per_group);
+  float cmaxs[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int n = n0 + 64 * wn + 32 * u + mi;
+    const int col = 64 * wn + 32 * u + mi;
+    const int n = n0 + col;
     float add = p.bias ? p.bias[n] : 0.f;
     if (p.gbias) add += p.gbias[(size_t)group * p.N + n];
     float cmax = -3.4e38f;
@@ -150,16 +154,43 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinArgs p) {
         const int row = 64 * wm + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
         float v = fmaf(acc[t][u][r], p.inv_scale, add);
         if (p.relu_out) v = fmaxf(v, 0.f);
-        if (p.Y) split_store_pair(p.Y, m0 + row, n, p.N, v);
+        T[row * LBN + col] = v;
         if (row_in_group0 + row < p.valid_rows_per_group) cmax = fmaxf(cmax, v);
       }
     }
-    if (p.colmax) {
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-      if (g == 0) smax[wm][64 * wn + 32 * u + mi] = cmax;
+    cmaxs[u] = fmaxf(cmax, __shfl_xor(cmax, 32));
+  }
+  __syncthreads();
+  if (p.Y) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // work item = (row, 8 consecutive columns): 128 x 16 items, 8 per thread; items 8..15 of a row read their two 16-byte halves in
+    // the opposite order, so that every ds_read_b128 lane group touches 16 distinct 16-byte slots of the 256-byte bank window
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int uu = tid + 256 * i, row = uu >> 4, c8 = uu & 15;
+      const float* src = T + row * LBN + 8 * c8;
+      const int flip = c8 >> 3;
+      const f32x4 va = *(const f32x4*)(src + 4 * flip), vb = *(const f32x4*)(src + 4 * (1 - flip));
+      const f32x4 v0 = flip ? vb : va, v1 = flip ? va : vb;
+      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      half8 hh, ll;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
+        hh[k] = (half_t)c;
+        ll[k] = (half_t)(v[k] - (float)hh[k]);
+      }
+      half_t* dst = p.Y + split_off<32>(m0 + row, n0 + 8 * c8, p.N);   // 8 | 32: the eight hi halves are contiguous, the lo halves 32 further
+      *(u32x4*)dst = __builtin_bit_cast(u32x4, hh);
+      *(u32x4*)(dst + 32) = __builtin_bit_cast(u32x4, ll);
     }
   }
   if (p.colmax) {
+    __syncthreads();                                  // the tile has been read: its memory carries the column-max exchange now
+    float (*smax)[LBN] = (float (*)[LBN])lds;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (g == 0) smax[wm][64 * wn + 32 * u + mi] = cmaxs[u];
     __syncthreads();
     if (tid < LBN) atomic_max_float(p.colmax + (size_t)group * p.N + n0 + tid, fmaxf(smax[0][tid], smax[1][tid]));
   }

@@ -150,6 +150,131 @@ __global__ __launch_bounds__(1024) void nearest_kernel(const float* __restrict__
   }
 }
 
+// The same proxy through a uniform grid (exact): the hinge relu(tau - d) is zero unless some body vertex lies within tau of the
+// point, and with cells of edge >= tau such a vertex sits in one of the 27 cells around the point's cell - so only those are
+// searched (~100 distances instead of 6890).  Points without a vertex in reach contribute exactly nothing in both versions; ties
+// resolve to the lowest vertex index like torch.min.  One block per body: vertices (SoA), cell offsets and the cell-sorted vertex
+// list live in LDS; the block then walks all selected points of its body.
+constexpr int kMaxCells = 4096;
+__global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restrict__ verts, const float* __restrict__ scene,
+                                                            const int* __restrict__ idx, const int* __restrict__ count,
+                                                            const float* __restrict__ bbox, float* __restrict__ loss,
+                                                            float* __restrict__ gverts, int V, int N, float tau) {
+  extern __shared__ __attribute__((aligned(16))) float sv[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cnt = count[b];
+  if (cnt == 0) return;                                  // block-uniform
+  const int Vp = (V + 3) & ~3;
+  float* sx = sv;
+  float* sy = sv + Vp;
+  float* sz = sv + 2 * Vp;
+  int* cstart = (int*)(sv + 3 * Vp);                     // [kMaxCells + 1] exclusive offsets
+  int* cursor = cstart + kMaxCells + 1;                  // [kMaxCells]
+  unsigned short* order = (unsigned short*)(cursor + kMaxCells);   // [Vp] vertex ids sorted by cell
+  __shared__ int part[1024];
+  __shared__ float wred[16];
+
+  float lo[3], ext[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { lo[c] = bbox[b * 6 + c]; ext[c] = fmaxf(bbox[b * 6 + 3 + c] - lo[c], 1e-6f); }
+  float h = fmaxf(tau, cbrtf(ext[0] * ext[1] * ext[2] / 3000.f));
+  int nx, ny, nz;
+  for (;;) {                                             // uniform: every thread runs the same few iterations
+    nx = (int)(ext[0] / h) + 1; ny = (int)(ext[1] / h) + 1; nz = (int)(ext[2] / h) + 1;
+    if ((long long)nx * ny * nz <= kMaxCells) break;
+    h *= 1.1f;
+  }
+  const int nc = nx * ny * nz;
+  const float ih = 1.f / h;
+  auto cell_of = [&](float x, float y, float z, int& cx, int& cy, int& cz) {
+    cx = min(nx - 1, max(0, (int)((x - lo[0]) * ih)));
+    cy = min(ny - 1, max(0, (int)((y - lo[1]) * ih)));
+    cz = min(nz - 1, max(0, (int)((z - lo[2]) * ih)));
+  };
+  for (int v = tid; v < V; v += 1024) {
+    const float* p = verts + ((size_t)b * V + v) * 3;
+    sx[v] = p[0]; sy[v] = p[1]; sz[v] = p[2];
+  }
+  for (int c = tid; c < nc; c += 1024) cursor[c] = 0;
+  __syncthreads();
+  for (int v = tid; v < V; v += 1024) {                  // histogram
+    int cx, cy, cz;
+    cell_of(sx[v], sy[v], sz[v], cx, cy, cz);
+    atomicAdd(&cursor[cx + nx * (cy + ny * cz)], 1);
+  }
+  __syncthreads();
+  {                                                      // exclusive scan of up to 4096 counts: 4 per thread + block scan
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = 4 * tid + i; loc[i] = c < nc ? cursor[c] : 0; sum += loc[i]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    int run = part[tid] - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = 4 * tid + i; if (c < nc) { cstart[c] = run; run += loc[i]; } }
+    if (tid == 1023) cstart[nc] = part[1023];
+  }
+  __syncthreads();
+  for (int c = tid; c < nc; c += 1024) cursor[c] = cstart[c];
+  __syncthreads();
+  for (int v = tid; v < V; v += 1024) {                  // scatter (order inside a cell is arbitrary; the search below does not care)
+    int cx, cy, cz;
+    cell_of(sx[v], sy[v], sz[v], cx, cy, cz);
+    order[atomicAdd(&cursor[cx + nx * (cy + ny * cz)], 1)] = (unsigned short)v;
+  }
+  __syncthreads();
+
+  float contrib = 0.f;
+  for (int k = tid; k < cnt; k += 1024) {
+    const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + k]) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    int cx, cy, cz;
+    cell_of(px, py, pz, cx, cy, cz);
+    float best = 3.4e38f;
+    int bi = 0x7fffffff;
+    for (int dz = max(cz - 1, 0); dz <= min(cz + 1, nz - 1); ++dz)
+      for (int dy = max(cy - 1, 0); dy <= min(cy + 1, ny - 1); ++dy)
+        for (int dx = max(cx - 1, 0); dx <= min(cx + 1, nx - 1); ++dx) {
+          const int c = dx + nx * (dy + ny * dz);
+          for (int i = cstart[c]; i < cstart[c + 1]; ++i) {
+            const int v = order[i];
+            const float ex = px - sx[v], ey = py - sy[v], ez = pz - sz[v];
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < best || (d2 == best && v < bi)) { best = d2; bi = v; }   // first minimum by vertex index, like torch.min
+          }
+        }
+    if (bi != 0x7fffffff) {
+      const float d = sqrtf(best + 1e-12f);
+      const float hh = tau - d;
+      if (hh > 0.f) {
+        contrib += hh * hh;
+        const float s = 2.f * hh / d;                     // d(h^2)/dv = 2h (p - v)/d
+        float* g = gverts + ((size_t)b * V + bi) * 3;
+        atomicAdd(g + 0, s * (px - sx[bi]));
+        atomicAdd(g + 1, s * (py - sy[bi]));
+        atomicAdd(g + 2, s * (pz - sz[bi]));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
+  if ((tid & 63) == 0) wred[tid >> 6] = contrib;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += wred[w];
+    if (s != 0.f) atomicAdd(loss + b, s);
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------ LBS backward
 // thread = vertex, 8 bodies per block (same tiling as the forward skin_kernel).  In: d loss/d verts (gv, overwritten
 // in place by d loss/d posed-rest-vertex).  Out: gA[b][24][12] += sum_v w[v,j] [gv (x) vp | gv]  (LDS, then global atomics)
@@ -524,8 +649,19 @@ int collision_impl(const float* verts, const float* scene, float* loss, float* g
     ehm_set_error("collision proxy: %d vertices do not fit the 160 KiB LDS", V);
     return EHM_EINVAL;
   }
-  hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)ceil_div(N, 1024), B), dim3(1024), lds, st, verts, scene, s.idx, s.count, loss,
-                     gverts, V, N, tau);
+  const size_t lds_grid = lds + (size_t)(2 * kMaxCells + 1) * sizeof(int) + (size_t)Vp * sizeof(unsigned short) + 16;
+  static const bool use_grid = !(getenv("EHM_COLL_GRID") && atoi(getenv("EHM_COLL_GRID")) == 0);
+  if (use_grid && V <= 65535 && lds_grid <= 160 * 1024 - 4608) {
+    static bool attr2 = false;
+    if (!attr2) {
+      EHM_HIP(hipFuncSetAttribute((const void*)nearest_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(nearest_grid_kernel, dim3(B), dim3(1024), lds_grid, st, verts, scene, s.idx, s.count, s.bbox, loss, gverts, V, N, tau);
+  } else {
+    hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)ceil_div(N, 1024), B), dim3(1024), lds, st, verts, scene, s.idx, s.count, loss,
+                       gverts, V, N, tau);
+  }
   EHM_LAUNCH_CHECK();
   return 0;
 }

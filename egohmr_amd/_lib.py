@@ -78,7 +78,7 @@ class StepCoefs(C.Structure):
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("lowprec_steps", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -163,8 +163,11 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   EHM_HIP(hipMemcpyAsync(w.x_cur, noise, n * sizeof(float), hipMemcpyDeviceToDevice, st));   // x_T, :476-478
 
   int rc = 0;
+  const int base_prec = ehm_gcn_get_precision(gcn);
+  const int lowprec = base_prec == 1 /* f16x3 */ ? d->lowprec_steps : 0;
   for (int k = 0; k < d->num_steps && rc == 0; ++k) {
     const ehm_step_coefs& c = steps[k];
+    if (lowprec > 0) ehm_gcn_set_precision(gcn, k < lowprec ? 2 : base_prec);   // host-side kernel choice only; same X2 buffers
     const bool last = k == d->num_steps - 1;
     if (trace) EHM_HIP(hipMemcpyAsync(trace + (int64_t)k * n, w.x_cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257) ----
@@ -193,5 +196,6 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
         rc = ehm_ddpm_step(w.x_cur, x0_final, eps, grad, dst, c.coef1, c.coef2, c.log_variance, c.nonzero, c.grad_scale, n, st);
     }
   }
+  if (lowprec > 0) ehm_gcn_set_precision(gcn, base_prec);
   return rc;
 }

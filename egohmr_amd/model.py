@@ -211,6 +211,9 @@ class EgoHMR(nn.Module):
         self.backbone_matrix_core = True   # ResNet-50 blocks as split-f16 implicit GEMMs (csrc/conv.hip); False = library convs + ehm_bias_act
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
+        # precision schedule: None = every step in gcn_precision; k = only the LAST k executed steps of a fused
+        # sampling loop run in gcn_precision ('f16x3'), the earlier ones on plain f16 operands
+        self.f16x3_last_steps = None
         self.fused_sampler = FusedSampler(self)
         self.to(dev)
         self.eval()
@@ -560,7 +563,8 @@ class FusedSampler:
         tvecs = self.timestep_vectors(tmap)                                            # [T,2,hid]
         desc = _lib.SampleDesc(B=B, passes=2 if m.diffuse_fuse else 1, num_steps=T, ddim=int(ddim),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
-                               guide_denom=float(B) if m.guide_reduction == "mean" else 1.0, tau=m.collision_tau)
+                               guide_denom=float(B) if m.guide_reduction == "mean" else 1.0, tau=m.collision_tau,
+                               lowprec_steps=max(0, min(T, T - int(m.f16x3_last_steps))) if m.f16x3_last_steps is not None else 0)
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:
             raise _lib.EgoHMRHipError(f"ehm_sample_workspace_bytes rejected the descriptor (rc={nbytes})")

@@ -264,6 +264,8 @@ typedef struct {
   int num_scene_points; /* N (guidance only)                                        */
   float guide_denom;  /* B for COAP-style loss.mean(), 1 for VolSMPL-style sum()    */
   float tau;          /* collision proxy contact distance                          */
+  int lowprec_steps;  /* precision schedule: the FIRST lowprec_steps executed steps run the hidden convs on plain f16 operands
+                         (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */
 } ehm_sample_desc;
 
 /* GaussianDiffusion.p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508, :618-718)

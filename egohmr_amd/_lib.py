@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EHM_LIB_PATH") or os.path.join(_HERE, "libegohmr_hip.so")   # EHM_LIB_PATH: A/B a second build (experiments)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_f16.hip", "gcn_f16p.hip", "gcn_f16r.hip", "linear.hip", "conv.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -98,7 +98,7 @@ PROTOTYPES = {
     "ehm_gcn_row_tile": (_I, []),
     "ehm_gcn_set_precision": (_I, [_P, _I]),
     "ehm_gcn_get_precision": (_I, [_P]),
-    "ehm_gcn_set_tile_override": (_I, [_P, _I]),
+    "ehm_gcn_reserve": (_I, [_P, _I, _I]),
     "ehm_gcn_activation_group": (_I, [_P]),
     "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _I, _P]),
     "ehm_gcn_unpack_activations": (_I, [_P, _P, _L, _I, _I, _P]),

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_kernel(const float* __restr
 // input conv with the step-invariant projections hoisted (see ehm_gcn_input_layer in the header)
 // one wave = one virtual body x 64 channels; 4 waves per block = 4 channel groups
 // ------------------------------------------------------------------------------------------------
-template <bool SPLIT_OUT, int G>
+template <int OUT>   // 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows
 __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict__ h_img, const float* __restrict__ h_oth,
                                                         const uint8_t* __restrict__ vis, const float* __restrict__ x,
                                                         const float* __restrict__ Wx, const float* __restrict__ tvec,
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
     const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     const size_t row = (size_t)vb * kJ + j;
-    if (SPLIT_OUT) {
+    if (OUT != 0) {
       half8 hh, ll;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -325,9 +325,13 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
         hh[k] = (half_t)c;
         ll[k] = (half_t)(v[k] - (float)hh[k]);
       }
-      half_t* p = (half_t*)Y + split_off<G>(row, nb + c8, N);   // 8 | G: the eight hi halves are contiguous, the lo halves G further
-      *(u32x4*)p = __builtin_bit_cast(u32x4, hh);
-      *(u32x4*)(p + G) = __builtin_bit_cast(u32x4, ll);
+      if (OUT == 1) {
+        half_t* p = (half_t*)Y + split_off<32>(row, nb + c8, N);   // the eight hi halves are contiguous, the lo halves 32 further
+        *(u32x4*)p = __builtin_bit_cast(u32x4, hh);
+        *(u32x4*)(p + 32) = __builtin_bit_cast(u32x4, ll);
+      } else {
+        *(u32x4*)((half_t*)Y + row * (size_t)N + nb + c8) = __builtin_bit_cast(u32x4, hh);
+      }
     } else {
       float* p = Y + row * (size_t)N + nb + c8;
       *(f32x4*)p = v0;
@@ -348,6 +352,7 @@ constexpr int OUT_ROWS_PER_BLOCK = 16;
 // permutation applied to both operands, which a sum does not see - and the matching float4 of the 12 x K weights (48 KiB, L2 hits).
 // The four partial 16x16 tiles meet in 4 KiB of LDS.  HBM-bound by design: every activation row is read once, 16-byte loads,
 // 4 x 64 B per row and instruction.  (The previous VALU version re-read the weights from LDS for every row: 39 us per launch.)
+template <bool HALF_IN>   // HALF_IN: X holds f16 rows (the 'f16' mode's last hidden conv), converted on load
 __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restrict__ X, OutDev O, float* __restrict__ hs, int64_t rows) {
   __shared__ float part[4][16][16];
   const int K = O.K, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -355,12 +360,20 @@ __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restric
   const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK;
   const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
   const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: whole 16-k groups)
+  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
   const float* xr = X + r * K + (size_t)wave * kq + 4 * q;
+  const half_t* xh = (const half_t*)X + r * K + (size_t)wave * kq + 4 * q;
   const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 4 * q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: the dependent-accumulator latency (40 cyc) exceeds the issue interval
 #pragma unroll 4
   for (int k = 0; k < kq; k += 16) {                                 // 16 k = four MFMA steps per float4 pair
-    const f32x4 xv = *(const f32x4*)(xr + k);
+    f32x4 xv;
+    if (HALF_IN) {
+      const half4_t hv = *(const half4_t*)(xh + k);
+      xv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    } else {
+      xv = *(const f32x4*)(xr + k);
+    }
     f32x4 wv = *(const f32x4*)(wr + k);
     if (row >= 12) wv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -413,37 +426,23 @@ __global__ __launch_bounds__(192) void gcn_out_mix_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-// [S*Aoff | S*I] (rows = output joint, 48 columns: 24 neighbour joints of the off-diagonal branch, then the identity that
-// carries the diagonal branch through the same MFMA) as v_mfma_f32_32x32x16_f16 A fragments: lane l holds row l&31 (zero for
-// rows >= 24), columns 16 s + 8 (l>>5) .. +7 of k-step s; hi and lo halves; S = power of two with max|Aoff| * S in [512, 1024].
-__global__ void pack_aoff_frag_kernel(const float* __restrict__ Aoff, half8* __restrict__ out) {
-  const int lane = threadIdx.x;
-  float amax = 0.f;
-  for (int i = 0; i < kJ * kJ; ++i) amax = fmaxf(amax, fabsf(Aoff[i]));
-  int e = 0;
-  if (amax > 0.f && amax < 3.0e38f) {
-    (void)frexpf(amax, &e);     // amax = m * 2^e, m in [0.5, 1)
-    e = 10 - e;
-    if (e > 15) e = 15;         // S itself is an operand (the identity block): keep it a normal f16
-    if (e < -14) e = -14;
-  }
-  const float S = ldexpf(1.f, e);
-  const int i = lane & 31;
+// [Aoff | I] (rows = output joint, 48 columns: 24 neighbour joints of the off-diagonal branch, then the identity that carries the
+// diagonal branch through the same MFMA) as v_mfma_f32_32x32x16_f16 A fragments: lane l holds row l&31 (zero for rows >= 24),
+// columns 16 s + 8 (l>>5) .. +7 of k-step s.
+__global__ void pack_aoff_half_kernel(const float* __restrict__ Aoff, half8* __restrict__ out) {
+  const int lane = threadIdx.x, i = lane & 31;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    half8 hi, lo;
+    half8 v;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int kk = 16 * s + 8 * (lane >> 5) + c;
-      float v = 0.f;
-      if (i < kJ) v = kk < kJ ? Aoff[i * kJ + kk] * S : (kk - kJ == i ? S : 0.f);
-      hi[c] = (half_t)v;
-      lo[c] = (half_t)(v - (float)hi[c]);
+      float x = 0.f;
+      if (i < kJ) x = kk < kJ ? Aoff[i * kJ + kk] : (kk - kJ == i ? 1.f : 0.f);
+      v[c] = (half_t)x;
     }
-    out[(2 * s + 0) * 64 + lane] = hi;
-    out[(2 * s + 1) * 64 + lane] = lo;
+    out[s * 64 + lane] = v;
   }
-  if (lane == 0) ((float*)(out + 6 * 64))[0] = 1.f / S;
 }
 
 static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, float*& cursor, bool with_w, hipStream_t st) {
@@ -456,8 +455,8 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
     cursor += (size_t)2 * K * N;
     L.Ws = (half_t*)cursor;
     cursor += (size_t)2 * K * N;       // X2 format has the same byte size as float32
-    L.Ws16 = (half_t*)cursor;
-    cursor += (size_t)2 * K * N;
+    L.Wh = (half_t*)cursor;
+    cursor += (size_t)K * N;           // 2*K*N halves
     L.Ds = cursor;   cursor += (size_t)kJ * N;
     L.M1s = cursor;  cursor += (size_t)kJ * N;
   }
@@ -465,7 +464,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   L.M1 = cursor;     cursor += (size_t)kJ * N;
   L.shift = cursor;  cursor += N;
   L.Aoff = cursor;   cursor += kJ * kJ;
-  L.AoffF = cursor;  cursor += 1600;
+  L.AoffH = (const half_t*)cursor;  cursor += 768;     // 3 x 64 x 8 halves
   if (with_w) {
     dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(K, 32), 2);
     hipLaunchKernelGGL(pack_w_kernel, grid, dim3(256), 0, st, p.W, L.Wp, K, N);
@@ -473,7 +472,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   const int threads = 1024;  // block 0 also fills the 24x24 adjacency (576 <= 1024 threads)
   hipLaunchKernelGGL(pack_epilogue_kernel, dim3((unsigned)ceil_div(N, threads)), dim3(threads), 0, st, adj, p, L.D, L.M1,
                      L.shift, L.Aoff);
-  hipLaunchKernelGGL(pack_aoff_frag_kernel, dim3(1), dim3(64), 0, st, L.Aoff, (half8*)L.AoffF);
+  hipLaunchKernelGGL(pack_aoff_half_kernel, dim3(1), dim3(64), 0, st, L.Aoff, (half8*)L.AoffH);
   EHM_LAUNCH_CHECK();
   if (with_w) {
     // power-of-two weight scale that keeps |W|*scale well inside f16 and pushes the lo parts out of the subnormal range
@@ -495,8 +494,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
     L.w_scale = ldexpf(1.f, e);
     hipLaunchKernelGGL(pack_ws_kernel<32>, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws, (size_t)2 * N, K,
                        L.w_scale);
-    hipLaunchKernelGGL(pack_ws_kernel<16>, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws16, (size_t)2 * N, K,
-                       L.w_scale);
+    ehm_pack_half(L.Wp, L.Wh, (size_t)2 * K * N, L.w_scale, st);
     hipLaunchKernelGGL(scale_epilogue_kernel, dim3((unsigned)ceil_div(kJ * N, 256)), dim3(256), 0, st, L.D, L.M1, L.Ds, L.M1s, kJ * N,
                        1.f / L.w_scale);
     EHM_LAUNCH_CHECK();
@@ -516,15 +514,11 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   for (int i = 0; i < num_hidden; ++i) EHM_CHECK_ARG(hidden[i].in_dim == hid_dim && hidden[i].out_dim == hid_dim && hidden[i].W);
   hipStream_t st = (hipStream_t)stream;
   auto* g = new ehm_gcn();
-  if (const char* e = getenv("EHM_F16_STAGING")) g->reg_staging = strcmp(e, "reg") == 0;
-  if (const char* e = getenv("EHM_F16_PERSISTENT")) g->persistent = atoi(e) != 0;
-  if (const char* e = getenv("EHM_F16_PIPELINED")) g->pipelined = atoi(e);
-  if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);
-  if (const char* e = getenv("EHM_F16R_WIDE")) g->wide_tile = atoi(e);
+  if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);   // 0: one launch per hidden conv (debugging aid; bit-identical results)
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
-  const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ + 1600;   // + Aoff MFMA fragments (6 KiB) and 1/S
-  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (6 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
+  const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ + 768;
+  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (5 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
                   12 * (size_t)hid_dim + kJ * 6 + kJ * kJ + 8 + 64;
   if (hipMalloc(&g->arena, floats * sizeof(float)) != hipSuccess) {
     delete g;
@@ -549,9 +543,14 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
         hipMemcpyAsync(g->hidden_dev, g->hidden, sizeof(LayerDev) * num_hidden, hipMemcpyHostToDevice, st) != hipSuccess)
       rc = EHM_ENOMEM;
   }
+  if (rc == 0 && (hipMalloc(&g->chain_sticky, 64) != hipSuccess || hipMemsetAsync(g->chain_sticky, 0, 64, st) != hipSuccess)) rc = EHM_ENOMEM;
   if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
+  if (rc == 0) rc = ehm_gcn_reserve_rows(g, 2 * 256 * kJ);   // the benchmark shape; larger batches grow it on first use (ehm_gcn_reserve)
   if (rc != 0) {
     if (g->hidden_dev) (void)hipFree(g->hidden_dev);
+    if (g->chain_sticky) (void)hipFree(g->chain_sticky);
+    if (g->chain_sync) (void)hipFree(g->chain_sync);
+    if (g->hs) (void)hipFree(g->hs);
     (void)hipFree(g->arena);
     delete g;
     ehm_set_error("ehm_gcn_create: packing kernels failed");
@@ -567,6 +566,7 @@ extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
   if (h->hs) (void)hipFree(h->hs);
   if (h->hidden_dev) (void)hipFree(h->hidden_dev);
   if (h->chain_sync) (void)hipFree(h->chain_sync);
+  if (h->chain_sticky) (void)hipFree(h->chain_sticky);
   delete h;
 }
 
@@ -576,14 +576,11 @@ extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* 
   EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
   dim3 grid((unsigned)(B * passes), (unsigned)ceil_div(h->hid, 256));
   if (h->precision == EHM_PREC_F32)
-    hipLaunchKernelGGL((gcn_input_kernel<false, 32>), grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
-                       out, B, passes);
-  else if (h->pipelined == 1)   // split-f16 modes: the activation matrices travel in the X2 format (same byte size)
-    hipLaunchKernelGGL((gcn_input_kernel<true, 16>), grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
-                       out, B, passes);
-  else
-    hipLaunchKernelGGL((gcn_input_kernel<true, 32>), grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input,
-                       out, B, passes);
+    hipLaunchKernelGGL(gcn_input_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes);
+  else if (h->precision == EHM_PREC_F16X3)   // the activation matrices travel in the X2 split format (same byte size as float32)
+    hipLaunchKernelGGL(gcn_input_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes);
+  else                                       // plain f16 rows
+    hipLaunchKernelGGL(gcn_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes);
   EHM_LAUNCH_CHECK();
   return 0;
 }
@@ -594,8 +591,8 @@ extern "C" int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const
   EHM_CHECK_ARG(layer >= 0 && layer < h->num_hidden);
   EHM_CHECK_ARG(rows_pad > 0 && rows_pad % BM == 0);
   EHM_CHECK_ARG(X != out);
-  if (h->precision != EHM_PREC_F32)   // X / residual in X2 format; output X2 except for the last hidden conv (f32 for the output conv)
-    return ehm_gcn_hidden_f16_impl(h, layer, X, residual, out, rows_pad, layer != h->num_hidden - 1, (hipStream_t)stream);
+  if (h->precision != EHM_PREC_F32)   // X / residual / out in the mode's activation format, except that in mode 1 the last hidden conv writes float32 for the output conv
+    return ehm_gcn_tile_layer_impl(h, layer, X, residual, out, rows_pad, layer == h->num_hidden - 1, (hipStream_t)stream);
   const int m_tiles = (int)(rows_pad / BM);
   const int blocks = m_tiles * (h->hid / BNH);
   if (residual)
@@ -614,8 +611,7 @@ extern "C" int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t ro
   const int nblk = h->num_hidden / 2;
   *result_index = (nblk & 1) ? 2 : 0;
   if (nblk == 0) return 0;
-  if (h->chain && h->precision != EHM_PREC_F32 && h->pipelined == 2 && h->tile_override == 0)
-    return ehm_gcn_hidden_chain_impl(h, (void* const*)bufs, rows_pad, (hipStream_t)stream);
+  if (h->chain && h->precision != EHM_PREC_F32) return ehm_gcn_tile_chain_impl(h, (void* const*)bufs, rows_pad, (hipStream_t)stream);
   int in = 0;
   for (int blk = 0; blk < nblk; ++blk) {     // the same buffer rotation, one launch per conv
     const int y2 = in == 0 ? 2 : 0;
@@ -630,13 +626,39 @@ extern "C" int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t ro
 extern "C" int ehm_gcn_stack_status(ehm_gcn* h, void* stream) {
   EHM_CHECK_ARG(h);
   unsigned int flag = 0;
-  const int rc = ehm_gcn_chain_error(h, (hipStream_t)stream, &flag);
-  if (rc != 0) return rc;
+  if (h->chain_sticky) {
+    EHM_HIP(hipMemcpyAsync(&flag, h->chain_sticky, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    EHM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) EHM_HIP(hipMemsetAsync(h->chain_sticky, 0, sizeof(flag), (hipStream_t)stream));
+  }
   if (flag) {
-    ehm_set_error("ehm_gcn_hidden_stack: a producer wait timed out inside the chained kernel; results are invalid");
+    ehm_set_error("ehm_gcn_hidden_stack: a chained launch since the last status call timed out waiting for a producer tile, or left tiles "
+                  "unproduced (GPU shared / preempted / CU-masked?); the results of that sampling loop are invalid - re-run, or set EHM_F16_CHAIN=0");
     return EHM_EIO;
   }
   return 0;
+}
+
+int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad) {
+  if (rows_pad <= h->reserved_rows) return 0;
+  const size_t need = 8 + (size_t)(h->num_hidden > 0 ? h->num_hidden : 1) * (size_t)ceil_div(rows_pad, BM) + 8;
+  if (h->chain_sync) EHM_HIP(hipFree(h->chain_sync));
+  h->chain_sync = nullptr;
+  h->chain_sync_words = 0;
+  EHM_HIP(hipMalloc(&h->chain_sync, need * sizeof(unsigned int)));
+  h->chain_sync_words = need;
+  if (h->hs) EHM_HIP(hipFree(h->hs));
+  h->hs = nullptr;
+  h->hs_rows = 0;
+  EHM_HIP(hipMalloc(&h->hs, (size_t)round_up(rows_pad, 4096) * 12 * sizeof(float)));
+  h->hs_rows = round_up(rows_pad, 4096);
+  h->reserved_rows = rows_pad;
+  return 0;
+}
+
+extern "C" int ehm_gcn_reserve(ehm_gcn* h, int max_bodies, int passes) {
+  EHM_CHECK_ARG(h && max_bodies > 0 && (passes == 1 || passes == 2));
+  return ehm_gcn_reserve_rows(h, round_up((int64_t)max_bodies * passes * kJ, BM));
 }
 
 extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* vis, float* x0, int B, int passes,
@@ -644,15 +666,16 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
   EHM_CHECK_ARG(h && X && x0);
   EHM_CHECK_ARG(B > 0 && (passes == 1 || (passes == 2 && vis)));
   const int64_t rows = (int64_t)passes * B * kJ;
-  if (rows > h->hs_rows) {      // [rows,12] scratch of the two-kernel output conv; grows on first use of a larger batch only
-    if (h->hs) (void)hipFree(h->hs);
-    h->hs = nullptr;
-    h->hs_rows = 0;
-    EHM_HIP(hipMalloc(&h->hs, (size_t)round_up(rows, 4096) * 12 * sizeof(float)));
-    h->hs_rows = round_up(rows, 4096);
+  if (rows > h->hs_rows) {      // [rows,12] scratch of the two-kernel output conv: sized by ehm_gcn_create / ehm_gcn_reserve, grown here only
+    const int rc = ehm_gcn_reserve_rows(h, round_up(rows, BM));   // for a batch larger than reserved (allocates: call ehm_gcn_reserve before a capture)
+    if (rc != 0) return rc;
   }
-  hipLaunchKernelGGL(gcn_out_dot_kernel, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, X,
-                     h->out, h->hs, rows);
+  if (h->precision == EHM_PREC_F16)
+    hipLaunchKernelGGL(gcn_out_dot_kernel<true>, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, X, h->out,
+                       h->hs, rows);
+  else
+    hipLaunchKernelGGL(gcn_out_dot_kernel<false>, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, X, h->out,
+                       h->hs, rows);
   hipLaunchKernelGGL(gcn_out_mix_kernel, dim3(B), dim3(192), 0, (hipStream_t)stream, h->hs, h->out, vis, x0, B, passes);
   EHM_LAUNCH_CHECK();
   return 0;
@@ -667,9 +690,4 @@ extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
   return 0;
 }
 extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
-extern "C" int ehm_gcn_activation_group(const ehm_gcn* h) { return h ? (h->pipelined == 1 ? 16 : 32) : EHM_EINVAL; }
-extern "C" int ehm_gcn_set_tile_override(ehm_gcn* h, int mode) {
-  EHM_CHECK_ARG(h && mode >= 0 && mode <= 11);
-  h->tile_override = mode;
-  return 0;
-}
+extern "C" int ehm_gcn_activation_group(const ehm_gcn* h) { return h ? (h->precision == EHM_PREC_F16 ? 0 : 32) : EHM_EINVAL; }

@@ -14,8 +14,8 @@ constexpr int STAGE = A_TILE + B_TILE; // 10240 floats = 40 KiB
 
 struct LayerDev {
   float* Wp;     // [N/64][128][K]   packed W0|W1 columns, K contiguous
-  half_t* Ws;    // same tiles in split-f16 format X2<32> (see gcn_f16.hip), values scaled by w_scale
-  half_t* Ws16;  // the same in X2<16> for the pipelined kernel (gcn_f16p.hip)
+  half_t* Ws;    // same tiles in split-f16 format X2<32> (below), values scaled by w_scale
+  half_t* Wh;    // the same tiles as plain f16 (values scaled by w_scale): operands of the 'f16' mode (gcn_tile.hip)
   float* Ds;     // D / w_scale
   float* M1s;    // M1 / w_scale
   float w_scale; // power of two
@@ -23,7 +23,8 @@ struct LayerDev {
   float* M1;     // [24][N]  M[j][n] * scale[n]
   float* shift;  // [N]      (bias - mean) * scale + beta      (bias when no BN)
   float* Aoff;   // [24][24] symmetrised adjacency, zero diagonal
-  const void* AoffF;  // [Aoff*S | S*I] (24 x 48, rows padded to 32) as split-f16 MFMA A fragments [k-step 3][hi/lo][lane 64][8 halves], then float 1/S
+  const half_t* AoffH;  // [Aoff | I] (24 x 48, rows padded to 32) as f16 MFMA A-operand fragments [k-step 3][lane 64][8 halves]: the adjacency mix
+                        // of the 'f16' mode runs on the matrix cores (gcn_tile.hip)
   int K, N;
   int relu;
 };
@@ -43,28 +44,24 @@ struct ehm_gcn {
   int hid = 0;
   int num_hidden = 0;
   int precision = EHM_PREC_F32;
-  int reg_staging = 0;     // split-f16 convs: 1 = global_load -> VGPR -> ds_write staging, 0 = global_load_lds DMA
-  int persistent = 0;      // split-f16 convs: 1 = grid capped at the co-resident slots, blocks loop over tiles
-  int pipelined = 2;       // split-f16 convs: 2 = register double-buffered fragments + LDS-transposed epilogue (gcn_f16r.hip, default); 0 = 2-stage BK=32 kernel, hipcc-scheduled (gcn_f16.hip); 1 = 4-stage BK=16 (gcn_f16p.hip, X2<16>)
-  int tile_override = 0;   // split-f16 convs: 0 = pick by size, 1 = 192x64 tiles, 2 = 384x128 tiles
   LayerDev input{};
   LayerDev hidden[16]{};
-  LayerDev* hidden_dev = nullptr;        // device copy of hidden[] for the chained kernel (gcn_f16r.hip)
-  unsigned int* chain_sync = nullptr;    // tickets[8] | done[nl][m_tiles] | err, zeroed before every chained launch
+  LayerDev* hidden_dev = nullptr;        // device copy of hidden[] for the chained kernel (gcn_tile.hip)
+  unsigned int* chain_sync = nullptr;    // tickets[8] | done[nl][m_tiles] | err | finished, zeroed before every chained launch
+  unsigned int* chain_sticky = nullptr;  // one word, zeroed at create / by ehm_gcn_stack_status: accumulates the launches' err flags
   size_t chain_sync_words = 0;
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
-  int wide_tile = 0;                     // gcn_f16r.hip: 1 = 8-wave 192 x 128 blocks (EHM_F16R_WIDE), 0 = 4-wave 192 x 64 blocks
-  int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (split-f16, pipelined == 2), 0 = one launch per conv
+  int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (f16 modes), 0 = one launch per conv (EHM_F16_CHAIN=0)
   OutDev out{};
   float* arena = nullptr;
   float* hs = nullptr;      // [hs_rows,12] responses of the output conv (gcn_out_dot_kernel -> gcn_out_mix_kernel)
   int64_t hs_rows = 0;
+  int64_t reserved_rows = 0;   // rows_pad the sync words / hs scratch were sized for (ehm_gcn_reserve)
 };
 
 // Split-f16 activation / weight format ("X2<G>"): row-major rows of K values, every group of G consecutive k stored as
 // G f16 "hi" followed by G f16 "lo" (value = hi + lo, hi = rn_f16(x), lo = rn_f16(x - hi)).  Same bytes per row as
-// float32.  G = 32 (one 128-byte line per 32-k tile) for the 32-wide-K kernels, G = 16 (64 bytes per 16-k tile) for the
-// 4-stage pipelined GCN kernel.
+// float32.  G = 32: one 128-byte line per 32-k tile.
 template <int G = 32>
 static __device__ __forceinline__ size_t split_off(size_t row, int n, int N) {
   return row * (size_t)N * 2 + (size_t)(n / G) * (2 * G) + (n % G);

@@ -17,16 +17,13 @@ int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
 // sampler.hip
 int ehm_num_cus();   // multiProcessorCount of the current device (cached)
-// gcn_f16.hip
-int ehm_gcn_hidden_f16_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
-                            bool out_split, hipStream_t st);
-// gcn_f16p.hip
-int ehm_gcn_hidden_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
-int ehm_gcn_chain_error(const ehm_gcn* h, hipStream_t st, unsigned int* flag);
-int ehm_gcn_hidden_f16r_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
-                             bool out_split, hipStream_t st);
-int ehm_gcn_hidden_f16p_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad,
-                             bool out_split, hipStream_t st);
+// gcn_tile.hip (f16 matrix-core hidden convs: 'f16x3' split operands and plain 'f16')
+int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
+                            hipStream_t st);
+int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
+void ehm_pack_half(const float* X, void* Y, size_t n, float scale, hipStream_t st);
+// gcn.hip
+int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad);   // sync words + output-conv scratch for up to rows_pad rows (allocates: not inside a capture)
 // guidance.hip
 int64_t ehm_guidance_scratch_bytes(int B, int N);
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,

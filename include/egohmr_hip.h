@@ -99,18 +99,21 @@ int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_params* inpu
                    int hid_dim, void* stream);
 void ehm_gcn_destroy(ehm_gcn* h);
 
-/* Arithmetic of the hidden convs.  0 = f32-input MFMA (default, exact f32 products);
+/* Arithmetic of the hidden convs.  0 = f32-input MFMA (exact f32 products; what a fresh handle is in);
  * 1 = "f16x3": f16 MFMA on hi/lo-split operands, three products per term, f32 accumulate (22-bit operands,
- * f32-grade results); 2 = plain f16 MFMA (hi part only; NOT parity-grade - BASELINE config 5's fp16 denoiser).
- * In modes 1/2 the activation matrices exchanged between ehm_gcn_input_layer -> ehm_gcn_hidden_layer use the
- * opaque "X2" split format (same byte size as float32 [rows_pad,hid]); the last hidden conv writes float32 for
- * ehm_gcn_output_layer.  ehm_gcn_pack/unpack_activations convert float32 <-> X2 (tests, interop). */
+ * f32-grade results); 2 = plain f16 operands and f16 activation storage (NOT parity-grade on its own - BASELINE config 5's
+ * fp16 denoiser, and the early steps of ehm_sample_desc.lowprec_steps).
+ * Activation matrices exchanged between ehm_gcn_input_layer -> ehm_gcn_hidden_layer / _stack: mode 0 float32 [rows_pad,hid];
+ * mode 1 the opaque "X2" split format (same byte size), except that the LAST hidden conv writes float32; mode 2 f16
+ * [rows_pad,hid] throughout.  ehm_gcn_output_layer reads what the handle's mode produces.  ehm_gcn_pack/unpack_activations convert float32 <-> the mode's format (tests, interop). */
 int ehm_gcn_set_precision(ehm_gcn* h, int mode);
 int ehm_gcn_get_precision(const ehm_gcn* h);
-/* tuning knob of the split-f16 convs: 0 = tile picked by problem size (default), 1 = 192x64 tiles, 2 = 384x128 tiles */
-int ehm_gcn_set_tile_override(ehm_gcn* h, int mode);
-/* group = ehm_gcn_activation_group(h): k-group size of the handle's X2 layout (16 for the pipelined kernel, 32 otherwise) */
+/* group = ehm_gcn_activation_group(h): 32 = X2 split format (mode 1), 0 = plain f16 (mode 2); pass it to pack / unpack */
 int ehm_gcn_activation_group(const ehm_gcn* h);
+/* Size the handle's internal scratch (chained-launch counters, output-conv responses) for batches of up to max_bodies bodies x
+ * passes.  ehm_gcn_create reserves 256 x 2; a larger batch grows the scratch on first use (a hipMalloc - so call this first when
+ * the launches are going to be captured into a hipGraph). */
+int ehm_gcn_reserve(ehm_gcn* h, int max_bodies, int passes);
 int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, int group, void* stream);
 int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, int group, void* stream);
 
@@ -135,11 +138,12 @@ int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const float* res
 /* All hidden convs of one ModulatedGCN.forward (the `for i in range(self.num_layers): out = self.gconv_layers[i](out)` loop,
  * modulated_gcn.py:108-109; each _ResGraphConv = two _GraphConv + residual, :31-43).  bufs[0] holds the input conv's output,
  * bufs[1] and bufs[2] are scratch of the same size; *result_index says which buffer holds the result (0 or 2).  With the
- * default split-f16 operands this is ONE chained launch (per-row-tile counters instead of kernel boundaries); otherwise it
+ * f16 operands (modes 1, 2) this is ONE chained launch (per-row-tile counters instead of kernel boundaries); otherwise it
  * loops over ehm_gcn_hidden_layer with the same buffer rotation.  Env EHM_F16_CHAIN=0 forces the loop. */
 int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t rows_pad, int* result_index, void* stream);
-/* Synchronises the stream and reports whether the last chained launch flagged a timed-out producer wait (never expected;
- * the kernel gives up instead of hanging the device).  0 = fine. */
+/* Synchronises the stream and reports (and clears) whether ANY chained launch since the previous status call flagged a timed-out
+ * producer wait or an unproduced tile (never expected; the kernel gives up instead of hanging the device, and audits its own
+ * completion).  0 = fine, -5 = the results computed since the previous call are invalid. */
 int ehm_gcn_stack_status(ehm_gcn* h, void* stream);
 
 /* gconv_output (modulated_gcn.py:113) + the visibility fuse of egohmr.py:247-256:

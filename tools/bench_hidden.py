@@ -18,8 +18,6 @@ model = build_synthetic_model(dev, 0)
 model.gcn_precision = prec
 L = _lib.lib()
 h = model.fused_sampler.gcn()
-if os.environ.get("EHM_TILE"):
-    _lib.check(L.ehm_gcn_set_tile_override(h, int(os.environ["EHM_TILE"])))
 hid, tile = model.diffusion_model.hid_dim, L.ehm_gcn_row_tile()
 rows_pad = (2 * B * 24 + tile - 1) // tile * tile
 X = torch.randn(rows_pad, hid, device=dev) * float(os.environ.get("EHM_X_SCALE", "1"))   # EHM_X_SCALE=0: zero operands (clock / power probe)
@@ -31,7 +29,7 @@ if os.environ.get("EHM_STACK"):      # time the sampler's own call instead: all 
     import ctypes as C
     bufs = (C.c_void_p * 3)(X.data_ptr(), Y1.data_ptr(), Y2.data_ptr())
     res = C.c_int(0)
-    nl = L.ehm_gcn_activation_group(h) and 2 * model.diffusion_model.num_layers
+    nl = 2 * model.diffusion_model.num_layers
     for _ in range(2):
         _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), None))
     torch.cuda.synchronize()

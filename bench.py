@@ -44,14 +44,23 @@ def hidden_layer_flops(virtual_bodies: int, hid: int) -> float:
     return virtual_bodies * (24 * 2 * hid * hid + 24 * 24 * hid) * 2.0
 
 
+def kernel_source_sha1():
+    import hashlib
+    with open(os.path.join(REPO, "egohmr_amd", "csrc", "gcn_tile.hip"), "rb") as f:
+        return hashlib.sha1(f.read()).hexdigest()
+
+
 def pmc_traffic(precision):
-    """HBM-side bytes per launch of the dominant kernel, from the last committed rocprofv3 --pmc passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/pmc_traffic.json); None when no pass exists."""
+    """HBM-side bytes per hidden conv of the chained launch, from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, tools/pmc_round.sh -> profiles/pmc_traffic.json).  Counters cannot be read from inside this
+    process, so the figure is only reported when it was collected for THIS kernel source (sha1 of csrc/gcn_tile.hip recorded next
+    to it); otherwise None."""
     try:
         with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(precision, {}).get("bytes_per_launch")
+            e = json.load(f).get(precision, {})
     except OSError:
         return None
+    return e.get("bytes_per_conv") if e.get("kernel_source_sha1") == kernel_source_sha1() else None
 
 
 def time_dominant_kernel(model, B, passes, reps=5):
@@ -97,9 +106,10 @@ def time_dominant_kernel(model, B, passes, reps=5):
     return sum(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3 / (reps * nl), rows_pad
 
 
-def cpu_baseline(n, rs, num_scene_points, budget_s):
-    """The oracle in reference-faithful mode (encoders inside every step, two GCN passes, eager torch-CPU)
-    on a bounded sample: B=8 items, as many leading steps of the same schedule as fit the time budget."""
+def cpu_baseline(n, rs, num_scene_points, budget_s, faithful=True):
+    """The oracle on a bounded sample: B=4 items, as many leading steps of the same schedule as fit the time budget.
+    faithful=True: like the reference (encoders inside every step, two GCN passes, eager torch-CPU); faithful=False: the same CPU
+    arithmetic with the step-invariant encoders hoisted out of the loop - separates what hoisting buys from what the GPU buys."""
     from egohmr_amd import synthetic as syn
     from oracle import model as om, schedule as osched
     # eager torch-CPU on small batches is fastest at 16 threads on the MI355X host (measured 16/32/64: 0.28/0.20/0.10 bodies/s); use what helps and report it
@@ -108,7 +118,7 @@ def cpu_baseline(n, rs, num_scene_points, budget_s):
     B = 4
     sd, asset = syn.make_state_dict(0), syn.make_smpl_asset(0)
     mean, std = syn.make_body_rep_stats(0)
-    ref = om.EgoHMROracle(sd, asset, mean, std, faithful=True)
+    ref = om.EgoHMROracle(sd, asset, mean, std, faithful=faithful)
     bnp = syn.make_batch(B, num_scene_points, seed=0)
     batch = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in bnp.items()}
     tab = osched.make_tables(n, rs)
@@ -123,14 +133,18 @@ def cpu_baseline(n, rs, num_scene_points, budget_s):
             x = float(np.float32(tab.posterior_mean_coef1[i])) * mo["pred_x_start"] + float(np.float32(tab.posterior_mean_coef2[i])) * x \
                 + (0.0 if i == 0 else 1.0) * float(np.exp(0.5 * np.float32(tab.posterior_log_variance_clipped[i]))) * noise[1 + k]
             done += 1
-            if time.perf_counter() - t0 > budget_s and done >= 2:
+            if faithful and time.perf_counter() - t0 > budget_s and done >= 2:
                 break
     dt = time.perf_counter() - t0
-    per_step = dt / done
-    return {"value": B / (per_step * T), "unit": "bodies/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ (CPU restatement, reference-faithful: ResNet-50 + PointNet re-run every step, 2 GCN passes, eager "
-                      f"torch-CPU fp32, {cores} threads): B={B} items, first {done} of {T} steps timed ({dt:.1f} s), "
-                      f"extrapolated linearly to {T} steps"}
+    if faithful:
+        per_call = dt / done * T
+        how = "reference-faithful: ResNet-50 + PointNet re-run every step"
+    else:       # the first step carries the one-off encoders: time it apart
+        per_call = dt if done == T else float("nan")
+        how = "encoders hoisted (run once), otherwise the same eager CPU arithmetic"
+    return {"value": B / per_call, "unit": "bodies/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ (CPU restatement, {how}, 2 GCN passes, eager torch-CPU fp32, {cores} threads): B={B} items, "
+                      f"{done} of {T} steps timed ({dt:.1f} s)" + (f", extrapolated linearly to {T} steps" if faithful and done < T else "")}
 
 
 def main():
@@ -180,7 +194,7 @@ def main():
     ddim = bool(rs)
 
     def one_step():
-        fs._prep = None                                                              # conditioning is part of the job: re-encode
+        fs.invalidate()                                                              # conditioning is part of the job: re-encode
         packs = []
         for k in range(S):                                                           # samples of one item share its conditioning
             res = fs.run(diffusion, batch, noises[k], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0)
@@ -202,91 +216,123 @@ def main():
     assert torch.isfinite(res["other_outputs"]["pred_vertices"]).all()
     assert gathered.shape == (world * B * S, edist.PACKED_WIDTH)
 
-    # comparison legs (rank-local, N=1 only): the same job, same noise, with the hidden convs (a) on the f32-input MFMA (exact f32
-    # products) and (b) on plain f16 operands (one MFMA per product - the "fp16 denoiser" of BASELINE config 5; NOT parity-grade),
-    # each with its distance to the default path's vertices / joints
-    f32_leg = f16_leg = None
+    # comparison legs (rank-local, N=1 only): the same job, same noise, (a) WITHOUT the precision schedule (every step split-f16),
+    # (b) with the hidden convs on the f32-input MFMA (exact f32 products), (c) on plain f16 operands in every step (the "fp16
+    # denoiser" of BASELINE config 5; NOT parity-grade) - each with its distance to the default path's vertices / joints
+    legs = {}
     if args.precision == "f16x3" and world == 1 and S == 1:
         ref_v = res["other_outputs"]["pred_vertices"].float().clone()
-        ref_j = res["other_outputs"]["pred_keypoints_3d"].float().clone() if "pred_keypoints_3d" in res["other_outputs"] else None
+        ref_j = res["other_outputs"]["pred_keypoints_3d"].float().clone()
 
-        def leg(prec):
-            model.gcn_precision = prec
-            one_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            _, r = one_step()
-            torch.cuda.synchronize()
-            d = time.perf_counter() - t1
-            kd, _ = time_dominant_kernel(model, B, 2)
+        def leg(prec, last_steps):
+            old = (model.gcn_precision, model.f16x3_last_steps)
+            model.gcn_precision, model.f16x3_last_steps = prec, last_steps
+            try:
+                one_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, r = one_step()
+                torch.cuda.synchronize()
+                d = time.perf_counter() - t1
+            finally:
+                model.gcn_precision, model.f16x3_last_steps = old
             v = r["other_outputs"]["pred_vertices"].float()
             dv = (v - ref_v).norm(dim=-1)                                  # per-vertex distance [B, V], metres
-            o = {"value": B / d, "unit": "bodies/s", "ms_per_step": d * 1e3, "hidden_conv_avg_launch_ms": kd * 1e3,
-                 "vs_default_path": {"max_vertex_dist_mm": float(dv.max()) * 1e3, "mean_v2v_mm": float(dv.mean()) * 1e3}}
-            if ref_j is not None:
-                o["vs_default_path"]["mpjpe_mm"] = float((r["other_outputs"]["pred_keypoints_3d"].float() - ref_j).norm(dim=-1).mean()) * 1e3
-            model.gcn_precision = args.precision
-            return o, kd
+            return {"value": B / d, "unit": "bodies/s", "ms_per_step": d * 1e3,
+                    "vs_default_path": {"max_vertex_dist_mm": float(dv.max()) * 1e3, "mean_v2v_mm": float(dv.mean()) * 1e3,
+                                        "mpjpe_mm": float((r["other_outputs"]["pred_keypoints_3d"].float() - ref_j).norm(dim=-1).mean()) * 1e3}}
 
-        f32_leg, kd = leg("f32")
-        fl = hidden_layer_flops(2 * B, model.diffusion_model.hid_dim)
-        f32_leg["roofline"] = {"bound": "mfma", "kernel": "gcn_hidden_kernel (f32-input MFMA)", "achieved": fl / kd / 1e12,
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / kd / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                               "avg_launch_ms": kd * 1e3}
-        f16_leg, kd = leg("f16")
-        f16_leg["note"] = "plain f16 operands in the hidden convs (f32 accumulate, everything else f32): reported for BASELINE config 5, not the parity path"
-        f16_leg["roofline"] = {"bound": "mfma", "achieved": fl / kd / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": fl / kd / 1e12 / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": kd * 1e3}
+        legs["all_steps_f16x3"] = leg("f16x3", None)
+        legs["f32_mfma_path"] = leg("f32", None)
+        legs["f16_denoiser_path"] = leg("f16", None)
+        legs["f16_denoiser_path"]["note"] = ("plain f16 operands and f16 activations in the hidden convs of EVERY step (f32 accumulate, everything "
+                                             "else f32): BASELINE config 5's fp16 denoiser, not a parity path on its own")
 
     # split of one call (rank 0, informative)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    fs._prep = None
+    fs.invalidate()
     st = fs.prepare(batch)
     torch.cuda.synchronize()
     t_enc = time.perf_counter() - t1
 
     if rank == 0:
         passes = 2
-        k_dur, rows_pad = time_dominant_kernel(model, B, passes)
         hid = model.diffusion_model.hid_dim
         flops = hidden_layer_flops(passes * B, hid)
-        achieved = flops / k_dur / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
-        kname = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue)",
-                 "f16x3": "gcn_hidden_chain_kernel<3> = 8 chained hidden convs per launch, tile code of gcn_hidden_f16r_kernel (split-f16 MFMA, 3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue); avg_launch_ms is per conv",
-                 "f16": "gcn_hidden_chain_kernel<1> (plain f16 MFMA, f32 accumulate, same fused epilogue); avg_launch_ms is per conv"}[args.precision]
+        n_hidden = 2 * model.diffusion_model.num_layers
+        lowprec = fs.lowprec_steps(T, guided) if args.precision == "f16x3" else 0           # leading steps on plain f16 operands
+        kernels = {}                                                                # live HIP-event timing of each conv kernel this job runs
+
+        def time_kernel(prec):
+            old = model.gcn_precision
+            model.gcn_precision = prec
+            try:
+                kd, _ = time_dominant_kernel(model, B, passes)
+            finally:
+                model.gcn_precision = old
+            peak = PEAK_F32_MFMA_TFLOPS if prec == "f32" else PEAK_F16_MFMA_TFLOPS
+            per_prod = 3 if prec == "f16x3" else 1
+            name = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue), one launch per conv",
+                    "f16x3": "gcn_hidden_chain_kernel<3> (csrc/gcn_tile.hip): the 8 hidden convs of a GCN forward chained in one launch; split-f16 operands, "
+                             "3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue",
+                    "f16": "gcn_hidden_chain_kernel<1> (csrc/gcn_tile.hip): the 8 hidden convs chained in one launch; plain f16 operands and f16 "
+                           "activations, f32 accumulate, adjacency mix on the matrix cores, fused BN/ReLU/residual epilogue"}[prec]
+            return {"bound": "mfma", "kernel": name, "achieved": flops / kd / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / kd / 1e12 / peak,
+                    "mfma_flops_per_algorithmic_flop": per_prod, "issued_mfma_frac": flops * per_prod / kd / 1e12 / peak,
+                    "traffic": pmc_traffic(prec), "avg_launch_ms": kd * 1e3, "avg_launch_ms_is": "per conv = chained launch / 8" if prec != "f32" else "per conv",
+                    "flops_per_launch": flops, "formula": "virtual_bodies*(24*2*hid^2 + 24*24*hid)*2, virtual_bodies = passes*B (SURVEY 8d, hoisted)"}
+
+        if args.precision == "f16x3":
+            kernels["f16x3"] = time_kernel("f16x3")
+            kernels["f16x3"]["launches_per_call"], kernels["f16x3"]["ms_per_call"] = T - lowprec, kernels["f16x3"]["avg_launch_ms"] * n_hidden * (T - lowprec)
+            if lowprec:
+                kernels["f16"] = time_kernel("f16")
+                kernels["f16"]["launches_per_call"], kernels["f16"]["ms_per_call"] = lowprec, kernels["f16"]["avg_launch_ms"] * n_hidden * lowprec
+        else:
+            kernels[args.precision] = time_kernel(args.precision)
+            kernels[args.precision]["launches_per_call"] = T
+            kernels[args.precision]["ms_per_call"] = kernels[args.precision]["avg_launch_ms"] * n_hidden * T
+        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_call"])            # the kernel the job spends most time in
+        value = world * B * S * args.steps / dt
+        flops_per_body = 183.8e9 if args.workload == "ddpm100" else None            # SURVEY 8d, hoisted, T = 100 with diffuse_fuse
         out = {
             "metric": "sampled bodies/sec (100-step DDPM, batch 256)" if args.workload == "ddpm100" else f"sampled bodies/sec ({args.workload})",
-            "value": world * B * S * args.steps / dt,
+            "value": value,
             "unit": "bodies/s",
             "n_gpus": world,
+            "n_ranks_seen": world if world == 1 else int(torch.distributed.get_world_size()),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16x3": "f32 (denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands, f32 accumulate)",
-                      "f16": "f16 denoiser GEMMs (f32 accumulate) + f32 everything else"}[args.precision],
+            "dtype": {"f32": "f32",
+                      "f16x3": "f32 results: denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands (f32 accumulate) on the last "
+                               f"{T - lowprec} of {T} steps, plain f16 operands on the first {lowprec} (precision schedule, DESIGN.md 3.6; "
+                               "final bodies within 1e-5 m of the all-split run, measured below)",
+                      "f16": "f16 denoiser GEMMs and activations (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": S, "collision_guided": guided, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
-                       "gcn_precision": args.precision, "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
+                       "gcn_precision": args.precision, "f16x3_last_steps": (T - lowprec) if args.precision == "f16x3" else None,
+                       "f16x3_last_steps_policy": str(model.f16x3_last_steps),
+                       "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
                        "parallelism": f"items sharded x{world}, one RCCL all-gather of [B,226] at the end"},
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "mfma_flops_per_algorithmic_flop": 3 if args.precision == "f16x3" else 1,
-                         "issued_mfma_frac": achieved * (3 if args.precision == "f16x3" else 1) / peak,   # MFMA work actually issued / peak
-                         "traffic": pmc_traffic(args.precision), "avg_launch_ms": k_dur * 1e3, "flops_per_launch": flops,
-                         "formula": "virtual_bodies*(24*2*hid^2 + 24*24*hid)*2, virtual_bodies = passes*B (SURVEY 8d, hoisted)"},
+            "roofline": kernels[dominant],
+            "roofline_other_kernel": {k: v for k, v in kernels.items() if k != dominant} or None,
             "breakdown_ms": {"encoders_and_projections_once": t_enc * 1e3, "per_call_total": dt / args.steps * 1e3,
-                             "hidden_convs_est": k_dur * 1e3 * 2 * model.diffusion_model.num_layers * T},
+                             "hidden_convs_est": sum(v["ms_per_call"] for v in kernels.values())},
+            "target": {"north_star_bodies_per_s": 10000,
+                       "parity_ceiling_bodies_per_s": (PEAK_F16_MFMA_TFLOPS / 3) * 1e12 / flops_per_body if flops_per_body else None,
+                       "note": "183.8 GFLOP per body (SURVEY 8d); with every product as 3 MFMA the dense f16 peak allows 833 TFLOP/s algorithmic = the "
+                               "ceiling above, so >= 10k bodies/s is out of reach at f32-grade arithmetic on every step"},
         }
-        out["f32_mfma_path"] = f32_leg
-        out["f16_denoiser_path"] = f16_leg
+        out.update(legs)
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, rs, N, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(n, rs, N, args.cpu_seconds * 0.6)
+            out["cpu_baseline_hoisted"] = cpu_baseline(n, rs, N, args.cpu_seconds * 0.4, faithful=False) if T <= 100 else None
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

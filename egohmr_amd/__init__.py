@@ -12,6 +12,7 @@ _LAZY = {
     "SpacedDiffusion": ("diffusion", "SpacedDiffusion"),
     "GaussianDiffusion": ("diffusion", "GaussianDiffusion"),
     "EgoHMR": ("model", "EgoHMR"),
+    "EgoHMRVolsmpl": ("model", "EgoHMRVolsmpl"),
     "rot6d_to_rotmat": ("geometry", "rot6d_to_rotmat"),
     "rotmat_to_rot6d": ("geometry", "rotmat_to_rot6d"),
     "EgoHMRHipError": ("_lib", "EgoHMRHipError"),

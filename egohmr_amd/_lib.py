@@ -78,7 +78,7 @@ class StepCoefs(C.Structure):
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("lowprec_steps", C.c_int)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -116,6 +116,7 @@ PROTOTYPES = {
     "ehm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _L, _P]),
     "ehm_collision_proxy": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "ehm_collision_query": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "ehm_smpl_backward_rot6d": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "ehm_guidance_grad_finish": (_I, [_P, _P, _P, _I, _F, _P]),
     "ehm_nn_dist2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
       for (int k = 0; k < 8; ++k) {
         const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
         hh[k] = (half_t)c;
-        ll[k] = (half_t)(v[k] - (float)hh[k]);
+        ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
       }
       if (OUT == 1) {
         half_t* p = (half_t*)Y + split_off<32>(row, nb + c8, N);   // the eight hi halves are contiguous, the lo halves 32 further

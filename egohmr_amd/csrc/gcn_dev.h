@@ -70,7 +70,7 @@ template <int G = 32>
 static __device__ __forceinline__ void split_store(half_t* base, size_t row, int n, int N, float v) {
   const float c = fminf(fmaxf(v, -65504.f), 65504.f);
   const half_t hi = (half_t)c;
-  const half_t lo = (half_t)(v - (float)hi);
+  const half_t lo = (half_t)fminf(fmaxf(v - (float)hi, -65504.f), 65504.f);   // |v| > 131008 saturates both halves (never inf)
   half_t* p = base + split_off<G>(row, n, N);
   p[0] = hi;
   p[G] = lo;
@@ -87,7 +87,7 @@ static __device__ __forceinline__ float split_load(const half_t* base, size_t ro
 static __device__ __forceinline__ unsigned int split_pack_bits(float v) {
   const float c = fminf(fmaxf(v, -65504.f), 65504.f);
   const half_t hi = (half_t)c;
-  const half_t lo = (half_t)(v - (float)hi);
+  const half_t lo = (half_t)fminf(fmaxf(v - (float)hi, -65504.f), 65504.f);
   return (unsigned int)__builtin_bit_cast(unsigned short, hi) | ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 static __device__ __forceinline__ unsigned int split_pair_word(float v, bool odd) {   // the dword split_store_pair writes

@@ -619,7 +619,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
-            if constexpr (P == 3) ll[c] = (half_t)(v[c] - (float)hh[c]);
+            if constexpr (P == 3) ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
           }
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hh), yB, vo_out, so, kStoreAux);
           if constexpr (P == 3) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ll), yB, vo_out + 64u, so, kStoreAux);

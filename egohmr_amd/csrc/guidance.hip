@@ -51,15 +51,17 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ ver
 }
 
 // ordered stream compaction: idx[b][0..count) = indices of scene points with bb_min <= p <= bb_max (all three coords)
+// margin = 0: egohmr.py:550-552; margin = tau: "all points" of the VolSMPL twin (egohmr_volsmpl.py:609-612) - a point farther than tau from
+// the box is farther than tau from every vertex and contributes exactly nothing to the hinge, so the selection stays exact
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ scene, const float* __restrict__ bbox,
-                                                      int* __restrict__ idx, int* __restrict__ count, int N) {
+                                                      int* __restrict__ idx, int* __restrict__ count, int N, float margin) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int wsum[16];
   __shared__ int base;
   if (tid == 0) base = 0;
   float lo[3], hi[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { lo[c] = bbox[b * 6 + c]; hi[c] = bbox[b * 6 + 3 + c]; }
+  for (int c = 0; c < 3; ++c) { lo[c] = bbox[b * 6 + c] - margin; hi[c] = bbox[b * 6 + 3 + c] + margin; }
   __syncthreads();
   for (int i0 = 0; i0 < N; i0 += 1024) {
     const int i = i0 + tid;
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
 // grid (point chunks of 1024, B); dynamic LDS: body vertices as SoA x[Vp] y[Vp] z[Vp] (Vp = V rounded up to 4)
 __global__ __launch_bounds__(1024) void nearest_kernel(const float* __restrict__ verts, const float* __restrict__ scene,
                                                        const int* __restrict__ idx, const int* __restrict__ count,
-                                                       float* __restrict__ loss, float* __restrict__ gverts, int V, int N,
-                                                       float tau) {
+                                                       float* __restrict__ loss, float* __restrict__ gverts, int* __restrict__ hits,
+                                                       int V, int N, float tau) {
   extern __shared__ __attribute__((aligned(16))) float sv[];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int cnt = count[b];
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(1024) void nearest_kernel(const float* __restrict__
   __syncthreads();
   const int k = chunk * 1024 + tid;
   float contrib = 0.f;
+  int nhit = 0;
   if (k < cnt) {
     const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + k]) * 3;
     const float px = p[0], py = p[1], pz = p[2];
@@ -129,24 +132,30 @@ __global__ __launch_bounds__(1024) void nearest_kernel(const float* __restrict__
     const float h = tau - d;
     if (h > 0.f) {
       contrib = h * h;
-      const float s = 2.f * h / d;                        // d(h^2)/dv = 2h (p - v)/d
-      float* g = gverts + ((size_t)b * V + bi) * 3;
-      atomicAdd(g + 0, s * (px - sx[bi]));
-      atomicAdd(g + 1, s * (py - sy[bi]));
-      atomicAdd(g + 2, s * (pz - sz[bi]));
+      ++nhit;
+      if (gverts) {
+        const float s = 2.f * h / d;                      // d(h^2)/dv = 2h (p - v)/d
+        float* g = gverts + ((size_t)b * V + bi) * 3;
+        atomicAdd(g + 0, s * (px - sx[bi]));
+        atomicAdd(g + 1, s * (py - sy[bi]));
+        atomicAdd(g + 2, s * (pz - sz[bi]));
+      }
     }
   }
   // block sum of the hinge terms
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
+  for (int o = 32; o >= 1; o >>= 1) { contrib += __shfl_xor(contrib, o); nhit += __shfl_xor(nhit, o); }
   __shared__ float wred[16];
-  if ((tid & 63) == 0) wred[tid >> 6] = contrib;
+  __shared__ int hred[16];
+  if ((tid & 63) == 0) { wred[tid >> 6] = contrib; hred[tid >> 6] = nhit; }
   __syncthreads();
   if (tid == 0) {
     float s = 0.f;
+    int nh = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += wred[w];
+    for (int w = 0; w < 16; ++w) { s += wred[w]; nh += hred[w]; }
     if (s != 0.f) atomicAdd(loss + b, s);
+    if (hits && nh) atomicAdd(hits + b, nh);
   }
 }
 
@@ -159,7 +168,7 @@ constexpr int kMaxCells = 4096;
 __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restrict__ verts, const float* __restrict__ scene,
                                                             const int* __restrict__ idx, const int* __restrict__ count,
                                                             const float* __restrict__ bbox, float* __restrict__ loss,
-                                                            float* __restrict__ gverts, int V, int N, float tau) {
+                                                            float* __restrict__ gverts, int* __restrict__ hits, int V, int N, float tau) {
   extern __shared__ __attribute__((aligned(16))) float sv[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int cnt = count[b];
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
   unsigned short* order = (unsigned short*)(cursor + kMaxCells);   // [Vp] vertex ids sorted by cell
   __shared__ int part[1024];
   __shared__ float wred[16];
+  __shared__ int hred[16];
 
   float lo[3], ext[3];
 #pragma unroll
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
   __syncthreads();
 
   float contrib = 0.f;
+  int nhit = 0;
   for (int k = tid; k < cnt; k += 1024) {
     const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + k]) * 3;
     const float px = p[0], py = p[1], pz = p[2];
@@ -254,23 +265,28 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
       const float hh = tau - d;
       if (hh > 0.f) {
         contrib += hh * hh;
-        const float s = 2.f * hh / d;                     // d(h^2)/dv = 2h (p - v)/d
-        float* g = gverts + ((size_t)b * V + bi) * 3;
-        atomicAdd(g + 0, s * (px - sx[bi]));
-        atomicAdd(g + 1, s * (py - sy[bi]));
-        atomicAdd(g + 2, s * (pz - sz[bi]));
+        ++nhit;
+        if (gverts) {
+          const float s = 2.f * hh / d;                   // d(h^2)/dv = 2h (p - v)/d
+          float* g = gverts + ((size_t)b * V + bi) * 3;
+          atomicAdd(g + 0, s * (px - sx[bi]));
+          atomicAdd(g + 1, s * (py - sy[bi]));
+          atomicAdd(g + 2, s * (pz - sz[bi]));
+        }
       }
     }
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
-  if ((tid & 63) == 0) wred[tid >> 6] = contrib;
+  for (int o = 32; o >= 1; o >>= 1) { contrib += __shfl_xor(contrib, o); nhit += __shfl_xor(nhit, o); }
+  if ((tid & 63) == 0) { wred[tid >> 6] = contrib; hred[tid >> 6] = nhit; }
   __syncthreads();
   if (tid == 0) {
     float s = 0.f;
+    int nh = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += wred[w];
+    for (int w = 0; w < 16; ++w) { s += wred[w]; nh += hred[w]; }
     if (s != 0.f) atomicAdd(loss + b, s);
+    if (hits && nh) hits[b] = nh;
   }
 }
 
@@ -618,49 +634,49 @@ Scratch carve_scratch(void* base, int B, int N) {
   return s;
 }
 
-thread_local void* g_scratch = nullptr;
-thread_local int64_t g_scratch_bytes = 0;
+// Scratch of the stand-alone entry points (ehm_collision_proxy / _query, ehm_smpl_backward_rot6d): one buffer per (host thread, device).
+// Calls on ONE device from one thread must be stream-ordered with respect to each other (same stream, or externally synchronised):
+// ehm_sample_loop does not use this - it carves its scratch out of the caller's workspace.
+constexpr int kMaxDevices = 16;
+thread_local void* g_scratch[kMaxDevices] = {};
+thread_local int64_t g_scratch_bytes[kMaxDevices] = {};
 int own_scratch(int64_t bytes, void** out) {
-  if (bytes > g_scratch_bytes) {
-    if (g_scratch) (void)hipFree(g_scratch);
-    g_scratch = nullptr;
-    g_scratch_bytes = 0;
-    EHM_HIP(hipMalloc(&g_scratch, bytes));
-    g_scratch_bytes = bytes;
+  int dev = 0;
+  EHM_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) { ehm_set_error("device ordinal %d out of range", dev); return EHM_EINVAL; }
+  if (bytes > g_scratch_bytes[dev]) {
+    if (g_scratch[dev]) { EHM_HIP(hipDeviceSynchronize()); (void)hipFree(g_scratch[dev]); }
+    g_scratch[dev] = nullptr;
+    g_scratch_bytes[dev] = 0;
+    EHM_HIP(hipMalloc(&g_scratch[dev], bytes));
+    g_scratch_bytes[dev] = bytes;
   }
-  *out = g_scratch;
+  *out = g_scratch[dev];
   return 0;
 }
 
-int collision_impl(const float* verts, const float* scene, float* loss, float* gverts, int B, int V, int N, float tau,
-                   const Scratch& s, hipStream_t st) {
-  EHM_HIP(hipMemsetAsync(gverts, 0, (size_t)B * V * 3 * sizeof(float), st));
+int collision_impl(const float* verts, const float* scene, float* loss, float* gverts, int* hits, int B, int V, int N, float tau,
+                   float margin, const Scratch& s, hipStream_t st) {
+  if (gverts) EHM_HIP(hipMemsetAsync(gverts, 0, (size_t)B * V * 3 * sizeof(float), st));
+  if (hits) EHM_HIP(hipMemsetAsync(hits, 0, (size_t)B * sizeof(int), st));
   EHM_HIP(hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), st));
   hipLaunchKernelGGL(bbox_kernel, dim3(B), dim3(256), 0, st, verts, s.bbox, V);
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, scene, s.bbox, s.idx, s.count, N);
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, st, scene, s.bbox, s.idx, s.count, N, margin);
   const int Vp = (V + 3) & ~3;
   const size_t lds = (size_t)3 * Vp * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    EHM_HIP(hipFuncSetAttribute((const void*)nearest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    attr_set = true;
-  }
+  // (per device, and cheap: set unconditionally rather than once per process)
+  EHM_HIP(hipFuncSetAttribute((const void*)nearest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   if (lds > 160 * 1024 - 256) {
     ehm_set_error("collision proxy: %d vertices do not fit the 160 KiB LDS", V);
     return EHM_EINVAL;
   }
   const size_t lds_grid = lds + (size_t)(2 * kMaxCells + 1) * sizeof(int) + (size_t)Vp * sizeof(unsigned short) + 16;
-  static const bool use_grid = !(getenv("EHM_COLL_GRID") && atoi(getenv("EHM_COLL_GRID")) == 0);
-  if (use_grid && V <= 65535 && lds_grid <= 160 * 1024 - 4608) {
-    static bool attr2 = false;
-    if (!attr2) {
-      EHM_HIP(hipFuncSetAttribute((const void*)nearest_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608));
-      attr2 = true;
-    }
-    hipLaunchKernelGGL(nearest_grid_kernel, dim3(B), dim3(1024), lds_grid, st, verts, scene, s.idx, s.count, s.bbox, loss, gverts, V, N, tau);
-  } else {
+  if (V <= 65535 && lds_grid <= 160 * 1024 - 4608) {
+    EHM_HIP(hipFuncSetAttribute((const void*)nearest_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608));
+    hipLaunchKernelGGL(nearest_grid_kernel, dim3(B), dim3(1024), lds_grid, st, verts, scene, s.idx, s.count, s.bbox, loss, gverts, hits, V, N, tau);
+  } else {   // bodies too large for the in-LDS grid: brute force over an LDS-resident copy of the vertices
     hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)ceil_div(N, 1024), B), dim3(1024), lds, st, verts, scene, s.idx, s.count, loss,
-                       gverts, V, N, tau);
+                       gverts, hits, V, N, tau);
   }
   EHM_LAUNCH_CHECK();
   return 0;
@@ -687,12 +703,12 @@ int64_t ehm_guidance_scratch_bytes(int B, int N) {
 }
 
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
-                      const float* scene, int B, int N, float tau, float denom, float* verts_ws, float* joints_ws, float* R_ws,
+                      const float* scene, int B, int N, float tau, float denom, float margin, float* verts_ws, float* joints_ws, float* R_ws,
                       float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st) {
   const int V = smpl->d.V;
   const Scratch s = carve_scratch(scratch, B, N);
   int rc = ehm_smpl_forward_impl(smpl, betas, x, true, mean, std_, verts_ws, joints_ws, R_ws, A_ws, nullptr, B, st);   // egohmr.py:528-537
-  if (rc == 0) rc = collision_impl(verts_ws, scene, loss, gverts, B, V, N, tau, s, st);
+  if (rc == 0) rc = collision_impl(verts_ws, scene, loss, gverts, nullptr, B, V, N, tau, margin, s, st);
   if (rc == 0) rc = backward_impl(smpl, betas, x, mean, std_, R_ws, A_ws, gverts, gpose, B, s, st);
   if (rc == 0) {
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)ceil_div((int64_t)B * kPoseDim, 256)), dim3(256), 0, st, gpose, grad, B, denom);
@@ -707,7 +723,16 @@ extern "C" int ehm_collision_proxy(const float* verts, const float* scene, float
   void* sc = nullptr;
   int rc = own_scratch(ehm_guidance_scratch_bytes(B, N), &sc);
   if (rc) return rc;
-  return collision_impl(verts, scene, loss, gverts, B, V, N, tau, carve_scratch(sc, B, N), (hipStream_t)stream);
+  return collision_impl(verts, scene, loss, gverts, nullptr, B, V, N, tau, 0.f, carve_scratch(sc, B, N), (hipStream_t)stream);
+}
+
+extern "C" int ehm_collision_query(const float* verts, const float* scene, float* loss, float* gverts, int32_t* hits, int B, int V, int N,
+                                   float tau, int all_points, void* stream) {
+  EHM_CHECK_ARG(verts && scene && loss && B > 0 && V > 0 && N > 0 && tau > 0.f);
+  void* sc = nullptr;
+  int rc = own_scratch(ehm_guidance_scratch_bytes(B, N), &sc);
+  if (rc) return rc;
+  return collision_impl(verts, scene, loss, gverts, hits, B, V, N, tau, all_points ? tau : 0.f, carve_scratch(sc, B, N), (hipStream_t)stream);
 }
 
 extern "C" int ehm_smpl_backward_rot6d(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_,

@@ -27,5 +27,5 @@ int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad);   // sync words + output
 // guidance.hip
 int64_t ehm_guidance_scratch_bytes(int B, int N);
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
-                      const float* scene, int B, int N, float tau, float denom, float* verts_ws, float* joints_ws, float* R_ws,
+                      const float* scene, int B, int N, float tau, float denom, float margin, float* verts_ws, float* joints_ws, float* R_ws,
                       float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st);

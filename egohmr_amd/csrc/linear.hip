@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(LinArgs p) {
       for (int k = 0; k < 8; ++k) {
         const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
         hh[k] = (half_t)c;
-        ll[k] = (half_t)(v[k] - (float)hh[k]);
+        ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
       }
       half_t* dst = p.Y + split_off<32>(m0 + row, n0 + 8 * c8, p.N);   // 8 | 32: the eight hi halves are contiguous, the lo halves 32 further
       *(u32x4*)dst = __builtin_bit_cast(u32x4, hh);

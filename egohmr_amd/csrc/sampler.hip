@@ -24,17 +24,15 @@ void ehm_set_error(const char* fmt, ...) {
 extern "C" const char* ehm_last_error(void) { return g_err; }
 extern "C" const char* ehm_target_arch(void) { return "gfx950"; }
 
-int ehm_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+int ehm_num_cus() {   // of the CURRENT device (cached per ordinal)
+  static int n[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (n[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n = prop.multiProcessorCount;
-    else
-      n = 256;   // MI355X
+    n[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;   // MI355X
   }
-  return n;
+  return n[dev];
 }
 
 namespace {
@@ -181,7 +179,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     // ---- collision guidance on x_t (gaussian_diffusion.py:378-385, egohmr.py:517-570) ----
     const float* grad = nullptr;
     if (rc == 0 && c.grad_scale != 0.f) {
-      rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom,
+      rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom, d->guide_all_points ? d->tau : 0.f,
                              w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, w.g_scratch, st);
       grad = w.g_grad;
     }

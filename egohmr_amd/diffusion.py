@@ -171,11 +171,15 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ single steps (generic route)
     def _uniform_index(self, t) -> int:
-        i = int(t[0])
-        return i
+        """The reference's p_sample / ddim_sample take one timestep per sample; its loops (and its guidance gate, `t[0] <= 10`,
+        gaussian_diffusion.py:378) always pass a uniform vector.  The native steps take schedule coefficients by value, so a
+        non-uniform ``t`` is refused instead of being silently read as t[0]."""
+        if t.numel() > 1 and not bool((t == t[0]).all()):
+            raise ValueError("egohmr_amd samplers need the same timestep for every item of the batch (got a non-uniform t)")
+        return int(t[0])
 
-    def _step(self, model, batch, x, t, ddim, guided, cond_grad_weight, eta, noise):
-        i = self._uniform_index(t)
+    def _step(self, model, batch, x, t, ddim, guided, cond_grad_weight, eta, noise, index=None):
+        i = self._uniform_index(t) if index is None else index      # the loops pass their python index: no device read-back
         batch["x_t"] = x
         mo = model(batch, self._model_timesteps(t))
         x0 = _lib.f32(mo["pred_x_start"], x.device)
@@ -252,7 +256,7 @@ class GaussianDiffusion:
             t = th.tensor([i] * shape[0], device=device)                              # :495
             with th.no_grad():
                 eps = None if noise_stack is None else noise_stack[1 + k]
-                out = self._step(model, batch, data, t, ddim, cond_fn_with_grad, cond_grad_weight, eta, eps)
+                out = self._step(model, batch, data, t, ddim, cond_fn_with_grad, cond_grad_weight, eta, eps, index=i)
                 yield out
                 data = out["sample"]
 

@@ -6,15 +6,16 @@ import torch
 
 from . import synthetic as syn
 from .diffusion import create_gaussian_diffusion
-from .model import EgoHMR
+from .model import EgoHMR, EgoHMRVolsmpl
 
 
 def build_synthetic_model(device="cuda", seed: int = 0, diffuse_fuse: bool = True, identity_stats: bool = False,
-                          state_dict: dict | None = None, smpl_asset: dict | None = None, gcn_nonlocal_layer: bool = False) -> EgoHMR:
+                          state_dict: dict | None = None, smpl_asset: dict | None = None, gcn_nonlocal_layer: bool = False,
+                          volsmpl: bool = False) -> EgoHMR:
     """EgoHMR with the test-time flags of test_egohmr.py:112-118, seeded synthetic weights and SMPL asset
     (no checkpoint / licensed model file exists offline)."""
     mean, std = syn.make_body_rep_stats(seed, identity=identity_stats)
-    model = EgoHMR(device=device, body_rep_mean=mean, body_rep_std=std, with_focal_length=True, with_bbox_info=True,
+    model = (EgoHMRVolsmpl if volsmpl else EgoHMR)(device=device, body_rep_mean=mean, body_rep_std=std, with_focal_length=True, with_bbox_info=True,
                    with_cam_center=True, scene_feat_dim=512, scene_type="cube", scene_cano=True, cond_mask_prob=0.0,
                    only_mask_img_cond=True, pelvis_vis_loosen=True, diffuse_fuse=diffuse_fuse, gcn_nonlocal_layer=gcn_nonlocal_layer,
                    smpl_asset=smpl_asset if smpl_asset is not None else syn.make_smpl_asset(seed))

@@ -71,7 +71,8 @@ class SMPL(nn.Module):
     # ------------------------------------------------------------------ native handle
     def handle(self):
         """ehm_smpl* for the current device placement of the buffers (re-created after .to())."""
-        key = (self.v_template.data_ptr(), self.posedirs.data_ptr(), str(self.v_template.device))
+        bufs = (self.v_template, self.shapedirs, self.posedirs, self.J_regressor, self.lbs_weights)
+        key = tuple((b.data_ptr(), b._version) for b in bufs) + (str(self.v_template.device),)   # in-place loads (load_state_dict) re-pack too
         if self._handle is None or self._handle_key != key:
             self._free()
             L = _lib.lib()
@@ -102,9 +103,12 @@ class SMPL(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, return_verts=True,
                 return_full_pose=False, pose2rot=True, **kwargs):
-        if pose2rot:
-            raise NotImplementedError("the sampling path always passes rotation matrices (pose2rot=False, egohmr.py:276)")
         dev = self.v_template.device
+        if pose2rot:        # axis-angle inputs (ground-truth bodies of the driver, test_egohmr.py:307-310): Rodrigues like smplx's batch_rodrigues
+            from .geometry import aa_to_rotmat
+            B0 = max(body_pose.shape[0], global_orient.shape[0])
+            global_orient = aa_to_rotmat(_lib.f32(global_orient, dev).reshape(-1, 3)).reshape(B0, 1, 3, 3)
+            body_pose = aa_to_rotmat(_lib.f32(body_pose, dev).reshape(-1, 3)).reshape(B0, 23, 3, 3)
         if dev.type != "cuda":
             raise _lib.EgoHMRHipError("SMPL.forward needs the module on a HIP device (.to('cuda')); egohmr_amd has no CPU path")
         B = max(betas.shape[0], body_pose.shape[0], global_orient.shape[0])
@@ -169,15 +173,33 @@ def load_smpl_asset(model_path: str) -> dict:
 _GENDER_FILE = {"neutral": "SMPL_NEUTRAL.pkl", "male": "SMPL_MALE.pkl", "female": "SMPL_FEMALE.pkl"}
 
 
-def create(model_path: str = "data/smpl", model_type: str = "smpl", gender: str = "neutral", asset: dict | None = None, **kwargs) -> SMPL:
-    """Drop-in for ``smplx.create`` (egohmr.py:105-107).  With no model file on disk and no
-    ``asset`` the seeded synthetic SMPL-shaped asset is used (the licensed files cannot ship)."""
+def resolve_model_file(model_path: str, model_type: str, gender: str) -> str | None:
+    """smplx.create's path resolution (pip smplx 0.1.28 body_models.create): a directory gets ``model_type`` appended, then the
+    gender file name - the documented layout is ``data/smpl/smpl/SMPL_NEUTRAL.pkl`` (reference README.md:60-65).  A flat
+    ``data/smpl/SMPL_NEUTRAL.pkl`` and a direct file path are accepted as well."""
+    if os.path.isdir(model_path):
+        for cand in (os.path.join(model_path, model_type, _GENDER_FILE[gender]), os.path.join(model_path, _GENDER_FILE[gender])):
+            if os.path.isfile(cand):
+                return cand
+        return None
+    return model_path if os.path.isfile(model_path) else None
+
+
+def create(model_path: str = "data/smpl", model_type: str = "smpl", gender: str = "neutral", asset: dict | None = None,
+           allow_synthetic: bool = False, **kwargs) -> SMPL:
+    """Drop-in for ``smplx.create`` (egohmr.py:105-107).  The licensed model files cannot ship, so tests / benchmarks pass a
+    synthetic ``asset`` (or ``allow_synthetic=True``) explicitly; a missing file is otherwise an error, never a silent
+    substitute - every vertex and metric would come from a fake body."""
     if model_type != "smpl":
         raise ValueError("only model_type='smpl' is on the EgoHMR path")
     if asset is None:
-        cand = os.path.join(model_path, _GENDER_FILE[gender]) if os.path.isdir(model_path) else model_path
-        if os.path.isfile(cand):
-            asset = load_smpl_asset(cand)
-        else:
+        path = resolve_model_file(model_path, model_type, gender)
+        if path is not None:
+            asset = load_smpl_asset(path)
+        elif allow_synthetic:
             asset = synthetic.make_smpl_asset({"neutral": 0, "male": 1, "female": 2}[gender])
+        else:
+            raise FileNotFoundError(
+                f"no SMPL model for gender '{gender}' under '{model_path}' (looked for {model_type}/{_GENDER_FILE[gender]} and "
+                f"{_GENDER_FILE[gender]}); pass asset=... or allow_synthetic=True to run on the synthetic SMPL-shaped asset")
     return SMPL(asset, gender=gender, **kwargs)

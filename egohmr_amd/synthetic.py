@@ -325,3 +325,15 @@ def make_body_rep_stats(seed: int = 0, identity: bool = False):
     mean = g.normal(scale=0.3, size=144).astype(np.float32)
     std = np.concatenate([np.full(6, 0.55), np.full(138, 0.42)]).astype(np.float32)
     return mean, std
+
+
+def make_gt_annotations(batch_size: int, seed: int = 0) -> dict:
+    """Ground-truth body annotations of a batch as the EgoBody loader delivers them (dataloaders/egobody_dataset.py:241-277:
+    axis-angle ``global_orient`` [B,3] / ``body_pose`` [B,69], ``betas`` [B,10], ``gender`` [B] with 0 = male, 1 = female),
+    for the driver block of test_egohmr.py:268-318.  Its own random stream: ``make_batch`` stays bit-identical."""
+    g = _rng(7000 + seed)
+    B = batch_size
+    return {"global_orient": g.normal(scale=0.4, size=(B, 3)).astype(np.float32),
+            "body_pose": g.normal(scale=0.25, size=(B, 69)).astype(np.float32),
+            "betas": g.normal(scale=0.8, size=(B, 10)).astype(np.float32),
+            "gender": (g.random(B) < 0.5).astype(np.int64)}

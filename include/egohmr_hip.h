@@ -233,6 +233,15 @@ int ehm_ddim_step(const float* x, const float* x0, const float* noise, float* x_
 int ehm_collision_proxy(const float* verts, const float* scene, float* loss, float* gverts, int B, int V, int N,
                         float tau, void* stream);
 
+/* The same proxy with the knobs of the reference's other call sites:
+ *   all_points != 0   no bbox selection - the batched `volume.collision_loss(scene, smpl_output)` of the VolSMPL twin
+ *                     (models/egohmr/egohmr_volsmpl.py:609-612); 0 = egohmr.py:550-552 as above
+ *   hits [B] int32    (may be NULL) number of selected scene points closer than tau to the body: the count behind
+ *                     EgoHMR.eval_coll (egohmr.py:487-514, `occupancy > 0.5`) / eval_coll_volsmpl (egohmr_volsmpl.py:548-579, `sdf < 0`)
+ *   gverts            may be NULL (metric only) */
+int ehm_collision_query(const float* verts, const float* scene, float* loss, float* gverts, int32_t* hits, int B, int V, int N,
+                        float tau, int all_points, void* stream);
+
 /* VJP of ehm_smpl_forward_rot6d w.r.t. the DE-NORMALISED 6-D pose (the quirk of egohmr.py:523-528:
  * autograd.grad is taken w.r.t. x_t*std+mean): gverts [B,V,3] -> gpose6d [B,144].
  * Needs the forward's x/mean/std/betas again (recomputes the chain). */
@@ -268,6 +277,7 @@ typedef struct {
   int num_scene_points; /* N (guidance only)                                        */
   float guide_denom;  /* B for COAP-style loss.mean(), 1 for VolSMPL-style sum()    */
   float tau;          /* collision proxy contact distance                          */
+  int guide_all_points; /* 1 = VolSMPL-style guidance over ALL scene points (egohmr_volsmpl.py:609-612), 0 = bbox-selected (egohmr.py:550-552) */
   int lowprec_steps;  /* precision schedule: the FIRST lowprec_steps executed steps run the hidden convs on plain f16 operands
                          (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */
 } ehm_sample_desc;

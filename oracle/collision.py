@@ -30,3 +30,29 @@ def proxy_collision_loss(points, verts, joints=None, full_pose_aa=None, tau: flo
         d = torch.sqrt(d2min + 1e-12)
         total = total + (torch.relu(tau - d) ** 2).sum()
     return total
+
+
+def proxy_min_dist(points, verts):
+    """points [n,3], verts [V,3] -> distance of every point to its nearest vertex (same epsilon as the loss)."""
+    out = []
+    for s in range(0, points.shape[0], 1024):
+        diff = points[s:s + 1024, None, :] - verts[None, :, :]
+        out.append(torch.sqrt((diff * diff).sum(-1).min(dim=1).values + 1e-12))
+    return torch.cat(out) if out else points.new_zeros(0)
+
+
+def proxy_collision_loss_batched(points, verts, tau: float = TAU):
+    """The VolSMPL-shaped call `volume.collision_loss(points [B,N,3], smpl_output) -> [B]` (models/egohmr/egohmr_volsmpl.py:609-612):
+    every scene point of every item, no bounding-box selection."""
+    return torch.stack([proxy_collision_loss(points[[b]], verts[[b]], tau=tau) for b in range(points.shape[0])])
+
+
+def proxy_occupancy(points, verts, tau: float = TAU):
+    """Stand-in for `coap.query(points [1,n,3], smpl_output) -> occupancy [1,n]` (egohmr.py:509, `> 0.5` = inside):
+    1 where the point is closer than tau to the surface, else 0."""
+    return (proxy_min_dist(points[0], verts[0]) < tau).to(verts.dtype).unsqueeze(0)
+
+
+def proxy_sdf(points, verts, tau: float = TAU):
+    """Stand-in for `volume.query_fast(points [1,n,3], smpl_output) -> sdf [1,n]` (egohmr_volsmpl.py:574, `< 0` = inside)."""
+    return (proxy_min_dist(points[0], verts[0]) - tau).unsqueeze(0)

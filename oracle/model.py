@@ -257,7 +257,9 @@ class EgoHMROracle:
     # stands in for ``smpl.coap.collision_loss`` (learned network, unavailable offline).
     GRAD_ZERO_JOINTS = [0, 3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23]
 
-    def guide_coll(self, batch, output, t, compute_grad="x_t", reduction="mean"):
+    def guide_coll(self, batch, output, t, compute_grad="x_t", reduction="mean", all_points=False):
+        """reduction='mean', all_points=False: egohmr.py:517-570 (COAP).  reduction='sum', all_points=True: the VolSMPL twin
+        (egohmr_volsmpl.py:582-629): one batched loss over ALL scene points, `-loss.sum()`."""
         assert self.collision_loss is not None
         with torch.enable_grad():
             x = (batch["x_t"] if compute_grad == "x_t" else output["pred_x_start"]).detach().to(self.dtype)
@@ -276,6 +278,8 @@ class EgoHMROracle:
                 bb_max = v.max(1).values.reshape(1, 3).detach()
                 pts = self.scene_pcd_verts[[i]]
                 inds = (pts >= bb_min).all(-1) & (pts <= bb_max).all(-1)
+                if all_points:                                               # egohmr_volsmpl.py:609-612: no selection
+                    inds = torch.ones_like(inds)
                 if inds.any():
                     losses.append(self.collision_loss(pts[inds].unsqueeze(0), v, so.joints[[i]], aa[[i]]))
                 else:
@@ -288,3 +292,17 @@ class EgoHMROracle:
                 g[:, self.GRAD_ZERO_JOINTS] = 0                              # :567
                 return g.reshape(-1, 144), loss.detach()
             return torch.zeros(B, 144, dtype=self.dtype), loss.detach()
+
+    def eval_coll(self, output, tau=0.05):
+        """egohmr.py:487-514 (and eval_coll_volsmpl, egohmr_volsmpl.py:548-579) with the proxy: per item, bbox-selected scene points
+        closer than tau to the body, over N."""
+        from oracle.collision import proxy_min_dist
+        p = output["pred_smpl_params"]
+        so = self.smpl(betas=p["betas"], body_pose=p["body_pose"], global_orient=p["global_orient"])
+        out = []
+        for i in range(so.vertices.shape[0]):
+            v = so.vertices[i]
+            pts = self.scene_pcd_verts[i]
+            inds = (pts >= v.min(0).values).all(-1) & (pts <= v.max(0).values).all(-1)
+            out.append(float((proxy_min_dist(pts[inds], v) < tau).sum()) / pts.shape[0] if inds.any() else 0.0)
+        return out

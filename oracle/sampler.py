@@ -22,7 +22,7 @@ def _coef(table, i, dtype):
 
 
 def p_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, cond_fn_with_grad=False,
-                  cond_grad_weight=1.0, guide_reduction="mean", trace=None):
+                  cond_grad_weight=1.0, guide_reduction="mean", trace=None, guide_all_points=False):
     """Returns the last step's dict {'sample','pred_xstart','other_outputs'} (gaussian_diffusion.py:391-446)."""
     dt = noise.dtype
     x = noise[0]
@@ -40,7 +40,7 @@ def p_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, cond_fn_wit
         logvar = _coef(tables.posterior_log_variance_clipped, i, dt)
         eps = noise[1 + k]
         if cond_fn_with_grad and i <= 10:                                              # :378 (respaced index)
-            g, _ = model.guide_coll(batch, mo, t_model, compute_grad="x_t", reduction=guide_reduction)
+            g, _ = model.guide_coll(batch, mo, t_model, compute_grad="x_t", reduction=guide_reduction, all_points=guide_all_points)
             if i >= 5:
                 mean = mean.float() + cond_grad_weight * var * g.float()               # :381
             else:
@@ -90,11 +90,11 @@ def ddim_sample_loop(model, batch, tables: Tables, noise: torch.Tensor, eta: flo
 
 
 def val_losses(model, batch, tables: Tables, noise, timestep_respacing="", cond_fn_with_grad=False,
-               cond_grad_weight=1.0, guide_reduction="mean", trace=None):
+               cond_grad_weight=1.0, guide_reduction="mean", trace=None, guide_all_points=False):
     """gaussian_diffusion.py:749-780 with compute_loss=False: returns the final step's model dict."""
     model.validation_setup()
     if timestep_respacing == "":
-        o = p_sample_loop(model, batch, tables, noise, cond_fn_with_grad, cond_grad_weight, guide_reduction, trace)
+        o = p_sample_loop(model, batch, tables, noise, cond_fn_with_grad, cond_grad_weight, guide_reduction, trace, guide_all_points)
     elif timestep_respacing[0:4] == "ddim":
         o = ddim_sample_loop(model, batch, tables, noise, 0.0, trace, cond_fn_with_grad, guide_reduction)
     else:

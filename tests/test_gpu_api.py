@@ -297,7 +297,7 @@ def test_full_size_properties_c2():
         return {k: sub(v) for k, v in x.items()} if isinstance(x, dict) else x[:S]
 
     def run(b, nz):
-        model.fused_sampler._prep = None
+        model.fused_sampler.invalidate()
         return d.val_losses(model, batch_to_device(b, dev), shape=[nz.shape[1], 144], clip_denoised=False, timestep_respacing="ddim10",
                             compute_loss=False, noise_stack=nz.to(dev))
 

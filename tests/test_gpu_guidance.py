@@ -59,7 +59,7 @@ def test_collision_proxy_vs_oracle(dev, model, smpl_asset, B, N):
     near = verts[:, g.integers(0, 6890, size=N // 4)] + torch.from_numpy(g.normal(scale=0.02, size=(B, N // 4, 3)).astype(np.float32))
     scene = torch.cat([near, torch.from_numpy(g.uniform(-1.2, 1.2, size=(B, N - N // 4, 3)).astype(np.float32))], dim=1)
     scene[-1] = 5.0                                          # last body: nothing inside its bbox -> zero loss / gradient
-    loss, gverts = model.fused_sampler.collision(verts.to(dev), scene.to(dev))
+    loss, gverts, _ = model.fused_sampler.collision(verts.to(dev), scene.to(dev))
     ref_loss, ref_g = [], []
     for i in range(B):
         v = verts[[i]].clone().requires_grad_()

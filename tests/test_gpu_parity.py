@@ -217,7 +217,9 @@ def test_single_steps_vs_reference_golden(L, dev, golden_dir):
             self.t = t
             return {"pred_x_start": self.x0}
 
-    for n, rs, idx in [(50, "", 49), (50, "", 7), (50, "", 0), (100, "ddim10", 9), (100, "ddim10", 3), (100, "ddim10", 0)]:
+    for n, rs, idx in [(50, "", 49), (50, "", 7), (50, "", 0), (100, "ddim10", 9), (100, "ddim10", 3), (100, "ddim10", 0),
+                       (100, "ddim50", 49), (100, "ddim50", 17), (100, "ddim50", 0), (1000, "ddim50", 49), (1000, "ddim50", 1),
+                       (1000, "", 999), (1000, "", 500), (1000, "", 3), (1000, "", 0)]:      # + BASELINE config 4 / 5 schedules
         tag = f"n{n}_{rs or 'ddpm'}_i{idx}"
         d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
         x, x0, eps = (torch.from_numpy(g[f"{tag}__{k}"]).to(dev) for k in ("x", "x0", "eps"))
@@ -284,7 +286,12 @@ def test_end_to_end_vs_reference_golden(golden_dir, dev, model, name, route, pre
         if route == "fused":
             res = model.fused_sampler.run(d, b, noise, ddim=bool(rs), trace=True)
             o = res["other_outputs"]
-            np.testing.assert_allclose(model.fused_sampler.last_trace.cpu().numpy(), g["x_t_trace"], atol=5e-5)
+            tr = model.fused_sampler.last_trace.cpu().numpy()
+            low = model.fused_sampler.lowprec_steps(d.num_timesteps)          # leading steps on plain f16 operands (precision schedule)
+            np.testing.assert_allclose(tr[:low + 1], g["x_t_trace"][:low + 1], atol=2e-3)     # x_t fed to those steps + the first f16x3 one
+            if low + 4 < d.num_timesteps:                                     # the early steps' rounding is contracted away step by step
+                np.testing.assert_allclose(tr[low + 4:], g["x_t_trace"][low + 4:], atol=1e-4)
+            np.testing.assert_allclose(tr[-1], g["x_t_trace"][-1], atol=5e-5)
         else:
             d.allow_fused = False    # force the Python-driven loop: model(batch, t) + ehm_ddpm_step / ehm_ddim_step per step
             o = d.val_losses(model, b, shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False,

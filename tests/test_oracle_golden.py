@@ -94,7 +94,9 @@ def test_g7_single_steps(golden_dir):
             self.t = t
             return {"pred_x_start": self.x0}
 
-    for n, rs, idx in [(50, "", 49), (50, "", 7), (50, "", 0), (100, "ddim10", 9), (100, "ddim10", 3), (100, "ddim10", 0)]:
+    for n, rs, idx in [(50, "", 49), (50, "", 7), (50, "", 0), (100, "ddim10", 9), (100, "ddim10", 3), (100, "ddim10", 0),
+                       (100, "ddim50", 49), (100, "ddim50", 17), (100, "ddim50", 0), (1000, "ddim50", 49), (1000, "ddim50", 1),
+                       (1000, "", 999), (1000, "", 500), (1000, "", 3), (1000, "", 0)]:      # + BASELINE config 4 / 5 schedules
         tag = f"n{n}_{rs or 'ddpm'}_i{idx}"
         full = schedule.make_tables(n, rs)
         # run exactly one step: tables truncated so that the loop's single index is ``idx``
@@ -184,3 +186,29 @@ def test_g13_gcn_with_non_local_block(golden_dir):
     np.testing.assert_allclose(y.numpy(), g["y"], atol=1e-5)
     y0 = om.modulated_gcn(sd, x, om.smpl_adjacency(), num_blocks=1, nonlocal_layer=False)
     assert float((y - y0).abs().max()) > 1e-2          # the block is not an identity with these weights
+
+
+@pytest.mark.parametrize("name", ["g14_e2e_ddim50_of_100", "g14_e2e_ddpm50_volsmpl_guided"])
+def test_g14_c4_schedule_and_volsmpl_twin(golden_dir, synth_weights, smpl_asset, name):
+    """BASELINE config 4's 'ddim50' respacing end to end, and the VolSMPL twin (models/egohmr/egohmr_volsmpl.py:582-629: batched
+    collision loss over ALL scene points, -loss.sum(), w = 30) with both collision metrics (egohmr.py:487-514,
+    egohmr_volsmpl.py:548-579), against the reference's own run (oracle/make_golden.py g14_*).  The 1000-step goldens of the set
+    are checked on the GPU only (tests/test_gpu_configs.py): a thousand CPU evaluations do not belong in this suite."""
+    g = _load(golden_dir, name)
+    B, N, n, rs = int(g["B"]), int(g["N"]), int(g["n"]), str(g["respacing"])
+    guided = bool(g["guided"])
+    b = _tt(syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"])))
+    if guided:
+        b["scene_pcd_verts_full"][:, : N // 3, 1] = b["smpl_params"]["transl"][:, None, 1] - 0.6
+    tab = schedule.make_tables(n, rs)
+    noise = torch.from_numpy(syn.make_noise_stack(tab.num_timesteps, B, seed=int(g["noise_seed"])))
+    m = _model(synth_weights, smpl_asset, faithful=False, collision_loss=proxy_collision_loss)
+    o = sampler.val_losses(m, b, tab, noise, rs, cond_fn_with_grad=guided, cond_grad_weight=float(g["cond_grad_weight"]),
+                           guide_reduction="sum" if guided else "mean", guide_all_points=guided)
+    _check_out(o, g)
+    if guided:
+        np.testing.assert_allclose(np.array(m.eval_coll(o)), g["eval_coll"], atol=1e-12)
+        np.testing.assert_allclose(np.array(m.eval_coll(o)), g["eval_coll_volsmpl"], atol=1e-12)
+        assert g["eval_coll"].max() > 0                       # the floor does cut through the bodies of this fixture
+        o_mean = sampler.val_losses(m, b, tab, noise, rs, cond_fn_with_grad=True, cond_grad_weight=float(g["cond_grad_weight"]))
+        assert float((o_mean["pred_x_start"] - o["pred_x_start"]).abs().max()) > 3e-5     # ... and the COAP-style variant (mean over B, bbox) differs

@@ -346,8 +346,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     ++stamp_it;
 #endif
     TSTAMP(0);
-    // ---- head: stages 0 / 1 of `cur` are in flight (plus, possibly, the previous tile's stores)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- head: stages 0 / 1 of `cur` are in flight (plus, possibly, the previous tile's stores).  Stage 1's six activation pieces are
+    //      always the LAST memory instructions a wave has issued: wait for everything older (vmcnt counts in issue order) - my stores
+    //      have reached L2, stage 0 has landed - and leave those six to the first K tile's own wait.
+#ifdef EHM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stamp stores of lane 0 sit behind the six DMAs)
+#else
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
     __syncthreads();
     if (pending_publish) { publish(prev); pending_publish = false; }
     TSTAMP(5);
@@ -465,30 +471,34 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     const bool out_f32 = io.out_f32 != 0, has_res = io.Res != nullptr, relu = io.relu != 0;
     const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(io.Y + ((size_t)cur.m_tile * 192 + 96 * wm) * (out_f32 ? (size_t)N * 4 : (size_t)arow));
     const __amdgpu_buffer_rsrc_t resB = ehm_buffer_rsrc((has_res ? io.Res : io.Y) + ((size_t)cur.m_tile * 192 + 96 * wm) * arow);
-    // item (it, lane): scratch row it*8 + (lane>>3) of the pass, channels 4*(lane&7) .. +3 of the wave's 32
-    const int lr = lane >> 3, c4 = 4 * (lane & 7);
-    const int ch0 = 64 * cur.n_tile + 32 * wn + c4;                        // first channel of my items
-    unsigned int vo_in, vo_out;                                             // lane offsets: residual / output accesses (without the item's row block)
-    if constexpr (P == 3) vo_in = (unsigned int)lr * arow + (unsigned int)(((ch0 >> 5) * 64 + (ch0 & 31)) * 2);   // X2: 4 hi halves here, 4 lo halves 64 B on
-    else vo_in = (unsigned int)lr * arow + (unsigned int)ch0 * 2u;
-    vo_out = out_f32 ? (unsigned int)lr * tblrow + (unsigned int)ch0 * 4u : vo_in;
+    // item (it, lane), it = 0..2 per pass: scratch row rl = 16 it + (lane>>2), channels 8 (lane&3) .. +7 of the wave's 32: 16 bytes of f16
+    // (32 of float32) per lane, 4 lanes per 64-byte row segment, 16 rows per wave instruction
+    const int lr = lane >> 2, c8 = 8 * (lane & 3);
+    const int ch0 = 64 * cur.n_tile + 32 * wn + c8;                        // first channel of my items
+    unsigned int col_in, col_out;                                           // byte offsets of the item's columns: residual / output
+    if constexpr (P == 3) col_in = (unsigned int)(((ch0 >> 5) * 64 + (ch0 & 31)) * 2);   // X2: 8 hi halves here, 8 lo halves 64 B on
+    else col_in = (unsigned int)ch0 * 2u;
+    col_out = out_f32 ? (unsigned int)ch0 * 4u : col_in;
     const unsigned int orow = out_f32 ? tblrow : arow;
-    // wave row of item `it` in pass `p` (before + lr):  P == 1: pass = half-wave x: 48 p + 8 it;  P == 3: pass = body beta: 48 (it/3) + 24 p + 8 (it%3)
-    auto item_row = [](int p, int it) { return P == 1 ? 48 * p + 8 * it : 48 * (it / 3) + 24 * p + 8 * (it % 3); };
-    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    // wave row of scratch row rl in pass p:  P == 1: pass = half-wave x -> 48 p + rl;  P == 3: pass = body beta, scratch rows = 24 g + joint
+    // -> 48 (rl / 24) + 24 p + rl % 24
+    auto item_vrow = [&](int p, int it) -> unsigned int {
+      const int rl = 16 * it + lr;
+      return (unsigned int)(P == 1 ? 48 * p + rl : 24 * p + rl + (rl >= 24 ? 24 : 0));
+    };
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    u32x2_t rq[P == 3 ? 12 : 12];                                          // residual of the CURRENT pass (P == 3: hi and lo) / of both passes (P == 1)
+    u32x4_t rq[6];                                                         // residual: P == 1 both passes (3 + 3 items), P == 3 the current pass (hi, lo per item)
     auto load_res_pass = [&](int p) {
       if (has_res) {
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
+        for (int it = 0; it < 3; ++it) {
+          const unsigned int vo = item_vrow(p, it) * arow + col_in;
           if constexpr (P == 3) {
-            rq[2 * it] = __builtin_amdgcn_raw_buffer_load_b64(resB, vo_in, item_row(p, it) * arow, kLoadAux);
-            rq[2 * it + 1] = __builtin_amdgcn_raw_buffer_load_b64(resB, vo_in + 64u, item_row(p, it) * arow, kLoadAux);
+            rq[2 * it] = __builtin_amdgcn_raw_buffer_load_b128(resB, vo, 0, kLoadAux);
+            rq[2 * it + 1] = __builtin_amdgcn_raw_buffer_load_b128(resB, vo + 64u, 0, kLoadAux);
           } else {
-            rq[6 * p + it] = __builtin_amdgcn_raw_buffer_load_b64(resB, vo_in, item_row(p, it) * arow, kLoadAux);
+            rq[3 * p + it] = __builtin_amdgcn_raw_buffer_load_b128(resB, vo, 0, kLoadAux);
           }
         }
       }
@@ -586,43 +596,47 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
       wbase = STG + wave * 256 + 3072 * g + mi;                  // scratch row 24 g + joint
     }
     TSTAMP(7);
-    const int rbase = STG + wave * 256 + 4 * lane;               // item it at + 1024 it floats (16 bytes per lane, 1 KiB per wave instruction)
+    const int rbase = STG + wave * 256 + (lr >> 3) * 1024 + (lr & 7) * 32 + c8;   // item it at + 2048 it floats
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (P == 3) { if (p == 1) load_res_pass(1); }
 #pragma unroll
       for (int k = 0; k < 24; ++k) lds[wbase + vimm(k)] = V[p][k];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-private: program order is enough
-      f32x4 t[6];
+      f32x4 t[3][2];
 #pragma unroll
-      for (int it = 0; it < 6; ++it) t[it] = *(const f32x4*)(lds + rbase + 1024 * it);
+      for (int it = 0; it < 3; ++it) {
+        t[it][0] = *(const f32x4*)(lds + rbase + 2048 * it);
+        t[it][1] = *(const f32x4*)(lds + rbase + 2048 * it + 4);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        f32x4 v = t[it];
+      for (int it = 0; it < 3; ++it) {
+        float v[8] = {t[it][0][0], t[it][0][1], t[it][0][2], t[it][0][3], t[it][1][0], t[it][1][1], t[it][1][2], t[it][1][3]};
         if (has_res) {
           if constexpr (P == 3) {
-            const half4_t rh = __builtin_bit_cast(half4_t, rq[2 * it]), rl = __builtin_bit_cast(half4_t, rq[2 * it + 1]);
+            const half8 rh = __builtin_bit_cast(half8, rq[2 * it]), rl = __builtin_bit_cast(half8, rq[2 * it + 1]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += (float)rh[c] + (float)rl[c];
+            for (int c = 0; c < 8; ++c) v[c] += (float)rh[c] + (float)rl[c];
           } else {
-            const half4_t rh = __builtin_bit_cast(half4_t, rq[6 * p + it]);
+            const half8 rh = __builtin_bit_cast(half8, rq[3 * p + it]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += (float)rh[c];
+            for (int c = 0; c < 8; ++c) v[c] += (float)rh[c];
           }
         }
-        const unsigned int so = (unsigned int)item_row(p, it) * orow;
+        const unsigned int vo = item_vrow(p, it) * orow + col_out;
         if (out_f32) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yB, vo_out, so, kStoreAux);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]}), yB, vo, 0, kStoreAux);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v[4], v[5], v[6], v[7]}), yB, vo + 16u, 0, kStoreAux);
         } else {
-          half4_t hh, ll;
+          half8 hh, ll;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < 8; ++c) {
             hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
             if constexpr (P == 3) ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hh), yB, vo_out, so, kStoreAux);
-          if constexpr (P == 3) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ll), yB, vo_out + 64u, so, kStoreAux);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, kStoreAux);
+          if constexpr (P == 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, kStoreAux);
         }
       }
     }

@@ -629,7 +629,10 @@ extern "C" int ehm_gcn_stack_status(ehm_gcn* h, void* stream) {
   if (h->chain_sticky) {
     EHM_HIP(hipMemcpyAsync(&flag, h->chain_sticky, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
     EHM_HIP(hipStreamSynchronize((hipStream_t)stream));
-    if (flag) EHM_HIP(hipMemsetAsync(h->chain_sticky, 0, sizeof(flag), (hipStream_t)stream));
+    if (flag) {
+      EHM_HIP(hipMemsetAsync(h->chain_sticky, 0, sizeof(flag), (hipStream_t)stream));
+      h->chain_sync_clean = 0;            // a launch that gave up may have left tickets / counters behind
+    }
   }
   if (flag) {
     ehm_set_error("ehm_gcn_hidden_stack: a chained launch since the last status call timed out waiting for a producer tile, or left tiles "
@@ -647,6 +650,7 @@ int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad) {
   h->chain_sync_words = 0;
   EHM_HIP(hipMalloc(&h->chain_sync, need * sizeof(unsigned int)));
   h->chain_sync_words = need;
+  h->chain_sync_clean = 0;
   if (h->hs) EHM_HIP(hipFree(h->hs));
   h->hs = nullptr;
   h->hs_rows = 0;
@@ -678,6 +682,22 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
                        h->hs, rows);
   hipLaunchKernelGGL(gcn_out_mix_kernel, dim3(B), dim3(192), 0, (hipStream_t)stream, h->hs, h->out, vis, x0, B, passes);
   EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const float** hs, const void** out_dev, hipStream_t st) {
+  const int64_t rows = (int64_t)passes * B * kJ;
+  if (rows > h->hs_rows) {
+    const int rc = ehm_gcn_reserve_rows(h, round_up(rows, BM));
+    if (rc != 0) return rc;
+  }
+  if (h->precision == EHM_PREC_F16)
+    hipLaunchKernelGGL(gcn_out_dot_kernel<true>, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, st, X, h->out, h->hs, rows);
+  else
+    hipLaunchKernelGGL(gcn_out_dot_kernel<false>, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, st, X, h->out, h->hs, rows);
+  EHM_LAUNCH_CHECK();
+  *hs = h->hs;
+  *out_dev = &h->out;
   return 0;
 }
 

@@ -50,6 +50,8 @@ struct ehm_gcn {
   unsigned int* chain_sync = nullptr;    // tickets[8] | done[nl][m_tiles] | err | finished, zeroed before every chained launch
   unsigned int* chain_sticky = nullptr;  // one word, zeroed at create / by ehm_gcn_stack_status: accumulates the launches' err flags
   size_t chain_sync_words = 0;
+  int chain_sync_clean = 0;              // 1: the last chained launch zeroed tickets / done / finished itself (its last block does)
+  int64_t chain_sync_shape = 0;          // nl * m_tiles the words were last used with (err sits right behind done[])
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
   int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (f16 modes), 0 = one launch per conv (EHM_F16_CHAIN=0)
   OutDev out{};

@@ -674,19 +674,27 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   }
 
   if constexpr (CHAIN) {
-    // audit: the last block to run out of tickets checks that every row tile of the last conv was produced by all its channel tiles
-    // (a queue whose XCD received no block - CU masking - would otherwise go unnoticed)
+    // audit + reset: the last block to run out of tickets checks that every row tile of the last conv was produced by all its channel
+    // tiles (a queue whose XCD received no block - CU masking - would otherwise go unnoticed), then zeroes the tickets and counters
+    // for the NEXT launch on this handle (stream order): no memset node between the steps of a sampling loop.
+    __syncthreads();
     if (tid == 0) {
       const unsigned int old = __hip_atomic_fetch_add(a.finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == gridDim.x - 1) {
-        bool ok = true;
-        for (int m = 0; m < a.m_tiles; ++m)
-          ok = ok && __hip_atomic_load(&a.done[(size_t)(a.nl - 1) * a.m_tiles + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)a.n_tiles;
-        if (!ok) {
-          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+      slot[0] = old == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (slot[0]) {
+      bool ok = true;
+      for (int m = tid; m < a.m_tiles; m += 256)
+        ok = ok && __hip_atomic_load(&a.done[(size_t)(a.nl - 1) * a.m_tiles + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)a.n_tiles;
+      if (!ok) {
+        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      __syncthreads();
+      for (int i = tid; i < a.nl * a.m_tiles; i += 256) a.done[i] = 0u;
+      if (tid < 8) a.tickets[tid] = 0u;
+      if (tid == 0) *a.finished = 0u;
     }
   }
 }
@@ -788,7 +796,11 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
     const int rc = ehm_gcn_reserve_rows(h, rows_pad);
     if (rc != 0) return rc;
   }
-  EHM_HIP(hipMemsetAsync(h->chain_sync, 0, need * sizeof(unsigned int), st));
+  if (!h->chain_sync_clean || h->chain_sync_shape != (int64_t)nl * m_tiles) {   // otherwise the previous launch left the words zeroed
+    EHM_HIP(hipMemsetAsync(h->chain_sync, 0, h->chain_sync_words * sizeof(unsigned int), st));
+    h->chain_sync_shape = (int64_t)nl * m_tiles;
+  }
+  h->chain_sync_clean = 1;
   ChainArgs a;
   a.layers = h->hidden_dev;
   for (int i = 0; i < 3; ++i) a.buf[i] = bufs[i];

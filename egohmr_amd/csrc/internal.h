@@ -10,11 +10,18 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
 // rot6d -> R, joint regression, kinematic chain only (no skinning): R [B,24,9], A [B,24,12], joints24 into jws [B,(24+n_extra),3]
 int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_, float* Rws, float* Aws,
                        float* jws, int B, hipStream_t st);
+// output-conv mix + sampler update + pose chain + blend-coefficient fragments in one launch, then skinning (sampling loop only)
+int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
+                       const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, int do_pose,
+                       const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
+                       float* pose6d, int B, hipStream_t st);
 int ehm_smpl_num_verts(const ehm_smpl* h);
 int ehm_smpl_num_extra(const ehm_smpl* h);
 // gcn.hip
 int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
+// output conv, first half only: responses hs [passes*B*24, 12] = X . [W0 | W1] (scratch owned by the handle); *out_dev = the OutDev block
+int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const float** hs, const void** out_dev, hipStream_t st);
 // sampler.hip
 int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 // gcn_tile.hip (f16 matrix-core hidden convs: 'f16x3' split operands and plain 'f16')

@@ -168,30 +168,27 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     if (lowprec > 0) ehm_gcn_set_precision(gcn, k < lowprec ? 2 : base_prec);   // host-side kernel choice only; same X2 buffers
     const bool last = k == d->num_steps - 1;
     if (trace) EHM_HIP(hipMemcpyAsync(trace + (int64_t)k * n, w.x_cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257) ----
-    rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
-    int in = 0;
-    if (rc == 0) rc = ehm_gcn_hidden_stack(gcn, w.X, w.rows_pad, &in, st);
-    if (rc == 0) rc = ehm_gcn_output_layer(gcn, w.X[in], vis, x0_final, B, d->passes, st);
-    // ---- body decode (egohmr.py:258-278) ----
-    if (rc == 0 && (d->lbs_every_step || last))
-      rc = ehm_smpl_forward_impl(smpl, betas, x0_final, true, mean, std_, verts, joints, R, w.A, pose6d, B, st);
-    // ---- collision guidance on x_t (gaussian_diffusion.py:378-385, egohmr.py:517-570) ----
+    // ---- collision guidance on x_t (gaussian_diffusion.py:378-385, egohmr.py:517-570): depends on x_t and betas only, so it runs first
     const float* grad = nullptr;
-    if (rc == 0 && c.grad_scale != 0.f) {
+    if (c.grad_scale != 0.f) {
       rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom, d->guide_all_points ? d->tau : 0.f,
                              w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, w.g_scratch, st);
       grad = w.g_grad;
     }
-    // ---- x_{t-1} ----
+    // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257): input conv, chained hidden convs, output conv responses ----
+    if (rc == 0) rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
+    int in = 0;
+    if (rc == 0) rc = ehm_gcn_hidden_stack(gcn, w.X, w.rows_pad, &in, st);
+    const float* hs = nullptr;
+    const void* out_dev = nullptr;
+    if (rc == 0) rc = ehm_gcn_output_dot_impl(gcn, w.X[in], B, d->passes, &hs, &out_dev, st);
+    // ---- per body, one launch: output-conv mix + visibility fuse -> x0 (egohmr.py:247-256), x_{t-1} (gaussian_diffusion.py:298-337 /
+    //      :511-556), de-normalise + rot6d + kinematic chain (egohmr.py:258-260); then the skinning launch (egohmr.py:276) ----
     if (rc == 0) {
       const float* eps = noise + (int64_t)(1 + k) * n;
       float* dst = last ? x_final : w.x_cur;
-      if (d->ddim)
-        rc = ehm_ddim_step(w.x_cur, x0_final, eps, dst, c.sqrt_recip_ac, c.sqrt_recipm1_ac, c.sqrt_ac_prev, c.dir_coef, c.sigma,
-                           c.nonzero, n, st);
-      else
-        rc = ehm_ddpm_step(w.x_cur, x0_final, eps, grad, dst, c.coef1, c.coef2, c.log_variance, c.nonzero, c.grad_scale, n, st);
+      rc = ehm_step_body_impl(smpl, hs, out_dev, vis, w.x_cur, eps, grad, dst, x0_final, &c, d->ddim, d->passes, (d->lbs_every_step || last) ? 1 : 0,
+                              betas, mean, std_, verts, joints, R, w.A, pose6d, B, st);
     }
   }
   if (lowprec > 0) ehm_gcn_set_precision(gcn, base_prec);

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "egohmr_hip.h"
 #include "internal.h"
+#include "gcn_dev.h"
 #include "smpl_dev.h"
 
 namespace {
@@ -76,14 +77,12 @@ __global__ void rot6d_kernel(const float* __restrict__ x, float* __restrict__ Ro
 }
 
 // ------------------------------------------------------------------------------------------------ pose + chain
+// One wave per body, lane = joint.  `Rl` (may be nullptr): LDS copy [24][9] of the rotations for a caller that goes on to pack them.
 template <bool FROM_ROT6D>
-__global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rot_or_x,
-                                                        const float* __restrict__ mean, const float* __restrict__ std_,
-                                                        SmplDev S, float* __restrict__ Rws, float* __restrict__ Aout,
-                                                        float* __restrict__ joints, float* __restrict__ pose6d_out,
-                                                        int joints_stride) {
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void pose_chain_body(int b, int lane, const float* __restrict__ betas, const float* rot_or_x /* this body's row */,
+                                                const float* __restrict__ mean, const float* __restrict__ std_, const SmplDev& S,
+                                                float* __restrict__ Rws, float* __restrict__ Aout, float* __restrict__ joints,
+                                                float* __restrict__ pose6d_out, int joints_stride, float* Rl) {
   const int j = lane < kJ ? lane : 0;
   float R[9];
   if (FROM_ROT6D) {
@@ -91,13 +90,13 @@ __global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int e = j * 6 + c;
-      p[c] = rot_or_x[(size_t)b * kPoseDim + e] * std_[e] + mean[e];   // egohmr.py:258
+      p[c] = rot_or_x[e] * std_[e] + mean[e];                          // egohmr.py:258
       if (pose6d_out && lane < kJ) pose6d_out[(size_t)b * kPoseDim + e] = p[c];
     }
     rot6d_to_R(p[0], p[2], p[4], p[1], p[3], p[5], R);                 // 'diffusion' layout
   } else {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = rot_or_x[((size_t)b * kJ + j) * 9 + k];
+    for (int k = 0; k < 9; ++k) R[k] = rot_or_x[j * 9 + k];
   }
   // joint regression: J = J_template + J_shape . beta
   float Jx[3];
@@ -144,6 +143,10 @@ __global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rws[o * 9 + k] = R[k];
   }
+  if (Rl) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rl[j * 9 + k] = R[k];
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     joints[(size_t)b * joints_stride + j * 3 + r] = G[r * 4 + 3];           // posed joint = chain translation
@@ -153,6 +156,16 @@ __global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict_
     Aout[o * 12 + r * 4 + 2] = G[r * 4 + 2];
     Aout[o * 12 + r * 4 + 3] = G[r * 4 + 3] - gj;                              // rel_transforms
   }
+}
+
+template <bool FROM_ROT6D>
+__global__ __launch_bounds__(64) void pose_chain_kernel(const float* __restrict__ betas, const float* __restrict__ rot_or_x,
+                                                        const float* __restrict__ mean, const float* __restrict__ std_,
+                                                        SmplDev S, float* __restrict__ Rws, float* __restrict__ Aout,
+                                                        float* __restrict__ joints, float* __restrict__ pose6d_out,
+                                                        int joints_stride) {
+  pose_chain_body<FROM_ROT6D>(blockIdx.x, threadIdx.x, betas, rot_or_x + (size_t)blockIdx.x * (FROM_ROT6D ? kPoseDim : kJ * 9), mean, std_, S, Rws, Aout,
+                              joints, pose6d_out, joints_stride, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ skinning
@@ -259,9 +272,9 @@ __global__ __launch_bounds__(kVT, 2) void skin_kernel(const float* __restrict__ 
     }
     if (bb < nb) {
       float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
-      o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
-      o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
-      o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      const float ox = T[0] * px + T[1] * py + T[2] * pz + T[3], oy = T[4] * px + T[5] * py + T[6] * pz + T[7],
+                  oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      o[0] = ox; o[1] = oy; o[2] = oz;
     }
   }
 }
@@ -322,8 +335,10 @@ __global__ void pf_pack_kernel(const float* __restrict__ Rws, const float* __res
   out[(base + 1) * 64 + lane] = lo;
 }
 
+// `joints` (may be nullptr): rows [24 + n_extra][3] per body; the VertexJointSelector's extra joints (smplx vertex_joint_selector.py: 21
+// picked vertices) are written by the lane that owns the vertex - no separate gather launch.
 __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restrict__ PF, const float* __restrict__ A, SmplDev S,
-                                                        float* __restrict__ verts, int B, int v_tiles, int vt_groups) {
+                                                        float* __restrict__ verts, float* __restrict__ joints, int B, int v_tiles, int vt_groups) {
   __shared__ __attribute__((aligned(16))) float sA[32][kJ][12];   // 36 KiB: skinning transforms of the block's 32 bodies
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order: the blocks of one XCD walk the body tiles of the same vertex-tile group back to back (basis fragments from L2)
@@ -374,6 +389,9 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
   int jsp[4];
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) { wsp[s4] = S.w_val[(size_t)s4 * S.V + v]; jsp[s4] = S.w_idx[(size_t)s4 * S.V + v]; }
+  unsigned long long slots = 0;                               // extra joints that are copies of my vertex (none for almost every lane)
+  if (joints)
+    for (int e = 0; e < S.n_extra; ++e) slots |= (unsigned long long)(S.extra_idx[e] == v) << e;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int bb = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -393,9 +411,13 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
     }
     if (bb < nb) {
       float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
-      o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
-      o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
-      o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      const float ox = T[0] * px + T[1] * py + T[2] * pz + T[3], oy = T[4] * px + T[5] * py + T[6] * pz + T[7],
+                  oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      o[0] = ox; o[1] = oy; o[2] = oz;
+      for (unsigned long long m = slots; m; m &= m - 1) {
+        float* q = joints + ((size_t)(b0 + bb) * (kJ + S.n_extra) + kJ + __builtin_ctzll(m)) * 3;
+        q[0] = ox; q[1] = oy; q[2] = oz;
+      }
     }
   }
 }
@@ -572,15 +594,143 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
                        (sk_half8*)h->pf, B, b_tiles);
     const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
     const int blocks = (int)round_up(vt_groups, 8) * b_tiles;
-    hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const sk_half8*)h->pf, Aws, d, verts, B, v_tiles, vt_groups);
+    hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B,
+                       v_tiles, vt_groups);
   } else {
     const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
     const int blocks = (int)round_up(v_tiles, 8) * b_groups;
     hipLaunchKernelGGL(skin_kernel, dim3(blocks), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);
+    if (d.n_extra)
+      hipLaunchKernelGGL(extra_joints_kernel, dim3((unsigned)ceil_div((int64_t)B * d.n_extra * 3, 256)), dim3(256), 0, st, verts,
+                         d.extra_idx, joints, B, d.V, d.n_extra);
   }
-  if (d.n_extra)
-    hipLaunchKernelGGL(extra_joints_kernel, dim3((unsigned)ceil_div((int64_t)B * d.n_extra * 3, 256)), dim3(256), 0, st, verts,
-                       d.extra_idx, joints, B, d.V, d.n_extra);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ fused per-body step (sampling loop)
+// One launch per denoising step for everything that is per body and tiny - in the round-1 loop four launches (gcn_out_mix, ddpm / ddim
+// step, pose_chain, pf_pack: ~5 us each, all latency):
+//   (1) output conv: modulated adjacency mix of the [24 x 12] responses + bias, visibility fuse of the two passes -> x0 [144]
+//       (modulated_gcn_conv.py:47, egohmr.py:247-256; same operation order as gcn_out_mix_kernel)
+//   (2) sampler update x_t -> x_{t-1} (gaussian_diffusion.py:217-220,:333-336,:378-385 / :286-290,:539-555; roundings ordered like the
+//       eager torch ops, as ddpm_step_kernel / ddim_step_kernel)
+//   (3) de-normalise, rot6d -> R, joint regression, 24-joint kinematic chain by wave shuffles -> R, skinning transforms A, joints
+//   (4) the body's blend coefficients [R[1:] - I | betas] as split-f16 MFMA fragments for skin_mfma_kernel.
+// One wave per body.
+struct StepBodyArgs {
+  const float* hs;          // [passes*B*24, 12] responses of the output conv (gcn_out_dot_kernel)
+  OutDev O;
+  const uint8_t* vis;       // [B,24]
+  const float* x;           // x_t [B,144]
+  const float* noise;       // [B,144]
+  const float* grad;        // [B,144] or nullptr
+  float* x_next;            // may alias x
+  float* x0;                // [B,144]
+  ehm_step_coefs c;
+  int ddim, passes, B, do_pose;
+  const float *betas, *mean, *std_;
+  float *Rws, *Aws, *joints, *pose6d;
+  int jstride;
+  sk_half8* pf;             // nullptr: VALU skinning path (B < 24), no fragments
+};
+
+__global__ __launch_bounds__(64) void step_body_kernel(StepBodyArgs a, SmplDev S) {
+  __shared__ float sh[2][kJ][12];
+  __shared__ float x0s[kPoseDim];
+  __shared__ float Rl[kJ * 9];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < a.passes * kJ * 12; i += 64) {
+    const int p = i / (kJ * 12), rem = i % (kJ * 12);
+    sh[p][rem / 12][rem % 12] = a.hs[((size_t)(p * a.B + b) * kJ) * 12 + rem];
+  }
+  __syncthreads();
+  for (int e = lane; e < kPoseDim; e += 64) {
+    const int j = e / 6, c = e % 6;
+    const int p = (a.passes == 2 && !a.vis[(size_t)b * kJ + j]) ? 1 : 0;          // egohmr.py:249-254
+    const float s = a.O.A[j * kJ + j] * (a.O.M[j * 6 + c] * sh[p][j][c]);
+    float t = 0.f;
+    for (int jp = 0; jp < kJ; ++jp)
+      if (jp != j) t = fmaf(a.O.A[j * kJ + jp], a.O.M[jp * 6 + c] * sh[p][jp][6 + c], t);
+    const float x0 = s + t + a.O.bias[c];
+    const size_t i = (size_t)b * kPoseDim + e;
+    a.x0[i] = x0;
+    x0s[e] = x0;
+    const float xv = a.x[i], nz = a.noise[i];
+    float out;
+    if (a.ddim) {
+      const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(a.c.sqrt_recip_ac, xv), x0), a.c.sqrt_recipm1_ac);
+      const float mean = __fadd_rn(__fmul_rn(x0, a.c.sqrt_ac_prev), __fmul_rn(a.c.dir_coef, eps));
+      out = __fadd_rn(mean, __fmul_rn(__fmul_rn(a.c.nonzero, a.c.sigma), nz));
+    } else {
+      float mean = __fadd_rn(__fmul_rn(a.c.coef1, x0), __fmul_rn(a.c.coef2, xv));
+      if (a.grad) mean = __fadd_rn(mean, __fmul_rn(a.c.grad_scale, a.grad[i]));
+      const float sd = expf(__fmul_rn(0.5f, a.c.log_variance));
+      out = __fadd_rn(mean, __fmul_rn(__fmul_rn(a.c.nonzero, sd), nz));
+    }
+    a.x_next[i] = out;
+  }
+  if (!a.do_pose) return;
+  __syncthreads();
+  pose_chain_body<true>(b, lane, a.betas, x0s, a.mean, a.std_, S, a.Rws, a.Aws, a.joints, a.pose6d, a.jstride, Rl);
+  if (!a.pf) return;
+  __syncthreads();
+  if (lane < 2 * kBlendSteps) {                                 // 28 lanes: (k-step s, lane half h) -> 8 coefficients, hi and lo fragments
+    const int s = lane >> 1, h = lane & 1;
+    sk_half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * s + 8 * h + e;
+      float x = 0.f;
+      if (k < kPoseBasis) x = Rl[9 + k] - ((k % 9 == 0 || k % 9 == 4 || k % 9 == 8) ? 1.f : 0.f);   // R[1:] - I
+      else if (k < kPoseBasis + 10) x = a.betas[(size_t)b * 10 + (k - kPoseBasis)];
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+    const size_t base = ((size_t)(b >> 5) * kBlendSteps + s) * 2;
+    a.pf[(base + 0) * 64 + (b & 31) + 32 * h] = hi;
+    a.pf[(base + 1) * 64 + (b & 31) + 32 * h] = lo;
+  }
+}
+
+// sampler.hip's per-step call: output-conv mix + sampler update + pose chain + fragment pack in one launch, then the skinning launch.
+int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
+                       const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, int do_pose,
+                       const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
+                       float* pose6d, int B, hipStream_t st) {
+  const SmplDev& d = h->d;
+  static const int mfma_min = getenv("EHM_SKIN_MFMA_MIN_B") ? atoi(getenv("EHM_SKIN_MFMA_MIN_B")) : 24;
+  const bool mfma = d.PDf && B >= mfma_min;
+  const int b_tiles = (int)ceil_div(B, 32);
+  if (mfma && 32 * b_tiles > h->pf_cap) {                    // grows on the first call with a larger batch only
+    if (h->pf) EHM_HIP(hipFree(h->pf));
+    h->pf = nullptr;
+    h->pf_cap = 0;
+    EHM_HIP(hipMalloc(&h->pf, (size_t)b_tiles * kBlendSteps * 2 * 64 * 16));
+    EHM_HIP(hipMemsetAsync(h->pf, 0, (size_t)b_tiles * kBlendSteps * 2 * 64 * 16, st));   // padding bodies of the last tile
+    h->pf_cap = 32 * b_tiles;
+  }
+  StepBodyArgs a;
+  a.hs = hs; a.O = *(const OutDev*)out_dev; a.vis = vis; a.x = x; a.noise = noise; a.grad = grad; a.x_next = x_next; a.x0 = x0;
+  a.c = *c; a.ddim = ddim; a.passes = passes; a.B = B; a.do_pose = do_pose;
+  a.betas = betas; a.mean = mean; a.std_ = std_; a.Rws = Rws; a.Aws = Aws; a.joints = joints; a.pose6d = pose6d;
+  a.jstride = (kJ + d.n_extra) * 3;
+  a.pf = mfma ? (sk_half8*)h->pf : nullptr;
+  hipLaunchKernelGGL(step_body_kernel, dim3(B), dim3(64), 0, st, a, d);
+  if (do_pose) {
+    if (mfma) {
+      const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
+      const int blocks = (int)round_up(vt_groups, 8) * b_tiles;
+      hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B,
+                         v_tiles, vt_groups);
+    } else {
+      const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
+      hipLaunchKernelGGL(skin_kernel, dim3((int)round_up(v_tiles, 8) * b_groups), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);
+      if (d.n_extra)
+        hipLaunchKernelGGL(extra_joints_kernel, dim3((unsigned)ceil_div((int64_t)B * d.n_extra * 3, 256)), dim3(256), 0, st, verts, d.extra_idx,
+                           joints, B, d.V, d.n_extra);
+    }
+  }
   EHM_LAUNCH_CHECK();
   return 0;
 }

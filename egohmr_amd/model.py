@@ -218,6 +218,11 @@ class EgoHMR(nn.Module):
         # errors of earlier steps are contracted away by the posterior mean, measured in tools/precision_schedule.py: final bodies
         # within 7e-6 m of the all-f16x3 run at B=256 for DDPM-100 / DDIM-50; the parity bar is 1e-4 m); an int = that k; None = off
         self.f16x3_last_steps = "auto"
+        # hipGraph replay of the whole T-step loop (one graph launch instead of ~5 T kernel launches), unguided loops only.  Off by
+        # default: measured on MI355X (tools/latency_small.py, profiles/r02_latency_b8_ddim5.json) the loop is GPU-bound even at B = 8
+        # (3.74 ms eager vs 3.73 ms replayed for DDIM-5: the eight chained convs of a step are a dependency chain of tile times),
+        # so the graph only saves host CPU time.  True = use it; 'auto' = for passes * B <= 64.
+        self.use_hip_graph = False
         self.fused_sampler = FusedSampler(self)
         self.to(dev)
         self.eval()
@@ -340,6 +345,7 @@ class FusedSampler:
         self._prep_key = None
         self._prep = None
         self._ws = None
+        self._graphs = {}
         self.last_trace = None
 
     @property
@@ -629,19 +635,57 @@ class FusedSampler:
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:
             raise _lib.EgoHMRHipError(f"ehm_sample_workspace_bytes rejected the descriptor (rc={nbytes})")
-        ws = self._workspace(nbytes, m.device)
         dev = m.device
-        x_final, x0 = torch.empty(B, 144, device=dev), torch.empty(B, 144, device=dev)
-        verts, joints = torch.empty(B, V, 3, device=dev), torch.empty(B, m.smpl.num_joints_out, 3, device=dev)
-        R, pose6d = torch.empty(B, 24, 3, 3, device=dev), torch.empty(B, 144, device=dev)
-        tr = torch.empty(T, B, 144, device=dev) if trace else None
         mean, std = m._std_mean()
+        gcn, smpl_h = self.gcn(), m.smpl.handle()
+
+        def launch(bufs, ws, tr):
+            _lib.check(L.ehm_sample_loop(gcn, smpl_h, C.byref(desc), steps, _lib.ptr(bufs.h_img), _lib.ptr(bufs.h_oth), _lib.ptr(bufs.vis),
+                                         _lib.ptr(self._folded.Wx), _lib.ptr(bufs.tvecs), _lib.ptr(bufs.noise),
+                                         _lib.ptr(bufs.scene) if any_guided else None, _lib.ptr(bufs.betas), _lib.ptr(mean), _lib.ptr(std),
+                                         _lib.ptr(bufs.x_final), _lib.ptr(bufs.x0), _lib.ptr(bufs.verts), _lib.ptr(bufs.joints), _lib.ptr(bufs.R),
+                                         _lib.ptr(bufs.pose6d), _lib.ptr(tr), _lib.ptr(ws), nbytes, _lib.stream_ptr()), "ehm_sample_loop")
+
+        def out_bufs():
+            return dict(x_final=torch.empty(B, 144, device=dev), x0=torch.empty(B, 144, device=dev), verts=torch.empty(B, V, 3, device=dev),
+                        joints=torch.empty(B, m.smpl.num_joints_out, 3, device=dev), R=torch.empty(B, 24, 3, 3, device=dev),
+                        pose6d=torch.empty(B, 144, device=dev))
+
+        ins = dict(h_img=st.h_img, h_oth=st.h_oth, vis=st.vis, tvecs=tvecs, noise=noise[: T + 1].contiguous(), betas=st.betas, scene=st.scene)
+        graph = m.use_hip_graph is True or (m.use_hip_graph == "auto" and desc.passes * B <= 64)
+        tr = None
         with torch.cuda.device(dev):
-            _lib.check(L.ehm_sample_loop(self.gcn(), m.smpl.handle(), C.byref(desc), steps, _lib.ptr(st.h_img), _lib.ptr(st.h_oth),
-                                         _lib.ptr(st.vis), _lib.ptr(self._folded.Wx), _lib.ptr(tvecs), _lib.ptr(noise),
-                                         _lib.ptr(st.scene) if any_guided else None, _lib.ptr(st.betas), _lib.ptr(mean), _lib.ptr(std),
-                                         _lib.ptr(x_final), _lib.ptr(x0), _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(R), _lib.ptr(pose6d),
-                                         _lib.ptr(tr), _lib.ptr(ws), nbytes, _lib.stream_ptr()), "ehm_sample_loop")
+            if graph and not any_guided and not trace:
+                # hipGraph route: the loop's launches are captured once per (shape, schedule) with every pointer inside persistent
+                # buffers; a call copies its inputs in, replays, and copies the results out.
+                key = (B, T, int(ddim), desc.passes, desc.lbs_every_step, desc.lowprec_steps, m.gcn_precision, self._gcn_key,
+                       bytes(steps), st.scene.shape[1])
+                ent = self._graphs.get(key)
+                if ent is None:
+                    if len(self._graphs) >= 8:
+                        self._graphs.clear()
+                    bufs = SimpleNamespace(**{k: torch.empty_like(v) for k, v in ins.items()}, **out_bufs())
+                    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+                    for k, v in ins.items():
+                        getattr(bufs, k).copy_(v)
+                    launch(bufs, ws, None)                       # eager once: every lazy allocation inside the library happens here
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        launch(bufs, ws, None)
+                    ent = self._graphs[key] = SimpleNamespace(graph=g, bufs=bufs, ws=ws)
+                for k, v in ins.items():
+                    getattr(ent.bufs, k).copy_(v)
+                ent.graph.replay()
+                o = SimpleNamespace(**{k: getattr(ent.bufs, k).clone() for k in ("x_final", "x0", "verts", "joints", "R", "pose6d")})
+            else:
+                o = SimpleNamespace(**ins, **out_bufs())
+                tr = torch.empty(T, B, 144, device=dev) if trace else None
+                launch(o, self._workspace(nbytes, dev), tr)
+            # a chained launch that gave up on a producer wait (GPU shared / preempted) flags the handle instead of hanging: one
+            # read-back per sampling call turns that into an exception rather than silently wrong bodies
+            _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
+        x_final, x0, verts, joints, R, pose6d = o.x_final, o.x0, o.verts, o.joints, o.R, o.pose6d
         self.last_trace = tr
         if tr is not None:
             batch["x_t"] = tr[-1]

@@ -314,3 +314,28 @@ def test_full_size_properties_c2():
     ortho, det = float((R @ R.transpose(1, 2) - eye).abs().max()), float((torch.linalg.det(R) - 1).abs().max())
     print(f"C2 full size: max|RR^T - I| = {ortho:.2e}, max|det - 1| = {det:.2e}")
     assert ortho < 1e-4 and det < 1e-4      # float32 Gram-Schmidt of nearly parallel 6-D pairs (geometry.py:61-66) is not tighter than this
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_equals_eager_enqueue():
+    """EgoHMR.use_hip_graph: the whole sampling loop captured once into a hipGraph (persistent buffers, inputs copied in, results copied
+    out) and replayed must reproduce the eager enqueue bit for bit, call after call, and for a second input batch of the same shape."""
+    from egohmr_amd import synthetic as syn
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    dev = torch.device("cuda:0")
+    model = build_synthetic_model(dev, 0)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=100, timestep_respacing="ddim10")
+    outs = {}
+    for seed in (3, 4):
+        b = batch_to_device(syn.make_batch(6, 1024, seed=seed), dev)
+        noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, 6, seed=seed)).to(dev)
+        for mode in (False, True, True):
+            model.use_hip_graph = mode
+            o = model.fused_sampler.run(d, b, noise, ddim=True)["other_outputs"]
+            outs.setdefault(seed, []).append((o["pred_vertices"].clone(), o["pred_x_start"].clone()))
+    assert len(model.fused_sampler._graphs) == 1                       # one capture served both batches
+    for seed, runs in outs.items():
+        for v, x in runs[1:]:
+            assert torch.equal(v, runs[0][0]) and torch.equal(x, runs[0][1]), seed
+    assert not torch.equal(outs[3][0][0], outs[4][0][0])

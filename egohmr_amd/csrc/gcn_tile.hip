@@ -349,13 +349,19 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     // ---- head: stages 0 / 1 of `cur` are in flight (plus, possibly, the previous tile's stores).  Stage 1's six activation pieces are
     //      always the LAST memory instructions a wave has issued: wait for everything older (vmcnt counts in issue order) - my stores
     //      have reached L2, stage 0 has landed - and leave those six to the first K tile's own wait.
+    //      When the previous tile's stores are still in flight (early path) they were issued AFTER stage 0's DMA and before those six:
+    //      the K loop only needs stage 0, so leave the stores outstanding too and publish behind the first K tile's vmcnt(0) + barrier.
 #ifdef EHM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stamp stores of lane 0 sit behind the six DMAs)
 #else
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (pending_publish) {
+      if constexpr (P == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // 12 sixteen-byte stores per wave and tile (X2 hi + lo, or float32)
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                   // 6
+    } else {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
 #endif
     __syncthreads();
-    if (pending_publish) { publish(prev); pending_publish = false; }
     TSTAMP(5);
     thread_consts();
     unsigned int t_next = 0xffffffffu;
@@ -388,6 +394,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     for (int kt = 0; kt < KT - 2; ++kt) {
       const int buf = kt & 1;
       phases_before_barrier(buf);
+      if (pending_publish) { publish(prev); pending_publish = false; }     // every wave's stores of the previous tile have landed (vmcnt(0) + barrier)
       read_frags(f0, buf ^ 1, 0);              // (KS even: the next tile starts on set 0 again)
       stage(buf, kt + 2);
       mfmas(f_last);
@@ -397,14 +404,15 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
       if (tid == 0 && t_next < total) {        // were the producers of my NEXT tile complete already?
         Tile tn;
         decode(t_next, tn);
-        dep_seen = tn.layer == 0 ? 1u
-                   : (tn.layer == cur.layer &&                 // (a tile of a LATER layer may depend on the tile I am computing)
-                      __hip_atomic_load(dep_flag(tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)a.n_tiles) ? 1u : 0u;
+        // one relaxed read, no waiting: a next tile that depends on the tile I am still computing (next layer, same rows) simply reads
+        // an incomplete counter and takes the late path; nobody ever WAITS while holding an unpublished tile, so no cycle can form
+        dep_seen = (tn.layer == 0 || __hip_atomic_load(dep_flag(tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)a.n_tiles) ? 1u : 0u;
       }
     }
     {
       const int buf = (KT - 2) & 1;
       phases_before_barrier(buf);
+      if (pending_publish) { publish(prev); pending_publish = false; }     // (KT == 2: the loop above did not run)
       if constexpr (CHAIN)
         if (tid == 0) { slot[0] = t_next; slot[1] = dep_seen; }   // stage `buf` is dead from here on
       read_frags(f0, buf ^ 1, 0);

@@ -294,7 +294,44 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict_
   // 24x24 adjacency mix per lane (one channel), then through a float [24][256] LDS tile so that the rows leave as 16-byte stores
   // (one dword per lane and joint is store-issue bound: 30 us for 48 MiB).
   __shared__ __attribute__((aligned(16))) float T[kJ * 256];
-  {
+  if constexpr (OUT == 2) {
+    // 'f16' mode: the mix on the matrix cores, [Aoff | I] (24 x 48) x [h1; h0] (48 x channels) like the hidden convs' epilogue (gcn_tile.hip).
+    // A lane owns all 48 k of ONE channel; v_permlane32_swap of its k-blocks 2s / 2s+1 yields the B fragments of the wave's lower 32
+    // channels (P) and upper 32 channels (Q).  6 MFMA + ~100 VALU per wave instead of 576 v_fmac per lane.
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    f32x16 DA, DB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { DA[r] = 0.f; DB[r] = 0.f; }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const half8 af = ((const half8*)L.AoffH)[s3 * 64 + lane];
+      u32x4_t Pw, Qw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kp = 16 * s3 + 2 * e, kq = kp + 8;             // < 24: h1[k], else h0[k - 24]
+        const float p0 = kp < kJ ? h1[kp] : h0[kp - kJ], p1 = kp + 1 < kJ ? h1[kp + 1] : h0[kp + 1 - kJ];
+        const float q0 = kq < kJ ? h1[kq] : h0[kq - kJ], q1 = kq + 1 < kJ ? h1[kq + 1] : h0[kq + 1 - kJ];
+        const half2_t hp = {(half_t)fminf(fmaxf(p0, -65504.f), 65504.f), (half_t)fminf(fmaxf(p1, -65504.f), 65504.f)};
+        const half2_t hq = {(half_t)fminf(fmaxf(q0, -65504.f), 65504.f), (half_t)fminf(fmaxf(q1, -65504.f), 65504.f)};
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, hp), __builtin_bit_cast(unsigned int, hq), false, false);
+        Pw[e] = sw[0];
+        Qw[e] = sw[1];
+      }
+      DA = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, Pw), DA, 0, 0, 0);
+      DB = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, Qw), DB, 0, 0, 0);
+    }
+    const bool relu = L.relu != 0;
+    const int cA = 64 * wv + (lane & 31), half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {                               // D row = (r&3) + 8 (r>>2) + 4 half = joint; r >> 2 == 3 is padding
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float va = relu ? fmaxf(DA[r], 0.f) : DA[r], vb = relu ? fmaxf(DB[r], 0.f) : DB[r];
+      T[j * 256 + cA] = va;
+      T[j * 256 + cA + 32] = vb;
+    }
+  } else {
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* Ac = (const cfloat*)(uintptr_t)L.Aoff;
     const bool relu = L.relu != 0;

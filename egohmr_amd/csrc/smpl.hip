@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
       float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
       const float ox = T[0] * px + T[1] * py + T[2] * pz + T[3], oy = T[4] * px + T[5] * py + T[6] * pz + T[7],
                   oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
-      o[0] = ox; o[1] = oy; o[2] = oz;
+      typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+      *(f32x3u*)o = f32x3u{ox, oy, oz};                          // one 12-byte store per lane: a half-wave covers 384 contiguous bytes
       for (unsigned long long m = slots; m; m &= m - 1) {
         float* q = joints + ((size_t)(b0 + bb) * (kJ + S.n_extra) + kJ + __builtin_ctzll(m)) * 3;
         q[0] = ox; q[1] = oy; q[2] = oz;

@@ -210,6 +210,7 @@ class EgoHMR(nn.Module):
         self.guide_denom_override = None       # sharded / sub-batch runs: the GLOBAL batch size of `-loss.mean()`, else None
         self.guide_all_points = False          # COAP variant: bbox-selected scene points (egohmr.py:550-552); True = all points (egohmr_volsmpl.py:609-612)
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        self.overlap_encoders = True       # ResNet-50 and the scene PointNet on two HIP streams (FusedSampler.prepare)
         self.backbone_matrix_core = True   # ResNet-50 blocks as split-f16 implicit GEMMs (csrc/conv.hip); False = library convs + ehm_bias_act
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
@@ -439,13 +440,29 @@ class FusedSampler:
         self.gcn()
         dev = m.device
         g = lambda k: _lib.f32(batch[k], dev)
-        img_feats = self._backbone_fn()(g("img"))                                      # :183 (BatchNorm folded into the convs)
         transl = _lib.f32(batch["smpl_params"]["transl"], dev)
         scene = g("scene_pcd_verts_full")
         if m.scene_cano:
             scene = scene - transl.unsqueeze(1)                                        # :211
         scene = scene.contiguous()
-        scene_feats = m.scene_enc(scene)                                               # :214
+        img = g("img")
+        # The two encoders are independent, and complementary on the chip: ResNet-50's early layers stream 0.8 GB float32 activations
+        # per conv (HBM-bound, matrix cores idle), the PointNet's GEMMs are matrix-core bound.  Run them on two HIP streams.
+        if m.overlap_encoders:
+            cur = torch.cuda.current_stream(dev)
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                scene_feats = m.scene_enc(scene)                                       # :214
+            img_feats = self._backbone_fn()(img)                                       # :183 (BatchNorm folded into the convs)
+            cur.wait_stream(side)
+            scene_feats.record_stream(cur)
+            scene.record_stream(side)
+        else:
+            img_feats = self._backbone_fn()(img)
+            scene_feats = m.scene_enc(scene)
         transl_feat = m.transl_enc(transl)                                             # :217
         fx, cx, cy = g("fx"), g("cam_cx"), g("cam_cy")
         ofx = fx * m.cfg.CAM.FX_NORM_COEFF

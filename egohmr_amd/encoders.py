@@ -1,10 +1,12 @@
 """Step-invariant conditioning encoders (run once per item, SURVEY.md section 0 finding 2).
 
 The reference re-evaluates both inside every denoising step (models/egohmr/egohmr.py:183,:214);
-neither depends on x_t or t, so the build evaluates them once per sampled batch.  They are plain
-library convolutions / GEMMs (MIOpen / rocBLAS through PyTorch-ROCm): the per-step hot ops are the
-hand-written HIP kernels, these are not.  Sub-module and parameter names follow the reference so
-its checkpoints load (``backbone.*`` models/resnet.py:97-136, ``scene_enc.*`` models/respointnet.py:13-27).
+neither depends on x_t or t, so the build evaluates them once per sampled batch.  Both run on the
+hand-written split-f16 matrix-core kernels (csrc/conv.hip: the 52 bottleneck convolutions of ResNet-50
+as NHWC implicit GEMMs with BatchNorm folded; csrc/linear.hip: the scene PointNet's GEMMs with the
+max-pool fused); only the 7x7 stem and its max-pool go through MIOpen / ATen.  Sub-module and
+parameter names follow the reference so its checkpoints load (``backbone.*`` models/resnet.py:97-136,
+``scene_enc.*`` models/respointnet.py:13-27).
 """
 from __future__ import annotations
 

@@ -318,6 +318,9 @@ def main():
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
                        "gcn_precision": args.precision, "f16x3_last_steps": (T - lowprec) if args.precision == "f16x3" else None,
                        "f16x3_last_steps_policy": str(model.f16x3_last_steps),
+                       "pass_pruning": {"items_without_second_pass": int(B - st.num_masked) if model.prune_passes else 0, "of": B,
+                                        "note": "exact (egohmr.py:249-254): all-visible items skip the image-masked pass; the synthetic "
+                                                "visibility draw (Bernoulli 0.6 per OpenPose joint, SURVEY 8d) almost never produces one"},
                        "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
                        "parallelism": f"items sharded x{world}, one RCCL all-gather of [B,226] at the end"},
             "roofline": kernels[dominant],

@@ -78,7 +78,7 @@ class StepCoefs(C.Structure):
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -98,6 +98,8 @@ PROTOTYPES = {
     "ehm_gcn_row_tile": (_I, []),
     "ehm_gcn_set_precision": (_I, [_P, _I]),
     "ehm_gcn_get_precision": (_I, [_P]),
+    "ehm_gcn_set_uncond_mode": (_I, [_P, _I]),
+    "ehm_gcn_set_pass_map": (_I, [_P, _P, _P, _I]),
     "ehm_gcn_reserve": (_I, [_P, _I, _I]),
     "ehm_gcn_activation_group": (_I, [_P]),
     "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _I, _P]),

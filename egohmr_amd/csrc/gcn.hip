@@ -260,16 +260,17 @@ template <int OUT>   // 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 r
 __global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict__ h_img, const float* __restrict__ h_oth,
                                                         const uint8_t* __restrict__ vis, const float* __restrict__ x,
                                                         const float* __restrict__ Wx, const float* __restrict__ tvec,
-                                                        LayerDev L, float* __restrict__ Y, int B, int passes) {
+                                                        LayerDev L, float* __restrict__ Y, int B, int passes, int mask_all,
+                                                        const int32_t* __restrict__ mask_items) {
   const int N = L.N;
-  const int vb = blockIdx.x;           // virtual body = p*B + b
-  const int p = vb / B, b = vb % B;
+  const int vb = blockIdx.x;           // virtual body: [0, B) = conditional pass of item vb; B + k = second pass of item mask_items[k] (or k)
+  const int p = vb >= B ? 1 : 0, b = p ? (mask_items ? mask_items[vb - B] : vb - B) : vb;
   const int n_raw = blockIdx.y * 256 + threadIdx.x;
   const int n = n_raw < N ? n_raw : N - 1;                        // lanes past N recompute the last channel; their stores are dropped
   float base[2], img[2], wx[2][6];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    base[k] = h_oth[((size_t)b * 2 + k) * N + n] + tvec[k * N + n];
+    base[k] = ((p == 1 && mask_all) ? 0.f : h_oth[((size_t)b * 2 + k) * N + n]) + tvec[k * N + n];   // egohmr.py:150-158 force_mask: image part only / whole condition
     img[k] = (p == 0) ? h_img[((size_t)b * 2 + k) * N + n] : 0.f;
 #pragma unroll
     for (int c = 0; c < 6; ++c) wx[k][c] = Wx[(k * 6 + c) * N + n];
@@ -431,13 +432,14 @@ __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(192) void gcn_out_mix_kernel(const float* __restrict__ hs, OutDev O, const uint8_t* __restrict__ vis,
-                                                          float* __restrict__ x0, int B, int passes) {
+                                                          float* __restrict__ x0, int B, int passes, const int32_t* __restrict__ mask_slot) {
   __shared__ float sh[2][kJ][12];
   __shared__ float outs[2][kJ][6];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int slot = mask_slot ? mask_slot[b] : b;              // row block of my second pass: B + slot (slot < 0: pruned, all joints visible)
   for (int i = tid; i < passes * kJ * 12; i += 192) {
     const int p = i / (kJ * 12), rem = i % (kJ * 12);
-    sh[p][rem / 12][rem % 12] = hs[((size_t)(p * B + b) * kJ) * 12 + rem];
+    sh[p][rem / 12][rem % 12] = (p == 1 && slot < 0) ? 0.f : hs[((size_t)(p ? B + slot : b) * kJ) * 12 + rem];
   }
   __syncthreads();
   for (int e = tid; e < passes * kJ * 6; e += 192) {
@@ -611,13 +613,14 @@ extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* 
                                    const float* Wx, const float* tvec, float* out, int B, int passes, void* stream) {
   EHM_CHECK_ARG(h && h_img && h_oth && vis && x && Wx && tvec && out);
   EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
-  dim3 grid((unsigned)(B * passes), (unsigned)ceil_div(h->hid, 256));
+  dim3 grid((unsigned)ehm_gcn_virtual_bodies(h, B, passes), (unsigned)ceil_div(h->hid, 256));
+  const int32_t* mi = (passes == 2 && h->num_masked >= 0) ? h->mask_items : nullptr;
   if (h->precision == EHM_PREC_F32)
-    hipLaunchKernelGGL(gcn_input_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes);
+    hipLaunchKernelGGL(gcn_input_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes, h->uncond_masks_all, mi);
   else if (h->precision == EHM_PREC_F16X3)   // the activation matrices travel in the X2 split format (same byte size as float32)
-    hipLaunchKernelGGL(gcn_input_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes);
+    hipLaunchKernelGGL(gcn_input_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes, h->uncond_masks_all, mi);
   else                                       // plain f16 rows
-    hipLaunchKernelGGL(gcn_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes);
+    hipLaunchKernelGGL(gcn_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes, h->uncond_masks_all, mi);
   EHM_LAUNCH_CHECK();
   return 0;
 }
@@ -706,7 +709,7 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
                                     void* stream) {
   EHM_CHECK_ARG(h && X && x0);
   EHM_CHECK_ARG(B > 0 && (passes == 1 || (passes == 2 && vis)));
-  const int64_t rows = (int64_t)passes * B * kJ;
+  const int64_t rows = (int64_t)ehm_gcn_virtual_bodies(h, B, passes) * kJ;
   if (rows > h->hs_rows) {      // [rows,12] scratch of the two-kernel output conv: sized by ehm_gcn_create / ehm_gcn_reserve, grown here only
     const int rc = ehm_gcn_reserve_rows(h, round_up(rows, BM));   // for a batch larger than reserved (allocates: call ehm_gcn_reserve before a capture)
     if (rc != 0) return rc;
@@ -717,13 +720,27 @@ extern "C" int ehm_gcn_output_layer(ehm_gcn* h, const float* X, const uint8_t* v
   else
     hipLaunchKernelGGL(gcn_out_dot_kernel<false>, dim3((unsigned)ceil_div(rows, OUT_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, X, h->out,
                        h->hs, rows);
-  hipLaunchKernelGGL(gcn_out_mix_kernel, dim3(B), dim3(192), 0, (hipStream_t)stream, h->hs, h->out, vis, x0, B, passes);
+  hipLaunchKernelGGL(gcn_out_mix_kernel, dim3(B), dim3(192), 0, (hipStream_t)stream, h->hs, h->out, vis, x0, B, passes,
+                     (passes == 2 && h->num_masked >= 0) ? h->mask_slot : nullptr);
   EHM_LAUNCH_CHECK();
   return 0;
 }
 
+int ehm_gcn_virtual_bodies(const ehm_gcn* h, int B, int passes) {
+  return passes == 2 ? B + (h->num_masked >= 0 ? h->num_masked : B) : B;
+}
+const int32_t* ehm_gcn_mask_slot(const ehm_gcn* h, int passes) { return (passes == 2 && h->num_masked >= 0) ? h->mask_slot : nullptr; }
+
+extern "C" int ehm_gcn_set_pass_map(ehm_gcn* h, const int32_t* mask_items, const int32_t* mask_slot, int num_masked) {
+  EHM_CHECK_ARG(h && (num_masked < 0 || (mask_slot && (num_masked == 0 || mask_items))));
+  h->mask_items = num_masked >= 0 ? mask_items : nullptr;
+  h->mask_slot = num_masked >= 0 ? mask_slot : nullptr;
+  h->num_masked = num_masked < 0 ? -1 : num_masked;
+  return 0;
+}
+
 int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const float** hs, const void** out_dev, hipStream_t st) {
-  const int64_t rows = (int64_t)passes * B * kJ;
+  const int64_t rows = (int64_t)ehm_gcn_virtual_bodies(h, B, passes) * kJ;
   if (rows > h->hs_rows) {
     const int rc = ehm_gcn_reserve_rows(h, round_up(rows, BM));
     if (rc != 0) return rc;
@@ -747,4 +764,9 @@ extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
   return 0;
 }
 extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
+extern "C" int ehm_gcn_set_uncond_mode(ehm_gcn* h, int masks_whole_condition) {
+  EHM_CHECK_ARG(h && (masks_whole_condition == 0 || masks_whole_condition == 1));
+  h->uncond_masks_all = masks_whole_condition;
+  return 0;
+}
 extern "C" int ehm_gcn_activation_group(const ehm_gcn* h) { return h ? (h->precision == EHM_PREC_F16 ? 0 : 32) : EHM_EINVAL; }

@@ -44,6 +44,10 @@ struct ehm_gcn {
   int hid = 0;
   int num_hidden = 0;
   int precision = EHM_PREC_F32;
+  const int32_t* mask_items = nullptr;   // exact pass pruning (ehm_gcn_set_pass_map): items that need the second pass, [num_masked] ...
+  const int32_t* mask_slot = nullptr;    // ... and for every item its slot in that list or -1, [B]; nullptr = every item has a second pass
+  int num_masked = -1;
+  int uncond_masks_all = 0;              // second ("unconditional") pass of diffuse_fuse: 0 = image features masked, 1 = whole condition masked
   LayerDev input{};
   LayerDev hidden[16]{};
   LayerDev* hidden_dev = nullptr;        // device copy of hidden[] for the chained kernel (gcn_tile.hip)

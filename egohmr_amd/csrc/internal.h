@@ -12,7 +12,7 @@ int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const fl
                        float* jws, int B, hipStream_t st);
 // output-conv mix + sampler update + pose chain + blend-coefficient fragments in one launch, then skinning (sampling loop only)
 int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
-                       const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, int do_pose,
+                       const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int do_pose,
                        const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
                        float* pose6d, int B, hipStream_t st);
 int ehm_smpl_num_verts(const ehm_smpl* h);
@@ -20,6 +20,8 @@ int ehm_smpl_num_extra(const ehm_smpl* h);
 // gcn.hip
 int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
+int ehm_gcn_virtual_bodies(const ehm_gcn* h, int B, int passes);   // B + second passes after pruning (ehm_gcn_set_pass_map)
+const int32_t* ehm_gcn_mask_slot(const ehm_gcn* h, int passes);
 // output conv, first half only: responses hs [passes*B*24, 12] = X . [W0 | W1] (scratch owned by the handle); *out_dev = the OutDev block
 int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const float** hs, const void** out_dev, hipStream_t st);
 // sampler.hip

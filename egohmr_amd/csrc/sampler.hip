@@ -103,7 +103,7 @@ struct Workspace {
 
 Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* base) {
   Workspace w{};
-  w.rows = (int64_t)d->passes * d->B * kJ;
+  w.rows = (int64_t)(d->B + (d->passes == 2 ? (d->num_masked >= 0 ? d->num_masked : d->B) : 0)) * kJ;   // virtual bodies after pass pruning
   w.rows_pad = round_up(w.rows, ehm_gcn_row_tile());
   int64_t off = 0;
   auto take = [&](int64_t floats) {
@@ -144,6 +144,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   EHM_CHECK_ARG(gcn && smpl && d && steps && h_img && h_oth && vis && Wx && tvecs && noise && betas && mean && std_);
   EHM_CHECK_ARG(x_final && x0_final && verts && joints && R && pose6d && workspace);
   EHM_CHECK_ARG(d->B > 0 && d->num_steps > 0 && (d->passes == 1 || d->passes == 2));
+  EHM_CHECK_ARG(d->passes == 1 || ehm_gcn_virtual_bodies(gcn, d->B, 2) == d->B + (d->num_masked >= 0 ? d->num_masked : d->B));   // desc and ehm_gcn_set_pass_map agree
   const int hid = ehm_gcn_hid(gcn), nh = ehm_gcn_num_hidden(gcn), V = ehm_smpl_num_verts(smpl);
   EHM_CHECK_ARG(nh % 2 == 0);
   bool any_guided = false;
@@ -187,7 +188,8 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     if (rc == 0) {
       const float* eps = noise + (int64_t)(1 + k) * n;
       float* dst = last ? x_final : w.x_cur;
-      rc = ehm_step_body_impl(smpl, hs, out_dev, vis, w.x_cur, eps, grad, dst, x0_final, &c, d->ddim, d->passes, (d->lbs_every_step || last) ? 1 : 0,
+      rc = ehm_step_body_impl(smpl, hs, out_dev, vis, w.x_cur, eps, grad, dst, x0_final, &c, d->ddim, d->passes, ehm_gcn_mask_slot(gcn, d->passes),
+                              (d->lbs_every_step || last) ? 1 : 0,
                               betas, mean, std_, verts, joints, R, w.A, pose6d, B, st);
     }
   }

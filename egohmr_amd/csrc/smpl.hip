@@ -630,6 +630,7 @@ struct StepBodyArgs {
   float* x0;                // [B,144]
   ehm_step_coefs c;
   int ddim, passes, B, do_pose;
+  const int32_t* mask_slot; // pass pruning (ehm_gcn_set_pass_map) or nullptr
   const float *betas, *mean, *std_;
   float *Rws, *Aws, *joints, *pose6d;
   int jstride;
@@ -641,9 +642,10 @@ __global__ __launch_bounds__(64) void step_body_kernel(StepBodyArgs a, SmplDev S
   __shared__ float x0s[kPoseDim];
   __shared__ float Rl[kJ * 9];
   const int b = blockIdx.x, lane = threadIdx.x;
+  const int slot = a.mask_slot ? a.mask_slot[b] : b;            // row block of my second pass: B + slot (slot < 0: pruned, every joint visible)
   for (int i = lane; i < a.passes * kJ * 12; i += 64) {
     const int p = i / (kJ * 12), rem = i % (kJ * 12);
-    sh[p][rem / 12][rem % 12] = a.hs[((size_t)(p * a.B + b) * kJ) * 12 + rem];
+    sh[p][rem / 12][rem % 12] = (p == 1 && slot < 0) ? 0.f : a.hs[((size_t)(p ? a.B + slot : b) * kJ) * 12 + rem];
   }
   __syncthreads();
   for (int e = lane; e < kPoseDim; e += 64) {
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(64) void step_body_kernel(StepBodyArgs a, SmplDev S
 
 // sampler.hip's per-step call: output-conv mix + sampler update + pose chain + fragment pack in one launch, then the skinning launch.
 int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
-                       const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, int do_pose,
+                       const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int do_pose,
                        const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
                        float* pose6d, int B, hipStream_t st) {
   const SmplDev& d = h->d;
@@ -713,7 +715,7 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
   }
   StepBodyArgs a;
   a.hs = hs; a.O = *(const OutDev*)out_dev; a.vis = vis; a.x = x; a.noise = noise; a.grad = grad; a.x_next = x_next; a.x0 = x0;
-  a.c = *c; a.ddim = ddim; a.passes = passes; a.B = B; a.do_pose = do_pose;
+  a.c = *c; a.ddim = ddim; a.passes = passes; a.B = B; a.do_pose = do_pose; a.mask_slot = mask_slot;
   a.betas = betas; a.mean = mean; a.std_ = std_; a.Rws = Rws; a.Aws = Aws; a.joints = joints; a.pose6d = pose6d;
   a.jstride = (kJ + d.n_extra) * 3;
   a.pf = mfma ? (sk_half8*)h->pf : nullptr;

@@ -29,7 +29,7 @@ from .encoders import ResnetPointnet, ResNet50Features
 
 OPENPOSE_TO_SMPL = [8, 12, 9, 8, 13, 10, 8, 14, 11, 8, 14, 11, 0, 5, 2, 0, 5, 2, 6, 3, 7, 4, 7, 4]           # egohmr.py:111
 OPENPOSE_TO_SMPL_LOOSE = [8, 13, 10, 8, 13, 10, 8, 14, 11, 8, 14, 11, 1, 5, 2, 0, 5, 2, 6, 3, 7, 4, 7, 4]     # egohmr.py:114
-IMG_DIM, COND_SPLIT = 2048, (2048, 2694, 3206, 3718)   # img | scene+transl+cam | x_t embed | timestep embed
+IMG_DIM = 2048          # columns of the GCN input feature: img 2048 | scene + transl + cam | x_t embed 512 | timestep embed 512 (EgoHMR.cond_split)
 PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
 GRAD_ZERO_JOINTS = [0, 3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23]                               # egohmr.py:567
 
@@ -171,18 +171,16 @@ class EgoHMR(nn.Module):
         super().__init__()
         self.cfg = cfg if cfg is not None else default_cfg()
         self.device = torch.device(device) if device is not None else torch.device("cuda")
-        if not (with_focal_length and with_bbox_info and with_cam_center):
-            raise NotImplementedError("the sampling path is built for the test-time flags of test_egohmr.py:112-118 "
-                                      "(with_focal_length = with_bbox_info = with_cam_center = True)")
-        if cond_mask_prob not in (0, 0.0):
-            raise NotImplementedError("cond_mask_prob > 0 is a training-time option")
-        self.with_focal_length, self.with_bbox_info, self.with_cam_center = True, True, True
+        if not with_focal_length:
+            # the reference itself cannot be constructed this way: `if self.with_focal_length or self.with_vfov` (egohmr.py:77) reads an
+            # attribute that is never set
+            raise AttributeError("'EgoHMR' object has no attribute 'with_vfov' (the reference fails the same way for with_focal_length=False, "
+                                 "models/egohmr/egohmr.py:77); pass with_focal_length=True")
+        self.with_focal_length, self.with_bbox_info, self.with_cam_center = True, bool(with_bbox_info), bool(with_cam_center)
         self.scene_type, self.scene_cano = scene_type, scene_cano
         self.only_mask_img_cond, self.diffuse_fuse = only_mask_img_cond, diffuse_fuse
-        if diffuse_fuse and not only_mask_img_cond:
-            raise NotImplementedError("diffuse_fuse with only_mask_img_cond=False zeroes the whole condition (egohmr.py:157-158); "
-                                      "the shipped test configuration uses only_mask_img_cond=True")
-        self.cond_mask_prob = 0.0
+        # cond_mask_prob only acts under self.training (mask_cond, egohmr.py:159-168): the sampling path is eval-only, so it is kept and ignored
+        self.cond_mask_prob = float(cond_mask_prob)
         self.diffuse_feat_dim = 6
         dev = self.device
         self.register_buffer("body_rep_mean_buf", torch.as_tensor(body_rep_mean, dtype=torch.float32).reshape(144).clone(), persistent=False)
@@ -197,8 +195,9 @@ class EgoHMR(nn.Module):
         self.backbone = ResNet50Features()
         self.scene_enc = ResnetPointnet(out_dim=scene_feat_dim, hidden_dim=256)
         self.transl_enc = TranslEnc(3, 128)
-        ctx = self.cfg.MODEL.BACKBONE.OUT_CHANNELS + 1 + 3 + 2 + scene_feat_dim + 128
+        ctx = self.cfg.MODEL.BACKBONE.OUT_CHANNELS + 1 + (3 if with_bbox_info else 0) + (2 if with_cam_center else 0) + scene_feat_dim + 128   # :74-83
         self.context_feats_dim = ctx
+        self.cond_split = (IMG_DIM, ctx, ctx + 512, ctx + 1024)
         self.diffusion_model = ModulatedGCN(adj=smpl_tree_adjacency(), in_dim=ctx + 512 + 512, hid_dim=gcn_hid_dim, out_dim=6,
                                             num_layers=diffusion_blk, nonlocal_layer=gcn_nonlocal_layer)
         self.beta_layer = FCHeadBeta(ctx)
@@ -210,6 +209,7 @@ class EgoHMR(nn.Module):
         self.guide_denom_override = None       # sharded / sub-batch runs: the GLOBAL batch size of `-loss.mean()`, else None
         self.guide_all_points = False          # COAP variant: bbox-selected scene points (egohmr.py:550-552); True = all points (egohmr_volsmpl.py:609-612)
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)
         self.overlap_encoders = True       # ResNet-50 and the scene PointNet on two HIP streams (FusedSampler.prepare)
         self.backbone_matrix_core = True   # ResNet-50 blocks as split-f16 implicit GEMMs (csrc/conv.hip); False = library convs + ehm_bias_act
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
@@ -395,11 +395,12 @@ class FusedSampler:
             # fold InputProcess (Linear 6->512) into the x_t slice of the input conv: x @ (Wp^T W_k[2694:3206]) + bp W_k[...]
             W = gi.gconv.W.detach().double()                                            # [2, 3718, hid]
             Wp, bp = m.input_process.poseEmbedding.weight.detach().double(), m.input_process.poseEmbedding.bias.detach().double()
-            a, b, c, d = COND_SPLIT
+            a, b, c, d = m.cond_split
             Wx = torch.einsum("ec,kef->kcf", Wp, W[:, b:c, :])                          # [2,6,hid]
             bx = torch.einsum("e,kef->kf", bp, W[:, b:c, :])                            # [2,hid]
             self._folded = SimpleNamespace(Wx=Wx.float().contiguous(), bx=bx, W_img=gi.gconv.W.detach()[:, :a, :],
                                            W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :])
+        _lib.check(_lib.lib().ehm_gcn_set_uncond_mode(self._gcn, 0 if self.model.only_mask_img_cond else 1), "ehm_gcn_set_uncond_mode")
         mode = PRECISIONS[self.model.gcn_precision]
         if _lib.lib().ehm_gcn_get_precision(self._gcn) != mode:
             _lib.check(_lib.lib().ehm_gcn_set_precision(self._gcn, mode), "ehm_gcn_set_precision")
@@ -467,8 +468,12 @@ class FusedSampler:
         fx, cx, cy = g("fx"), g("cam_cx"), g("cam_cy")
         ofx = fx * m.cfg.CAM.FX_NORM_COEFF
         bc, bs = g("box_center"), g("box_size")
-        cam = torch.cat([torch.stack([cx / ofx, cy / ofx], -1), torch.stack([bc[:, 0] / ofx, bc[:, 1] / ofx, bs / ofx], -1),
-                         fx.unsqueeze(1)], dim=1)                                      # :195-205
+        cam = [fx.unsqueeze(1)]                                                        # :195-205 (prepended in this order)
+        if m.with_bbox_info:
+            cam = [torch.stack([bc[:, 0] / ofx, bc[:, 1] / ofx, bs / ofx], -1)] + cam
+        if m.with_cam_center:
+            cam = [torch.stack([cx / ofx, cy / ofx], -1)] + cam
+        cam = torch.cat(cam, dim=1)
         other = torch.cat([scene_feats, transl_feat, cam], dim=1)                      # :220-221
         vis = m.visibility({"orig_keypoints_2d": batch["orig_keypoints_2d"].to(dev)})
         f = self._folded
@@ -479,6 +484,11 @@ class FusedSampler:
                                betas=betas, scene=scene, transl=transl, fx=fx, cam_cx=cx, cam_cy=cy, img_feats=img_feats,
                                scene_feats=scene_feats)
         self._prep.inputs = ins                  # strong references (see the key above)
+        # pass pruning map (ehm_gcn_set_pass_map): items with an invisible joint need the second pass.  One host read-back per batch.
+        need = ~vis.all(dim=1)
+        self._prep.mask_items = torch.nonzero(need).flatten().to(torch.int32).contiguous()
+        self._prep.mask_slot = torch.where(need, torch.cumsum(need.to(torch.int32), 0) - 1, torch.full_like(need, -1, dtype=torch.int32)).to(torch.int32).contiguous()
+        self._prep.num_masked = int(self._prep.mask_items.numel())
         self._prep_key = key
         return self._prep
 
@@ -486,6 +496,16 @@ class FusedSampler:
         m = self.model
         mods = (m.backbone, m.scene_enc, m.transl_enc, m.beta_layer, m.embed_timestep)
         return tuple((t.data_ptr(), t._version) for mod in mods for t in list(mod.parameters()) + list(mod.buffers()))
+
+    def _apply_pass_map(self, st, passes):
+        """(virtual bodies, num_masked for the descriptor) after telling the handle which items still need the second pass."""
+        m, L = self.model, _lib.lib()
+        h = self.gcn()
+        if passes == 2 and m.prune_passes:
+            _lib.check(L.ehm_gcn_set_pass_map(h, _lib.ptr(st.mask_items) if st.num_masked else None, _lib.ptr(st.mask_slot), st.num_masked), "ehm_gcn_set_pass_map")
+            return st.B + st.num_masked, st.num_masked
+        _lib.check(L.ehm_gcn_set_pass_map(h, None, None, -1), "ehm_gcn_set_pass_map")
+        return passes * st.B, -1
 
     def invalidate(self):
         """Drop the cached conditioning (bench.py: the encoders are part of every timed call)."""
@@ -512,7 +532,7 @@ class FusedSampler:
         m, L = self.model, _lib.lib()
         hid, B = m.diffusion_model.hid_dim, st.B
         tile = L.ehm_gcn_row_tile()
-        rows = passes * B * 24
+        rows = self._apply_pass_map(st, passes)[0] * 24
         rows_pad = (rows + tile - 1) // tile * tile
         X = [torch.zeros(rows_pad, hid, device=m.device) for _ in range(3)]
         s = _lib.stream_ptr()
@@ -645,9 +665,11 @@ class FusedSampler:
         any_guided = any(s.grad_scale != 0.0 for s in steps)
         tmap = torch.tensor([diffusion.timestep_map[i] for i in range(T - 1, -1, -1)], device=m.device, dtype=torch.long)
         tvecs = self.timestep_vectors(tmap)                                            # [T,2,hid]
-        desc = _lib.SampleDesc(B=B, passes=2 if m.diffuse_fuse else 1, num_steps=T, ddim=int(ddim),
+        passes = 2 if m.diffuse_fuse else 1
+        _, num_masked = self._apply_pass_map(st, passes)
+        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
-                               guide_denom=self.guide_denom(B), tau=m.collision_tau,
+                               guide_denom=self.guide_denom(B), tau=m.collision_tau, num_masked=num_masked,
                                guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=self.lowprec_steps(T, any_guided))
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:
@@ -676,15 +698,20 @@ class FusedSampler:
                 # hipGraph route: the loop's launches are captured once per (shape, schedule) with every pointer inside persistent
                 # buffers; a call copies its inputs in, replays, and copies the results out.
                 key = (B, T, int(ddim), desc.passes, desc.lbs_every_step, desc.lowprec_steps, m.gcn_precision, self._gcn_key,
-                       bytes(steps), st.scene.shape[1])
+                       bytes(steps), st.scene.shape[1], num_masked)
                 ent = self._graphs.get(key)
                 if ent is None:
                     if len(self._graphs) >= 8:
                         self._graphs.clear()
                     bufs = SimpleNamespace(**{k: torch.empty_like(v) for k, v in ins.items()}, **out_bufs())
+                    bufs.mask_items, bufs.mask_slot = torch.empty_like(st.mask_items), torch.empty_like(st.mask_slot)
                     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
                     for k, v in ins.items():
                         getattr(bufs, k).copy_(v)
+                    bufs.mask_items.copy_(st.mask_items)
+                    bufs.mask_slot.copy_(st.mask_slot)
+                    if num_masked >= 0:      # the captured kernels read the pass map through these persistent arrays
+                        _lib.check(L.ehm_gcn_set_pass_map(gcn, _lib.ptr(bufs.mask_items) if num_masked else None, _lib.ptr(bufs.mask_slot), num_masked))
                     launch(bufs, ws, None)                       # eager once: every lazy allocation inside the library happens here
                     torch.cuda.synchronize(dev)
                     g = torch.cuda.CUDAGraph()
@@ -693,6 +720,8 @@ class FusedSampler:
                     ent = self._graphs[key] = SimpleNamespace(graph=g, bufs=bufs, ws=ws)
                 for k, v in ins.items():
                     getattr(ent.bufs, k).copy_(v)
+                ent.bufs.mask_items.copy_(st.mask_items)
+                ent.bufs.mask_slot.copy_(st.mask_slot)
                 ent.graph.replay()
                 o = SimpleNamespace(**{k: getattr(ent.bufs, k).clone() for k in ("x_final", "x0", "verts", "joints", "R", "pose6d")})
             else:

@@ -163,7 +163,7 @@ def nonlocal_manifest(hid_dim: int = 1024, prefix: str = "diffusion_model.non_lo
 
 
 def egohmr_manifest(hid_dim: int = 1024, num_blocks: int = 4, scene_feat_dim: int = 512,
-                    img_feat_dim: int = 2048, with_backbone: bool = True, nonlocal_layer: bool = False) -> list:
+                    img_feat_dim: int = 2048, with_backbone: bool = True, nonlocal_layer: bool = False, cam_dim: int = 6) -> list:
     """(name, shape) of every learnable tensor / buffer of the stage-2 model, reference names.
 
     Conditioning width = img 2048 + scene 512 + transl 128 + cam (2+3+1) = 2694
@@ -171,7 +171,7 @@ def egohmr_manifest(hid_dim: int = 1024, num_blocks: int = 4, scene_feat_dim: in
     SMPL / COAP buffers that the reference also keeps in its state_dict are not listed: the build
     loads the body model from its own asset and reference checkpoints are read with strict=False.
     """
-    ctx = img_feat_dim + 1 + 3 + 2 + scene_feat_dim + 128
+    ctx = img_feat_dim + cam_dim + scene_feat_dim + 128      # cam_dim = 1 (fx) + 3 (bbox, with_bbox_info) + 2 (centre, with_cam_center)
     in_dim = ctx + 512 + 512
     m = [
         ("input_process.poseEmbedding.weight", (512, 6)),

@@ -126,7 +126,17 @@ int ehm_gcn_row_tile(void);
  *   pre_k = (p==0 ? vis[b,j] * h_img[b,k,:] : 0) + h_oth[b,k,:] + tvec[k,:] + x[b,j,0:6] @ Wx[k]
  * then the modulated adjacency mix, bias, BatchNorm(eval), ReLU.
  *   h_img, h_oth [B,2,hid]; vis [B,24] uint8; x [B,144]; Wx [2,6,hid]; tvec [2,hid];
- *   out [rows_pad,hid], rows = passes*B*24. */
+ *   out [rows_pad,hid], rows = passes*B*24 ((B + num_masked)*24 under ehm_gcn_set_pass_map). */
+/* What the second pass of diffuse_fuse masks (EgoHMR.mask_cond(force_mask=True), egohmr.py:150-158): 0 (default) = the image features only
+ * (only_mask_img_cond=True, the shipped test configuration) -> pre_k of p = 1 drops h_img; 1 = the whole condition (only_mask_img_cond=False)
+ * -> it drops h_img and h_oth. */
+int ehm_gcn_set_uncond_mode(ehm_gcn* h, int masks_whole_condition);
+/* Exact pass pruning (from egohmr.py:239-254): an item whose 24 joints are ALL visible takes every output entry from the
+ * conditional pass, so its second pass is dead work.  mask_items [num_masked] int32 = the items that still need it (ascending),
+ * mask_slot [B] int32 = each item's index in that list or -1; DEVICE arrays that must stay alive while the map is set.  From then
+ * on, with passes == 2, the activation matrices hold (B + num_masked) * 24 rows: rows [0, B*24) the conditional pass, then the second
+ * pass of mask_items[0], mask_items[1], ...  num_masked < 0 clears the map (every item has a second pass: B * 2 * 24 rows). */
+int ehm_gcn_set_pass_map(ehm_gcn* h, const int32_t* mask_items, const int32_t* mask_slot, int num_masked);
 int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x,
                         const float* Wx, const float* tvec, float* out, int B, int passes, void* stream);
 
@@ -277,6 +287,7 @@ typedef struct {
   int num_scene_points; /* N (guidance only)                                        */
   float guide_denom;  /* B for COAP-style loss.mean(), 1 for VolSMPL-style sum()    */
   float tau;          /* collision proxy contact distance                          */
+  int num_masked;     /* second passes after pruning = what ehm_gcn_set_pass_map was given; -1 = no map (B)   */
   int guide_all_points; /* 1 = VolSMPL-style guidance over ALL scene points (egohmr_volsmpl.py:609-612), 0 = bbox-selected (egohmr.py:550-552) */
   int lowprec_steps;  /* precision schedule: the FIRST lowprec_steps executed steps run the hidden convs on plain f16 operands
                          (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */

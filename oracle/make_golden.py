@@ -134,7 +134,7 @@ def to_torch_batch(b):
     return out
 
 
-def build_reference_model(sd_np, asset, mean, std, diffuse_fuse=True, volsmpl=False):
+def build_reference_model(sd_np, asset, mean, std, diffuse_fuse=True, volsmpl=False, **ctor):
     if volsmpl:
         from models.egohmr.egohmr_volsmpl import EgoHMRVolsmpl as EgoHMR
     else:
@@ -145,10 +145,10 @@ def build_reference_model(sd_np, asset, mean, std, diffuse_fuse=True, volsmpl=Fa
     cwd = os.getcwd()
     os.chdir(tmp)
     try:
-        model = EgoHMR(cfg=ref_cfg(), device="cpu", body_rep_mean=torch.from_numpy(mean), body_rep_std=torch.from_numpy(std),
-                       with_focal_length=True, with_bbox_info=True, with_cam_center=True, scene_feat_dim=512,
-                       scene_type="cube", scene_cano=True, cond_mask_prob=0.0, only_mask_img_cond=True,
-                       pelvis_vis_loosen=True, diffuse_fuse=diffuse_fuse)
+        kw = dict(with_focal_length=True, with_bbox_info=True, with_cam_center=True, scene_feat_dim=512, scene_type="cube", scene_cano=True,
+                  cond_mask_prob=0.0, only_mask_img_cond=True, pelvis_vis_loosen=True, diffuse_fuse=diffuse_fuse)
+        kw.update(ctor)
+        model = EgoHMR(cfg=ref_cfg(), device="cpu", body_rep_mean=torch.from_numpy(mean), body_rep_std=torch.from_numpy(std), **kw)
     finally:
         os.chdir(cwd)
     ref_keys = {k: tuple(v.shape) for k, v in model.state_dict().items()
@@ -388,6 +388,24 @@ def g14_c4_c5_and_volsmpl(model, model_vol):
         save(name, batch_seed=41, noise_seed=41, B=B, N=N, n=n, respacing=rs, guided=guided, cond_grad_weight=w, **extra, **_pack_out(o))
 
 
+def g15_constructor_flags(asset, mean, std):
+    """EgoHMR.forward under the constructor flags the shipped test configuration does not use (egohmr.py:31-36): camera features without
+    the bbox part (with_bbox_info=False), a whole-condition second pass (diffuse_fuse with only_mask_img_cond=False, mask_cond :156-157) and
+    cond_mask_prob > 0 (training-only, must be a no-op in eval)."""
+    sd = syn.make_state_dict(15, cam_dim=3)
+    m = build_reference_model(sd, asset, mean, std, diffuse_fuse=True, with_bbox_info=False, with_cam_center=True,
+                              only_mask_img_cond=False, cond_mask_prob=0.3)
+    B = 3
+    b = syn.make_batch(B, num_scene_points=512, seed=51)
+    b["orig_keypoints_2d"][0, :, 2] = 1.0
+    x_t = syn.make_noise_stack(0, B, seed=51)[0]
+    tb = to_torch_batch(b)
+    tb["x_t"] = torch.from_numpy(x_t)
+    with torch.no_grad():
+        o = m(tb, torch.tensor([12] * B))
+    save("g15_forward_ctor_flags", batch_seed=51, weight_seed=15, cam_dim=3, num_scene_points=512, x_t=x_t, t=np.array([12] * B), **_pack_out(o))
+
+
 def g13_gcn_nonlocal():
     """ModulatedGCN(nonlocal_layer=True) (modulated_gcn.py:93-110): the reference module itself, synthetic weights with a
     non-trivial W.1 BatchNorm (the reference initialises it to zero = identity block)."""
@@ -438,6 +456,9 @@ def main():
         g14_c4_c5_and_volsmpl(build_reference_model(sd, asset, mean, std, diffuse_fuse=True),
                               build_reference_model(sd, asset, mean, std, diffuse_fuse=True, volsmpl=True))
         return
+    if os.environ.get("GOLDEN_ONLY") == "g15":
+        g15_constructor_flags(asset, *syn.make_body_rep_stats(0))
+        return
     if os.environ.get("GOLDEN_ONLY") == "g7":
         g7_single_steps()
         return
@@ -460,6 +481,7 @@ def main():
     g10_forward(model, model_nofuse)
     g8_g9_end_to_end(model)
     g14_c4_c5_and_volsmpl(model, build_reference_model(sd, asset, mean, std, diffuse_fuse=True, volsmpl=True))
+    g15_constructor_flags(asset, mean, std)
 
 
 if __name__ == "__main__":

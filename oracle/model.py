@@ -155,7 +155,8 @@ class EgoHMROracle:
 
     def __init__(self, state_dict: dict, smpl_asset: dict, body_rep_mean, body_rep_std,
                  diffuse_fuse=True, pelvis_vis_loosen=True, dtype=torch.float32, faithful=True,
-                 num_blocks=4, collision_loss=None, gcn_nonlocal_layer=False):
+                 num_blocks=4, collision_loss=None, gcn_nonlocal_layer=False, with_bbox_info=True, with_cam_center=True,
+                 only_mask_img_cond=True):
         self.dtype = dtype
         self.sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v))
                    for k, v in state_dict.items()}
@@ -163,6 +164,7 @@ class EgoHMROracle:
         self.mean = torch.as_tensor(body_rep_mean).to(dtype)
         self.std = torch.as_tensor(body_rep_std).to(dtype)
         self.diffuse_fuse = diffuse_fuse
+        self.with_bbox_info, self.with_cam_center, self.only_mask_img_cond = with_bbox_info, with_cam_center, only_mask_img_cond   # egohmr.py:31,36
         self.op2smpl = OPENPOSE_TO_SMPL_LOOSE if pelvis_vis_loosen else OPENPOSE_TO_SMPL
         self.adj = smpl_adjacency(dtype)
         self.faithful = faithful
@@ -191,10 +193,13 @@ class EgoHMROracle:
         transl_feat = F.linear(h, sd["transl_enc.layers.2.weight"], sd["transl_enc.layers.2.bias"])  # :217
         fx = batch["fx"].to(dt)
         ofx = fx * self.FX_NORM_COEFF
-        cam = torch.cat([torch.stack([batch["cam_cx"].to(dt) / ofx, batch["cam_cy"].to(dt) / ofx], -1),
-                         torch.stack([batch["box_center"][:, 0].to(dt) / ofx, batch["box_center"][:, 1].to(dt) / ofx,
-                                      batch["box_size"].to(dt) / ofx], -1),
-                         fx.unsqueeze(1)], dim=1)                                      # :195-205 -> [B,6]
+        cam = [fx.unsqueeze(1)]                                                        # :195-205: each part is PREpended
+        if self.with_bbox_info:
+            cam = [torch.stack([batch["box_center"][:, 0].to(dt) / ofx, batch["box_center"][:, 1].to(dt) / ofx,
+                                batch["box_size"].to(dt) / ofx], -1)] + cam
+        if self.with_cam_center:
+            cam = [torch.stack([batch["cam_cx"].to(dt) / ofx, batch["cam_cy"].to(dt) / ofx], -1)] + cam
+        cam = torch.cat(cam, dim=1)                                                    # -> [B, 1 (+3) (+2)]
         out = dict(img_feats=img_feats, scene=scene, scene_feats=scene_feats, transl_feat=transl_feat, cam=cam,
                    transl=transl)
         self._cache_key, self._cache = key, out
@@ -224,7 +229,10 @@ class EgoHMROracle:
         out = modulated_gcn(sd, torch.cat([cond, x_feat, temb], dim=-1), self.adj, num_blocks=self.num_blocks, nonlocal_layer=self.nonlocal_layer)  # :236-237
         if self.diffuse_fuse:                                                          # :239-254
             cond_u = cond.clone()
-            cond_u[:, :, 0:2048] = 0
+            if self.only_mask_img_cond:
+                cond_u[:, :, 0:2048] = 0                                               # mask_cond(force_mask=True), :151-155
+            else:
+                cond_u = torch.zeros_like(cond)                                        # :156-157
             out_u = modulated_gcn(sd, torch.cat([cond_u, x_feat, temb], dim=-1), self.adj, num_blocks=self.num_blocks, nonlocal_layer=self.nonlocal_layer)
             out_c = out
             out = out_u + 0 * (out_c - out_u)                                          # guidance_param = 0

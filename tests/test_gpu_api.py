@@ -339,3 +339,36 @@ def test_hip_graph_replay_equals_eager_enqueue():
         for v, x in runs[1:]:
             assert torch.equal(v, runs[0][0]) and torch.equal(x, runs[0][1]), seed
     assert not torch.equal(outs[3][0][0], outs[4][0][0])
+
+
+@pytest.mark.gpu
+def test_pass_pruning_is_exact():
+    """Items whose 24 SMPL joints are all visible take every output entry from the conditional pass (egohmr.py:249-254), so their
+    image-masked pass is skipped (ehm_gcn_set_pass_map): the sampled bodies must equal the unpruned run bit for bit - for a mixed
+    batch, an all-visible batch (no second pass at all) and a batch without any prunable item - through the fused loop and forward()."""
+    from egohmr_amd import synthetic as syn
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    dev = torch.device("cuda:0")
+    model = build_synthetic_model(dev, 0)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    B = 11
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=9)).to(dev)
+    for case, visible in (("mixed", [0, 3, 4, 10]), ("all", list(range(B))), ("none", [])):
+        bnp = syn.make_batch(B, 1024, seed=9)
+        bnp["orig_keypoints_2d"][:, 9, 2] = 0.0                     # make sure nobody is all-visible by accident ...
+        bnp["orig_keypoints_2d"][visible, :, 2] = 1.0               # ... except the chosen items
+        b = batch_to_device(bnp, dev)
+        outs = {}
+        for prune in (False, True):
+            model.prune_passes = prune
+            model.fused_sampler.invalidate()
+            o = model.fused_sampler.run(d, b, noise, ddim=True)["other_outputs"]
+            b["x_t"] = noise[0]
+            f = model(b, torch.full((B,), 7, device=dev))
+            outs[prune] = (o["pred_x_start"].clone(), o["pred_vertices"].clone(), f["pred_x_start"].clone())
+            st = model.fused_sampler.prepare(b)
+            assert st.num_masked == B - len(visible), case
+        for a, c in zip(outs[False], outs[True]):
+            assert torch.equal(a, c), case
+    model.prune_passes = True

@@ -407,3 +407,30 @@ def test_split_f16_hidden_conv_range_behaviour(dev, case):
     rel = {"x7e4": 1e-4, "sat2e5": 5e-4}.get(case, 3e-6)      # (lo / hi = 0.07 resp. 1 instead of 2^-11: the dropped lo*lo term is that much larger)
     assert float((y - r)[lim].abs().max()) < rel * max(1.0, float(r[lim].abs().max()))
     L.ehm_gcn_destroy(h)
+
+
+def test_forward_under_other_constructor_flags_vs_reference_golden(golden_dir, dev, smpl_asset):
+    """The constructor flags outside the shipped test configuration (egohmr.py:31-36): with_bbox_info=False, diffuse_fuse with
+    only_mask_img_cond=False (whole-condition second pass), cond_mask_prob > 0 (kept, a no-op in eval) - EgoHMR.forward against the
+    reference's own output (g15); with_focal_length=False fails like the reference does (self.with_vfov is never set, :77)."""
+    from egohmr_amd.factory import batch_to_device
+    from egohmr_amd.model import EgoHMR
+    g = _load(golden_dir, "g15_forward_ctor_flags")
+    sd = syn.make_state_dict(int(g["weight_seed"]), cam_dim=int(g["cam_dim"]))
+    mean, std = syn.make_body_rep_stats(0)
+    kw = dict(device=dev, body_rep_mean=mean, body_rep_std=std, with_focal_length=True, with_bbox_info=False, with_cam_center=True,
+              scene_feat_dim=512, scene_type="cube", scene_cano=True, cond_mask_prob=0.3, only_mask_img_cond=False, pelvis_vis_loosen=True,
+              diffuse_fuse=True, smpl_asset=smpl_asset)
+    m = EgoHMR(**kw)
+    res = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("smpl") for k in res.missing_keys)
+    assert m.context_feats_dim == 2048 + 3 + 512 + 128 and m.cond_mask_prob == 0.3
+    b = syn.make_batch(3, num_scene_points=int(g["num_scene_points"]), seed=int(g["batch_seed"]))
+    b["orig_keypoints_2d"][0, :, 2] = 1.0
+    tb = batch_to_device(b, dev)
+    tb["x_t"] = torch.from_numpy(g["x_t"]).to(dev)
+    for prec in ("f32", "f16x3"):
+        with precision(m, prec):
+            _check_out(m(tb, torch.from_numpy(g["t"]).to(dev)), g)
+    with pytest.raises(AttributeError, match="with_vfov"):
+        EgoHMR(**dict(kw, with_focal_length=False))

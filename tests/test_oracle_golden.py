@@ -212,3 +212,17 @@ def test_g14_c4_schedule_and_volsmpl_twin(golden_dir, synth_weights, smpl_asset,
         assert g["eval_coll"].max() > 0                       # the floor does cut through the bodies of this fixture
         o_mean = sampler.val_losses(m, b, tab, noise, rs, cond_fn_with_grad=True, cond_grad_weight=float(g["cond_grad_weight"]))
         assert float((o_mean["pred_x_start"] - o["pred_x_start"]).abs().max()) > 3e-5     # ... and the COAP-style variant (mean over B, bbox) differs
+
+
+def test_g15_forward_under_other_constructor_flags(golden_dir, smpl_asset):
+    """with_bbox_info=False (3 camera features instead of 6), diffuse_fuse with only_mask_img_cond=False (the second pass masks the WHOLE
+    condition, mask_cond egohmr.py:156-157), cond_mask_prob > 0 (training-only): the oracle vs the reference's own forward."""
+    g = _load(golden_dir, "g15_forward_ctor_flags")
+    sd = syn.make_state_dict(int(g["weight_seed"]), cam_dim=int(g["cam_dim"]))
+    mean, std = syn.make_body_rep_stats(0)
+    m = om.EgoHMROracle(sd, smpl_asset, mean, std, diffuse_fuse=True, with_bbox_info=False, with_cam_center=True, only_mask_img_cond=False)
+    b = syn.make_batch(3, num_scene_points=int(g["num_scene_points"]), seed=int(g["batch_seed"]))
+    b["orig_keypoints_2d"][0, :, 2] = 1.0
+    tb = _tt(b)
+    tb["x_t"] = torch.from_numpy(g["x_t"])
+    _check_out(m(tb, torch.from_numpy(g["t"])), g)

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EHM_LIB_PATH") or os.path.join(_HERE, "libegohmr_hip.so")   # EHM_LIB_PATH: A/B a second build (experiments)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -112,6 +112,8 @@ PROTOTYPES = {
     "ehm_linear_split": (_I, [C.POINTER(LinearDesc), _P]),
     "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "ehm_bias_act": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "ehm_resnet_stem_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
+    "ehm_resnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
     "ehm_nonlocal_attention": (_I, [_P, _P, _L, _I, _P]),
     "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

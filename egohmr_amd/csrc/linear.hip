@@ -1,4 +1,4 @@
-// Fused linear layer on the f16 matrix cores with f32-grade accuracy (split-f16 "f16x3", see gcn_f16.hip):
+// Fused linear layer on the f16 matrix cores with f32-grade accuracy (split-f16 "f16x3", see gcn_tile.hip):
 //     Y = act_out( [act_in(A0) | A1] . W^T * (1/w_scale) + bias + group_bias[row / rows_per_group] )   (+ column max per group)
 // Used for the scene PointNet of the conditioning path (models/respointnet.py:33-97: ResnetPointnet / ResnetBlockFC), where
 // the reference runs ~40 eager torch kernels over [B,N,256..1024] float32 tensors per call.  Restructuring used by the host
@@ -8,8 +8,8 @@
 //   * shortcut and fc_1 of a block accumulate into the same output, so they are ONE GEMM over the concatenated K
 //     ([relu(h) | net] . [W1 | S]^T): the loader switches source pointer at K0 (dual-source A operand);
 //   * the global max-pool over the N points is fused into the epilogue (wave shuffle -> LDS -> one atomic per column and block).
-// Operands are in the X2 split format of gcn_dev.h (32 hi halves + 32 lo halves per 32-k group).  Tile 128 x 128 x 32,
-// 4 waves (2x2, 64x64 each), global_load_lds double buffering, the same conflict-free XOR swizzle as the GCN kernels.
+// Operands are in the X2 split format of gcn_dev.h (32 hi halves + 32 lo halves per 32-k group).  Tile 192 x 128 x 32,
+// 4 waves (2 x 2, 96 x 64 each), persistent blocks, see linear_tile_kernel.
 #include "common.h"
 #include "egohmr_hip.h"
 #include "gcn_dev.h"
@@ -20,26 +20,40 @@ namespace {
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
-constexpr int LBM = 128, LBN = 128;
-constexpr int L_STAGE = (LBM + LBN) * BK;   // floats: 32 KiB
+constexpr int LBM = 192, LBN = 128;       // output tile; 4 waves as 2 x 2, 96 x 64 per wave (3 x 2 MFMA blocks of 32 x 32)
+constexpr int RK = BK;                    // floats per operand row and K tile (X2: 32 hi halves | 32 lo halves = 128 bytes)
+constexpr int LA_T = LBM * RK, LB_T = LBN * RK, LSTG = LA_T + LB_T;   // floats; one stage = 40 KiB
 
 struct LinArgs {
-  const half_t* A0; const half_t* A1; const half_t* W;
+  const float* A0; const float* A1; const float* W;    // X2 rows addressed as floats (K floats per row)
   const float* bias; const float* gbias;
-  half_t* Y; float* colmax;
+  char* Y; float* colmax;
   int K0, K1, M, N;
   int rows_per_group, valid_rows_per_group;
   int relu_in0, relu_out;
   float inv_scale;
 };
 
+struct LFrags {
+  half8 ah[3], al[3], bh[2], bl[2];
+};
+
+// ReLU of a split value: hi' = max(hi, 0), lo' = hi > 0 ? lo : 0 - on packed halves, 4 VALU per two elements (written as
+// instructions: from C the u16 minimum came back as 800 v_cmp + v_cndmask and their lane masks spilled 480 SGPRs)
 __device__ __forceinline__ void relu_split(half8& hi, half8& lo) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool pos = hi[e] > (half_t)0;
-    hi[e] = pos ? hi[e] : (half_t)0;
-    lo[e] = pos ? lo[e] : (half_t)0;
+  for (int e = 0; e < 4; ++e) {
+    unsigned int r, k;
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(h[e]));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(r), "s"(0x00010001u));     // 1 where hi' != 0 (hi' >= 0: its bits order like integers)
+    asm("v_pk_sub_u16 %0, 0, %1" : "=v"(k) : "v"(k));                         // 0xffff there, 0 elsewhere
+    h[e] = r;
+    l[e] &= k;
   }
+  hi = __builtin_bit_cast(half8, h);
+  lo = __builtin_bit_cast(half8, l);
 }
 
 __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
@@ -47,152 +61,296 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   else atomicMin((unsigned int*)addr, __float_as_uint(v));
 }
 
-__global__ __launch_bounds__(256, 2) void linear_split_kernel(LinArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * L_STAGE];   // 64 KiB; the ONLY LDS object (a second one makes hipcc
-                                                                    // drain vmcnt before every fragment read of the DMA pipeline)
+// Persistent blocks (2 per CU), software-pipelined across tiles like the GCN tile engine (gcn_tile.hip): K loop with register
+// double-buffered fragments and one barrier per K tile; after a tile's last barrier the NEXT tile's operand DMA goes out and only
+// then the epilogue runs, per wave and without a block barrier - each wave turns its 96 x 64 accumulators through the six 1 KiB
+// pieces of stage 1's activation region that its own DMA instructions fill (wave-private scratch) so that the X2 rows leave as
+// 16-byte stores.  With K = 256 .. 544 a tile has only 8 - 17 K tiles: in the one-tile-per-block kernel this replaces, prologue
+// and epilogue were more than half of a block's life (435 TFLOP/s issued on the PointNet at B = 256 x 4096 points).
+// Tile order: block b sits on XCD b % 8; the N / 128 column tiles of one row tile go to neighbouring blocks of ONE XCD in the same
+// iteration, so the row tile's activations come from HBM once.
+template <bool RELU_A>
+__global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * LSTG];   // 80 KiB; the ONLY LDS object
 
-  const int n_tiles = p.N / LBN, m_tiles = p.M / LBM;
-  const int total = m_tiles * n_tiles;
-  const int bid = blockIdx.x;
-  const int lin = ((total & 7) == 0) ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;   // XCD b%8 owns a contiguous run of row tiles
-  const int m_tile = lin / n_tiles, n_tile = lin % n_tiles;
-  const size_t m0 = (size_t)m_tile * LBM;
-  const int n0 = n_tile * LBN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int KS = 2, NM = 18, NR = 10;
+  const int tid = threadIdx.x;
   const int K = p.K0 + p.K1;
+  const int KT0 = p.K0 / RK, KT = K / RK;
+  const int n_tiles = p.N / LBN, m_tiles = p.M / LBM;
 
-  // DMA: 4 wave-instructions of 8 rows per wave and operand; row r_i = r0 + 32 i -> one swizzle key
-  const int ld_r = lane >> 3, ld_c = lane & 7;
-  const int r0 = 8 * wave + ld_r;
-  const int swz = (ld_c ^ ((r0 >> 1) & 7)) << 2;
-  const float* pA0 = (const float*)p.A0 + (m0 + r0) * p.K0 + swz;
-  const float* pA1 = p.K1 ? (const float*)p.A1 + (m0 + r0) * p.K1 + swz : nullptr;
-  const float* pW = (const float*)p.W + ((size_t)n0 + r0) * K + swz;
-  const int KT0 = p.K0 / BK, KT = K / BK;
-  auto stage = [&](int buf, int kt) {
-    float* base = lds + buf * L_STAGE;
-    const bool second = kt >= KT0;
-    const float* a = second ? pA1 + (size_t)(kt - KT0) * BK : pA0 + (size_t)kt * BK;
-    const size_t arow = (size_t)32 * (second ? p.K1 : p.K0);
+  int lane, wave, wm, wn, mi, g, r0, swz;
+  int oA[KS][2], oB[KS][2];
+  auto thread_consts = [&]() {                                 // re-derived per tile: nothing of this stays live across the epilogue
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    lane = t & 63;
+    wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    wm = wave >> 1; wn = wave & 1;
+    mi = lane & 31; g = lane >> 5;
+    r0 = 8 * wave + (lane >> 3);                               // DMA: one wave instruction = 8 rows x 128 B, rows r0 + 32 i share a key
+    swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2;
+    const int rA = 96 * wm + mi, rB = 64 * wn + mi;            // (+ 32 t / + 32 u leave the swizzle key alone)
+    const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const AS1 void*)(a + i * arow), (AS3 void*)(base + (wave + 4 * i) * 256), 16, 0, 0);
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const AS1 void*)(pW + (size_t)i * 32 * K + (size_t)kt * BK),
-                                       (AS3 void*)(base + LBM * BK + (wave + 4 * i) * 256), 16, 0, 0);
+      for (int hl = 0; hl < 2; ++hl) {
+        const int c = 4 * hl + 2 * s + g;                      // logical 16-byte chunk: [hi k0-31 | lo k0-31]
+        oA[s][hl] = rA * RK + ((c ^ keyA) << 2);
+        oB[s][hl] = LA_T + rB * RK + ((c ^ keyB) << 2);
+      }
+  };
+  thread_consts();
+
+  // ---- tiles of this block: iteration it -> (row tile, column tile)
+  const int G = gridDim.x, b = blockIdx.x;
+  const bool xcd_order = (G % 8 == 0) && ((G / 8) % n_tiles == 0);
+  auto tile_of = [&](int it, int& m, int& n) -> bool {
+    if (xcd_order) {
+      const int x = b & 7, j = b >> 3, per = (G >> 3) / n_tiles;
+      m = (it * per + j / n_tiles) * 8 + x;
+      n = j % n_tiles;
+    } else {
+      const long long t = (long long)it * G + b;
+      m = (int)(t / n_tiles);
+      n = (int)(t % n_tiles);
+    }
+    return m < m_tiles;
   };
 
-  const int mi = lane & 31, g = lane >> 5;
-  const int rA = 64 * wm + mi, rB = 64 * wn + mi;
-  const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
+  const float *pA0, *pA1, *pB;
+  const size_t a0row32 = (size_t)32 * p.K0, a1row32 = (size_t)32 * p.K1, brow32 = (size_t)32 * K;
+  auto set_tile_ptrs = [&](int m, int n) {
+    pA0 = p.A0 + ((size_t)m * LBM + r0) * p.K0 + swz;
+    pA1 = p.K1 ? p.A1 + ((size_t)m * LBM + r0) * p.K1 + swz : nullptr;
+    pB = p.W + ((size_t)n * LBN + r0) * K + swz;
+  };
+  auto dma_a = [&](int buf, int kt, int i) {
+    const float* src = kt < KT0 ? pA0 + i * a0row32 + (size_t)kt * RK : pA1 + i * a1row32 + (size_t)(kt - KT0) * RK;
+    __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + buf * LSTG + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+  auto dma_b = [&](int buf, int kt, int i) {
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * brow32 + (size_t)kt * RK), (AS3 void*)(lds + buf * LSTG + LA_T + (wave + 4 * i) * 256), 16,
+                                     0, 0);
+  };
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
+  };
 
-  f32x16 acc[2][2];
+  auto read_frags = [&](LFrags& f, int buf, int s) {
+    const float* S = lds + buf * LSTG;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 3; ++t) {
+      f.ah[t] = *(const half8*)(S + oA[s][0] + 32 * t * RK);
+      f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * RK);
+    }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u) {
+      f.bh[u] = *(const half8*)(S + oB[s][0] + 32 * u * RK);
+      f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * RK);
+    }
+    if constexpr (RELU_A) {                                       // (the ReLU'd operand is the only K segment: K1 == 0, checked by the host)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+      for (int t = 0; t < 3; ++t) relu_split(f.ah[t], f.al[t]);
+    }
+  };
+  f32x16 acc[3][2];
+  auto mfmas = [&](const LFrags& f) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                             // small cross terms first, leading term last
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[u], acc[t][u], 0, 0, 0);
+      }
+  };
+  // sched_group_barrier masks: 0x008 MFMA, 0x100 DS read, 0x010 VMEM
+  auto pin_reads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+  };
+  auto pin_reads_dma = [&]() {                                  // 10 x (MFMA, read), then the ten DMAs behind the last 8 MFMAs
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+  };
 
-  stage(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int it = 0, m, n;
+  if (!tile_of(0, m, n)) return;
+  set_tile_ptrs(m, n);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+
+  while (true) {
+    // ---- head: stage 1's six activation pieces are the last memory instructions this wave issued; everything older (stage 0,
+    //      the previous tile's stores) must be complete
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
-    const float* As = lds + (kt & 1) * L_STAGE;
-    const float* Bs = As + LBM * BK;
-    const bool relu_a = p.relu_in0 && kt < KT0;
+    thread_consts();
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int ch = 2 * s + g, cl = 4 + 2 * s + g;
-      half8 ah[2], al[2], bh[2], bl[2];
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ah[t] = *(const half8*)(As + (rA + 32 * t) * BK + ((ch ^ keyA) << 2));
-        al[t] = *(const half8*)(As + (rA + 32 * t) * BK + ((cl ^ keyA) << 2));
-        if (relu_a) relu_split(ah[t], al[t]);
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    LFrags f0, f1;
+    read_frags(f0, 0, 0);
+
+    auto first_phase = [&](int buf) {                  // k-step 0 of K tile kt: multiply f0 while f1 fills with k-step 1
+      read_frags(f1, buf, 1);
+      mfmas(f0);
+      pin_reads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                         // tile kt is in everyone's registers; tile kt + 1 is complete in LDS
+    };
+    for (int kt = 0; kt < KT - 2; ++kt) {
+      const int buf = kt & 1;
+      first_phase(buf);
+      read_frags(f0, buf ^ 1, 0);
+      stage(buf, kt + 2);
+      mfmas(f1);
+      pin_reads_dma();
+    }
+    {
+      const int buf = (KT - 2) & 1;
+      first_phase(buf);
+      read_frags(f0, buf ^ 1, 0);
+      mfmas(f1);
+      pin_reads();
+    }
+    first_phase((KT - 1) & 1);                         // ends with a barrier: every fragment is in registers, all LDS is dead
+
+    // ---- per-column constants, then the next tile's operand DMA, then this tile's epilogue
+    const int n0 = n * LBN;
+    const size_t row0 = (size_t)m * LBM;
+    const int group = (int)(row0 / p.rows_per_group);
+    const int lim = p.valid_rows_per_group - (int)(row0 % p.rows_per_group) - 96 * wm;   // rows of this wave that count for the maximum
+    float add[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + 64 * wn + 32 * u + mi;
+      add[u] = p.bias ? p.bias[col] : 0.f;
+      if (p.gbias) add[u] += p.gbias[(size_t)group * p.N + col];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f1);
+    int m_next, n_next;
+    const bool have_next = tile_of(it + 1, m_next, n_next);
+    if (have_next) {
+      set_tile_ptrs(m_next, n_next);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dma_a(0, 0, i);              // stage 1's activation pieces are the epilogue's scratch first
+    }
+
+    // accumulator layout: lane (mi, g) owns column 64 wn + 32 u + mi; register r of acc[t][u] is row 32 t + 8 (r >> 2) + 4 g + (r & 3).
+    // Row group Gq = 4 t + (r >> 2) = 8 rows; a pass turns three groups (24 rows x 64 columns = the wave's six 1 KiB pieces):
+    // piece 2 gi + u holds [8 rows][32 columns] of group 3 pass + gi.
+    const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(p.Y ? p.Y + (row0 + 96 * wm) * (size_t)p.N * 4 : (char*)p.A0);
+    const unsigned int yrow = (unsigned int)p.N * 4u;
+    const bool relu_out = p.relu_out != 0, has_y = p.Y != nullptr;
+    const int wbase = LSTG + wave * 256 + (4 * g) * 32 + mi;
+    const int rr = lane >> 3, oct = lane & 7;                  // my read items: row rr of group gi = item index, columns 8 oct .. + 7 of the wave's 64
+    const int rbase = LSTG + wave * 256 + (oct >> 2) * 1024 + rr * 32 + 8 * (oct & 3);
+    const int colw = n0 + 64 * wn + 8 * oct;                   // first column of my items
+    const unsigned int col_off = (unsigned int)(((colw >> 5) * 64 + (colw & 31)) * 2);   // X2: 8 hi halves here, the 8 lo halves 64 B on
+    float cmax[2] = {-3.4e38f, -3.4e38f};
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        const int Gq = 3 * ps + gi, t = Gq >> 2, q = Gq & 3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = fmaf(acc[t][u][4 * q + j], p.inv_scale, add[u]);
+            if (relu_out) v = fmaxf(v, 0.f);
+            cmax[u] = fmaxf(cmax[u], v);
+            if (has_y) lds[wbase + (2 * gi + u) * 1024 + j * 32] = v;
+          }
+      }
+      if (has_y) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private scratch: program order is enough
+        f32x4 tq[3][2];
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+          tq[gi][0] = *(const f32x4*)(lds + rbase + 2048 * gi);
+          tq[gi][1] = *(const f32x4*)(lds + rbase + 2048 * gi + 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+          const int Gq = 3 * ps + gi;
+          const float v[8] = {tq[gi][0][0], tq[gi][0][1], tq[gi][0][2], tq[gi][0][3], tq[gi][1][0], tq[gi][1][1], tq[gi][1][2], tq[gi][1][3]};
+          half8 hh, ll;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
+            ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
+          }
+          const unsigned int vo = (unsigned int)(8 * Gq + rr) * yrow + col_off;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
+        }
+      }
+    }
+    if (p.colmax) {
+      if (lim < 96) {                                           // (rare: the group's last row tile) redo the maximum over the valid rows only
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          cmax[u] = -3.4e38f;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = fmaf(acc[t][u][r], p.inv_scale, add[u]);
+              if (relu_out) v = fmaxf(v, 0.f);
+              if (32 * t + 8 * (r >> 2) + 4 * g + (r & 3) < lim) cmax[u] = fmaxf(cmax[u], v);
+            }
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        bh[u] = *(const half8*)(Bs + (rB + 32 * u) * BK + ((ch ^ keyB) << 2));
-        bl[u] = *(const half8*)(Bs + (rB + 32 * u) * BK + ((cl ^ keyB) << 2));
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], acc[t][u], 0, 0, 0);
-        }
-    }
-  }
-
-  // ---- epilogue.  Accumulator layout: lane = output column, registers = rows.  Bias / ReLU / the per-group column maximum are
-  //      taken there; the values then cross a float [128][128] LDS tile so that the rows leave as 16-byte X2 stores (8 hi halves,
-  //      8 lo halves) - with K = 256..512 a block has only 8-16 K tiles, and 64 dword stores per lane were most of its life time.
-  __syncthreads();                                    // every wave is done reading the last K tile: the stages become the tile
-  float* T = lds;
-  const int group = (int)(m0 / p.rows_per_group);
-  const int row_in_group0 = (int)(m0 % p.rows_per_group);
-  float cmaxs[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int col = 64 * wn + 32 * u + mi;
-    const int n = n0 + col;
-    float add = p.bias ? p.bias[n] : 0.f;
-    if (p.gbias) add += p.gbias[(size_t)group * p.N + n];
-    float cmax = -3.4e38f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 64 * wm + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
-        float v = fmaf(acc[t][u][r], p.inv_scale, add);
-        if (p.relu_out) v = fmaxf(v, 0.f);
-        T[row * LBN + col] = v;
-        if (row_in_group0 + row < p.valid_rows_per_group) cmax = fmaxf(cmax, v);
+        const float cm = fmaxf(cmax[u], __shfl_xor(cmax[u], 32));
+        if (g == 0 && lim > 0) atomic_max_float(p.colmax + (size_t)group * p.N + n0 + 64 * wn + 32 * u + mi, cm);
       }
     }
-    cmaxs[u] = fmaxf(cmax, __shfl_xor(cmax, 32));
-  }
-  __syncthreads();
-  if (p.Y) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    // work item = (row, 8 consecutive columns): 128 x 16 items, 8 per thread; items 8..15 of a row read their two 16-byte halves in
-    // the opposite order, so that every ds_read_b128 lane group touches 16 distinct 16-byte slots of the 256-byte bank window
+    if (!have_next) break;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int uu = tid + 256 * i, row = uu >> 4, c8 = uu & 15;
-      const float* src = T + row * LBN + 8 * c8;
-      const int flip = c8 >> 3;
-      const f32x4 va = *(const f32x4*)(src + 4 * flip), vb = *(const f32x4*)(src + 4 * (1 - flip));
-      const f32x4 v0 = flip ? vb : va, v1 = flip ? va : vb;
-      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      half8 hh, ll;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
-        hh[k] = (half_t)c;
-        ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
-      }
-      half_t* dst = p.Y + split_off<32>(m0 + row, n0 + 8 * c8, p.N);   // 8 | 32: the eight hi halves are contiguous, the lo halves 32 further
-      *(u32x4*)dst = __builtin_bit_cast(u32x4, hh);
-      *(u32x4*)(dst + 32) = __builtin_bit_cast(u32x4, ll);
-    }
-  }
-  if (p.colmax) {
-    __syncthreads();                                  // the tile has been read: its memory carries the column-max exchange now
-    float (*smax)[LBN] = (float (*)[LBN])lds;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (g == 0) smax[wm][64 * wn + 32 * u + mi] = cmaxs[u];
-    __syncthreads();
-    if (tid < LBN) atomic_max_float(p.colmax + (size_t)group * p.N + n0 + tid, fmaxf(smax[0][tid], smax[1][tid]));
+    for (int i = 0; i < 6; ++i) dma_a(1, 1, i);                // the scratch is free again: stage 1 of the next tile
+    m = m_next; n = n_next; ++it;
   }
 }
 
@@ -314,26 +472,33 @@ extern "C" int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int
 extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
   EHM_CHECK_ARG(d && d->A0 && d->W && (d->Y || d->colmax));
   EHM_CHECK_ARG(d->M > 0 && d->M % LBM == 0 && d->N > 0 && d->N % LBN == 0);
-  EHM_CHECK_ARG(d->K0 > 0 && d->K0 % BK == 0 && d->K1 >= 0 && d->K1 % BK == 0 && (d->K1 == 0 || d->A1));
+  EHM_CHECK_ARG(d->K0 > 0 && d->K0 % BK == 0 && d->K1 >= 0 && d->K1 % BK == 0 && (d->K1 == 0 || d->A1) && d->K0 + d->K1 >= 2 * BK);
   EHM_CHECK_ARG(d->rows_per_group > 0 && d->rows_per_group % LBM == 0 && d->M % d->rows_per_group == 0);
   EHM_CHECK_ARG(d->w_scale > 0.f);
+  EHM_CHECK_ARG(d->M < (int64_t)1 << 31 && (int64_t)LBM * d->N * 4 < ((int64_t)1 << 31));
   LinArgs a;
-  a.A0 = (const half_t*)d->A0; a.A1 = (const half_t*)d->A1; a.W = (const half_t*)d->W;
-  a.bias = d->bias; a.gbias = d->group_bias; a.Y = (half_t*)d->Y; a.colmax = d->colmax;
+  a.A0 = (const float*)d->A0; a.A1 = (const float*)d->A1; a.W = (const float*)d->W;
+  a.bias = d->bias; a.gbias = d->group_bias; a.Y = (char*)d->Y; a.colmax = d->colmax;
   a.K0 = d->K0; a.K1 = d->K1; a.M = (int)d->M; a.N = d->N;
   a.rows_per_group = d->rows_per_group;
   a.valid_rows_per_group = d->valid_rows_per_group > 0 ? d->valid_rows_per_group : d->rows_per_group;
   a.relu_in0 = d->relu_in0; a.relu_out = d->relu_out; a.inv_scale = 1.f / d->w_scale;
-  EHM_CHECK_ARG(d->M < (int64_t)1 << 31);
-  const int blocks = (int)(d->M / LBM) * (d->N / LBN);
-  hipLaunchKernelGGL(linear_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  const int64_t tiles = (d->M / LBM) * (d->N / LBN);
+  int64_t blocks = 2 * (int64_t)ehm_num_cus();            // what is co-resident (80 KiB of LDS per block)
+  if (blocks > tiles) blocks = tiles;
+  if (d->relu_in0 && d->K1 != 0) {
+    ehm_set_error("ehm_linear_split: relu_in0 needs K1 == 0 (the ReLU'd operand must be the only K segment)");
+    return EHM_EINVAL;
+  }
+  if (d->relu_in0) hipLaunchKernelGGL(linear_tile_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(linear_tile_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
                                  int C, void* stream) {
-  EHM_CHECK_ARG(pts && Wpos && bpos && R0 && P32 && B > 0 && N > 0 && N_padded >= N && N_padded % LBM == 0 && C > 0 && C % 32 == 0);
+  EHM_CHECK_ARG(pts && Wpos && bpos && R0 && P32 && B > 0 && N > 0 && N_padded >= N && C > 0 && C % 32 == 0);
   hipLaunchKernelGGL(pointnet_lift_kernel, dim3((unsigned)((size_t)B * N_padded)), dim3(256), 0, (hipStream_t)stream, pts, Wpos, bpos,
                      (half_t*)R0, (half_t*)P32, B, N, N_padded, C);
   EHM_LAUNCH_CHECK();

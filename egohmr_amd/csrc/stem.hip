@@ -1,0 +1,132 @@
+// ResNet-50 stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 64, BatchNorm folded by the caller) + bias + ReLU + max-pool 3x3 /
+// stride 2 / pad 1, NCHW float32 image in, NHWC float32 [N, H/4, W/4, 64] out (torchvision ResNet.forward's conv1 / bn1 / relu /
+// maxpool as used by models/resnet.py:139-150 -> models/egohmr/egohmr.py:183).  Replaces a library convolution (2.3 ms at
+// B = 256), an NCHW max-pool (1.0 ms), a bias/ReLU pass (0.4 ms) and the NCHW -> NHWC permute of the pooled tensor.
+//
+// Ci = 3 leaves nothing for an implicit GEMM to tile (K = 147), so the conv runs on the vector ALU in float32 with the roles
+// chosen so that nothing but FMAs sits in the inner loop:
+//   * lane = output channel (64 lanes = the 64 channels); the lane's 147 weights live in VGPRs for the wave's whole life;
+//   * the image is wave-uniform data: a (ci, kh) slice of the input row segment is fetched with SCALAR loads (s_load_dwordx8,
+//     K-cache) into SGPRs and enters v_fma_f32 as the scalar operand - no LDS, no per-lane address arithmetic;
+//   * a wave walks down 17 conv rows of a 17-pixel-wide strip (16 + 1 halo each way for the pool), keeps the 17 accumulators of
+//     the current row in registers, folds bias / ReLU / the 3-wide column maximum and carries the 3-row maximum in 8 registers:
+//     the pool is register-local because a lane owns one channel; every pooled pixel leaves as one 256-byte row of 64 lanes.
+// A small pre-pass copies the image into a zero-padded [N,3,H+8,W+8] scratch (5 left / top, 3 right / bottom) so that every
+// scalar load is in bounds and 32-byte aligned and the inner loop has no border conditions; conv pixels that are POOL padding
+// (row / column -1) are zero, which equals torch's -inf padding because every window also holds a real ReLU output (>= 0).
+#include "common.h"
+#include "egohmr_hip.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int SP_L = 5, SP_X = 8;     // left / top padding, total extra columns / rows of the scratch image
+
+__global__ void stem_pad_kernel(const float* __restrict__ img, float* __restrict__ pad, int H, int W, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Wp = W + SP_X, Hp = H + SP_X;
+  const int c = (int)(i % Wp), r = (int)((i / Wp) % Hp);
+  const long long plane = i / ((long long)Wp * Hp);
+  const int sr = r - SP_L, sc = c - SP_L;
+  pad[i] = (sr >= 0 && sr < H && sc >= 0 && sc < W) ? img[(plane * H + sr) * W + sc] : 0.f;
+}
+
+typedef const float __attribute__((address_space(4))) cfloat;
+
+// wave task = (image, strip of 16 conv columns, chunk of 16 conv rows); 4 tasks per block
+__global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __restrict__ pad, const float* __restrict__ Wt,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                                 int strips, int chunks, int tasks) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int Hc = H / 2, Wc = W / 2, Hq = H / 4, Wq = W / 4;      // conv / pooled extents
+  const int Wp = W + SP_X, Hp = H + SP_X;
+  int b = 4 * (int)blockIdx.x + wave;
+  if (b >= tasks) return;
+  const int chunk = b % chunks; b /= chunks;                      // pooled rows 8 chunk .. +7, conv rows 16 chunk - 1 .. + 15
+  const int strip = b % strips;
+  const int n = b / strips;
+  (void)Hc; (void)Wc;
+
+  float w[147];
+#pragma unroll
+  for (int k = 0; k < 147; ++k) w[k] = Wt[k * 64 + lane];
+  const float bs = bias[lane];
+
+  // conv pixel i of the strip = conv column 16 strip - 1 + i; its taps are padded columns 32 strip + 2 i + kw (kw = 0..6)
+  const float* img_n = pad + (size_t)n * 3 * Hp * Wp + 32 * strip;
+  float m[8];                                                      // running 3-row maximum of the column-pooled values
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = 0.f;
+  float* yrow = y + (((size_t)n * Hq + 8 * chunk) * Wq + 8 * strip) * 64 + lane;
+
+  for (int i = 0; i < 17; ++i) {
+    const int r = 16 * chunk - 1 + i;                             // conv row; its taps are padded rows 2 r + 2 + kh
+    float cm[8];
+    if (r < 0) {                                                   // pool padding
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cm[j] = 0.f;
+    } else {
+      float acc[17];
+#pragma unroll
+      for (int p = 0; p < 17; ++p) acc[p] = bs;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+          cfloat* xs = (cfloat*)(uintptr_t)(img_n + ((size_t)ci * Hp + (2 * r + 2 + kh)) * Wp);
+          float x[40];
+#pragma unroll
+          for (int j = 0; j < 40; ++j) x[j] = xs[j];
+#pragma unroll
+          for (int kw = 0; kw < 7; ++kw) {
+            const float wk = w[(ci * 7 + kh) * 7 + kw];
+#pragma unroll
+            for (int p = 0; p < 17; ++p) acc[p] = fmaf(x[2 * p + kw], wk, acc[p]);
+          }
+        }
+#pragma unroll
+      for (int p = 0; p < 17; ++p) acc[p] = fmaxf(acc[p], 0.f);
+      if (strip == 0) acc[0] = 0.f;                                // conv column -1: pool padding
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cm[j] = fmaxf(fmaxf(acc[2 * j], acc[2 * j + 1]), acc[2 * j + 2]);
+    }
+    if ((i & 1) == 0) {                                            // row 2 j: closes pooled row j - 1, opens pooled row j
+      if (i > 0) {
+        float* dst = yrow + (size_t)(i / 2 - 1) * Wq * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * 64] = fmaxf(m[j], cm[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = cm[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], cm[j]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ehm_resnet_stem_scratch_bytes(int N, int H, int W) {
+  return (size_t)N * 3 * (H + SP_X) * (W + SP_X) * sizeof(float);
+}
+
+extern "C" int ehm_resnet_stem(const float* img, const float* Wt, const float* bias, float* scratch, float* y, int N, int H, int W,
+                               void* stream) {
+  EHM_CHECK_ARG(img && Wt && bias && scratch && y && N > 0 && H > 0 && W > 0);
+  if (H % 32 != 0 || W % 32 != 0) {
+    ehm_set_error("ehm_resnet_stem needs H %% 32 == 0 and W %% 32 == 0 (got %d x %d)", H, W);
+    return EHM_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)N * 3 * (H + SP_X) * (W + SP_X);
+  hipLaunchKernelGGL(stem_pad_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, img, scratch, H, W, total);
+  EHM_LAUNCH_CHECK();
+  const int strips = W / 32, chunks = H / 32, tasks = N * strips * chunks;
+  hipLaunchKernelGGL(stem_conv_pool_kernel, dim3((unsigned)ceil_div(tasks, 4)), dim3(256), 0, st, scratch, Wt, bias, y, H, W, strips, chunks,
+                     tasks);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}

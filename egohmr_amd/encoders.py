@@ -4,7 +4,7 @@ The reference re-evaluates both inside every denoising step (models/egohmr/egohm
 neither depends on x_t or t, so the build evaluates them once per sampled batch.  Both run on the
 hand-written split-f16 matrix-core kernels (csrc/conv.hip: the 52 bottleneck convolutions of ResNet-50
 as NHWC implicit GEMMs with BatchNorm folded; csrc/linear.hip: the scene PointNet's GEMMs with the
-max-pool fused); only the 7x7 stem and its max-pool go through MIOpen / ATen.  Sub-module and
+max-pool fused; csrc/stem.hip: the 7x7 stem + ReLU + max-pool as one vector-ALU kernel).  Sub-module and
 parameter names follow the reference so its checkpoints load (``backbone.*`` models/resnet.py:97-136,
 ``scene_enc.*`` models/respointnet.py:13-27).
 """
@@ -142,9 +142,27 @@ class ResNet50Features(nn.Module):
             _lib.check(_lib.lib().ehm_conv_nhwc_split(C.byref(d), _lib.stream_ptr()), "ehm_conv_nhwc_split")
             return y
 
+        stem_wt = stem[0].reshape(64, 147).t().contiguous()                        # [147][64], k = (ci*7 + kh)*7 + kw
+        stem_b = stem[1].contiguous()
+
+        def stem_mc(x):
+            """conv1 + bn1 + relu + maxpool in one pass, NCHW in -> NHWC out (csrc/stem.hip)"""
+            N, _, H, W = x.shape
+            lib = _lib.lib()
+            if stem_wt.device != x.device:
+                raise _lib.EgoHMRHipError("ResNet50Features.folded(): weights and input live on different devices")
+            scratch = torch.empty(lib.ehm_resnet_stem_scratch_bytes(N, H, W) // 4, device=x.device)
+            y = torch.empty(N, H // 4, W // 4, 64, device=x.device)
+            _lib.check(lib.ehm_resnet_stem(x.data_ptr(), stem_wt.data_ptr(), stem_b.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W,
+                                           _lib.stream_ptr()), "ehm_resnet_stem")
+            return y
+
         def run_mc(x):
-            x = F.max_pool2d(cba(x.contiguous(), stem), 3, stride=2, padding=1)      # stem (Ci = 3) stays on the library conv
-            x = x.permute(0, 2, 3, 1).contiguous()                                  # NHWC from here on
+            x = _lib.f32(x)
+            if x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:               # (the reference always feeds 224 x 224 crops)
+                x = F.max_pool2d(cba(x.contiguous(), stem), 3, stride=2, padding=1).permute(0, 2, 3, 1).contiguous()
+            else:
+                x = stem_mc(x)                                                      # NHWC from here on
             for c1, c2, c3, ds in blocks:
                 y = conv_mc(conv_mc(x, c1), c2)
                 x = conv_mc(y, c3, res=x if ds is None else conv_mc(x, ds, relu=False))
@@ -232,7 +250,7 @@ class ResnetPointnet(nn.Module):
         P = self._prepare(dev)
         p = _lib.f32(p)
         B, N, _ = p.shape
-        Np = (N + 127) // 128 * 128
+        Np = (N + 191) // 192 * 192                                                      # row tile of csrc/linear.hip
         M = B * Np
         st = _lib.stream_ptr()
         f32buf = lambda cols: torch.empty(M, cols, dtype=torch.float32, device=dev)      # X2 buffers (same bytes as float32)

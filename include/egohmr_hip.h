@@ -176,11 +176,11 @@ typedef struct {
   void* Y;                 /* X2 [M, N] or NULL                                                     */
   float* colmax;           /* [M/rows_per_group, N] or NULL: running max over the group's valid rows
                               (caller initialises to -inf); fused torch.max(dim=1), respointnet.py:38 */
-  int64_t M;               /* rows, multiple of 128                                                 */
-  int N, K0, K1;           /* N multiple of 128; K0, K1 multiples of 32                             */
-  int rows_per_group;      /* padded points per body, multiple of 128                               */
+  int64_t M;               /* rows, multiple of 192 (the row tile)                                  */
+  int N, K0, K1;           /* N multiple of 128; K0, K1 multiples of 32, K0 + K1 >= 64              */
+  int rows_per_group;      /* padded points per body, multiple of 192                               */
   int valid_rows_per_group;/* real points per body (<= rows_per_group); 0 = all                     */
-  int relu_in0;            /* apply ReLU to A0 on load (ResnetBlockFC's actvn before fc_0 / fc_1)   */
+  int relu_in0;            /* apply ReLU to A0 on load (ResnetBlockFC's actvn before fc_0); needs K1 == 0 */
   int relu_out;            /* apply ReLU before storing                                             */
   float w_scale;           /* the power-of-two scale baked into W                                   */
 } ehm_linear_desc;
@@ -197,6 +197,15 @@ int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, vo
  * out = self.relu(out)`, used as EgoHMR's backbone at models/egohmr/egohmr.py:183) in ONE pass over the activation instead
  * of the three or four eager passes.  residual may be NULL; relu != 0 applies max(., 0). */
 int ehm_bias_act(float* y, const float* bias, const float* residual, int64_t n, int C, int HW, int relu, void* stream);
+
+/* ResNet-50 stem in one pass (torchvision ResNet.forward conv1 / bn1 / relu / maxpool, models/resnet.py:139-150 as used at
+ * models/egohmr/egohmr.py:183): conv 7x7 stride 2 pad 3 (3 -> 64) + bias + ReLU + max-pool 3x3 stride 2 pad 1.
+ *   img [N,3,H,W] float32 (NCHW), H % 32 == 0, W % 32 == 0;   y [N,H/4,W/4,64] float32 (NHWC)
+ *   Wt [147][64]: the BatchNorm-folded weights transposed, row k = (ci*7 + kh)*7 + kw;   bias [64]
+ *   scratch: ehm_resnet_stem_scratch_bytes(N,H,W) bytes of device memory (zero-padded copy of the image) */
+size_t ehm_resnet_stem_scratch_bytes(int N, int H, int W);
+int ehm_resnet_stem(const float* img, const float* Wt, const float* bias, float* scratch, float* y, int N, int H, int W,
+                    void* stream);
 
 /* NHWC convolution + bias (+ identity) + ReLU as an implicit GEMM on the f16 matrix cores with f32-grade accuracy (hi/lo split
  * operands, f32 accumulate): y[n,ho,wo,co] = act(sum x[n, ho*s-p+kh, wo*s-p+kw, ci] w[co,kh,kw,ci] + bias[co] (+ residual)).

@@ -370,6 +370,32 @@ def test_pointnet_vs_oracle(dev, model, synth_weights, B, N):
 
 # --------------------------------------------------------------------------------------------- ResNet-50 backbone
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 96), (1, 32, 32)])
+def test_resnet_stem_vs_torch_fp64(dev, shape):
+    """csrc/stem.hip (conv 7x7 s2 p3 + bias + ReLU + max-pool 3x3 s2 p1, NCHW -> NHWC) against torch float64 on the same inputs
+    (torchvision ResNet.forward conv1 / bn1 / relu / maxpool, models/resnet.py:139-150), including the image borders, a
+    non-square image and the smallest legal one."""
+    import torch.nn.functional as F
+    from egohmr_amd import _lib
+    N, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.max_pool2d(F.relu(F.conv2d(img.double(), w.double(), b.double(), stride=2, padding=3)), 3, stride=2, padding=1).permute(0, 2, 3, 1)
+    L = _lib.lib()
+    x, wt, bd = img.to(dev), w.reshape(64, 147).t().contiguous().to(dev), b.to(dev)
+    scratch = torch.empty(L.ehm_resnet_stem_scratch_bytes(N, H, W) // 4, device=dev)
+    y = torch.full((N, H // 4, W // 4, 64), float("nan"), device=dev)
+    _lib.check(L.ehm_resnet_stem(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W, None))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    print(f"[stem {shape}] max|err| vs fp64 = {err:.3e} (|y|max = {ref.abs().max().item():.2f})")
+    assert err < 2e-5
+    assert L.ehm_resnet_stem(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, 48, W, None) != 0   # H % 32
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("matrix_core", [True, False])
 def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, matrix_core):
     """The BatchNorm-folded backbone (split-f16 implicit-GEMM convs of csrc/conv.hip, or library convs + ehm_bias_act) against the

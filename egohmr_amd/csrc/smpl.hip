@@ -337,6 +337,13 @@ __global__ void pf_pack_kernel(const float* __restrict__ Rws, const float* __res
 
 // `joints` (may be nullptr): rows [24 + n_extra][3] per body; the VertexJointSelector's extra joints (smplx vertex_joint_selector.py: 21
 // picked vertices) are written by the lane that owns the vertex - no separate gather launch.
+#ifdef EHM_STAMPS
+__device__ unsigned long long* g_sdbg = nullptr;
+#define SSTAMP(i) do { if (g_sdbg && (threadIdx.x & 63) == 0) g_sdbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restrict__ PF, const float* __restrict__ A, SmplDev S,
                                                         float* __restrict__ verts, float* __restrict__ joints, int B, int v_tiles, int vt_groups) {
   __shared__ __attribute__((aligned(16))) float sA[32][kJ][12];   // 36 KiB: skinning transforms of the block's 32 bodies
@@ -346,40 +353,59 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
   const int b_tiles = (B + 31) / 32;
   const int vg = (kk / b_tiles) * 8 + xcd, bt = kk % b_tiles;
   if (vg >= vt_groups) return;
+  SSTAMP(0);
   const int b0 = 32 * bt, nb = min(32, B - b0);
-  for (int i = tid; i < 32 * kJ * 12; i += 256) (&sA[0][0][0])[i] = (i / (kJ * 12)) < nb ? A[(size_t)b0 * kJ * 12 + i] : 0.f;
-  __syncthreads();
-  const int vt = 4 * vg + wave;
-  if (vt >= v_tiles) return;
+  const int vt = min(4 * vg + wave, v_tiles - 1);             // (a surplus wave of the last group recomputes the last tile and stores nothing)
+  const bool live = 4 * vg + wave < v_tiles;
 
+  // blend GEMM operands: fragment sets three k-steps deep (a set = 8 x 1 KiB coalesced loads from L2; nine MFMAs = 288 cycles cover
+  // a third of that latency), the first two requested before the transforms are staged
   const sk_half8* pa = PF + ((size_t)bt * kBlendSteps * 2) * 64 + lane;
   const sk_half8* pb = (const sk_half8*)S.PDf + ((size_t)vt * kBlendSteps * 6) * 64 + lane;
+  struct FragSet { sk_half8 a_hi, a_lo, b_hi[3], b_lo[3]; } F[3];
+  auto load_set = [&](FragSet& f, int s) {
+    f.a_hi = pa[(2 * s) * 64]; f.a_lo = pa[(2 * s + 1) * 64];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { f.b_hi[c] = pb[(6 * s + 2 * c) * 64]; f.b_lo[c] = pb[(6 * s + 2 * c + 1) * 64]; }
+  };
+  load_set(F[0], 0);
+  load_set(F[1], 1);
+
+  // the 32 bodies' skinning transforms: 2304 float4, nine per thread, all requested before the first is stored (the element-wise
+  // copy loop this replaces was 36 dependent round trips = 23.6 k of the wave's 57.7 k cycles)
+  {
+    const f32x4* src = (const f32x4*)(A + (size_t)b0 * kJ * 12);
+    f32x4 tmp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = tid + 256 * k;
+      tmp[k] = (i / (kJ * 3)) < nb ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ((f32x4*)&sA[0][0][0])[tid + 256 * k] = tmp[k];
+  }
+  __syncthreads();
+  if (!live) return;
+  SSTAMP(1);
+
   f32x16 acc[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  sk_half8 a_hi = pa[0], a_lo = pa[64], b_hi[3], b_lo[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { b_hi[c] = pb[(2 * c) * 64]; b_lo[c] = pb[(2 * c + 1) * 64]; }
   for (int s = 0; s < kBlendSteps; ++s) {
-    // next step's fragments in flight under this step's nine MFMAs (the last iteration re-reads step 13: harmless)
-    const int sn = s + 1 < kBlendSteps ? s + 1 : s;
-    const sk_half8 na_hi = pa[(2 * sn) * 64], na_lo = pa[(2 * sn + 1) * 64];
-    sk_half8 nb_hi[3], nb_lo[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { nb_hi[c] = pb[(6 * sn + 2 * c) * 64]; nb_lo[c] = pb[(6 * sn + 2 * c + 1) * 64]; }
+    if (s + 2 < kBlendSteps) load_set(F[(s + 2) % 3], s + 2);
+    const FragSet& f = F[s % 3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {   // small cross terms first, leading term last
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi[c], acc[c], 0, 0, 0);
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo[c], acc[c], 0, 0, 0);
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[c], acc[c], 0, 0, 0);
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a_lo, f.b_hi[c], acc[c], 0, 0, 0);
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a_hi, f.b_lo[c], acc[c], 0, 0, 0);
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a_hi, f.b_hi[c], acc[c], 0, 0, 0);
     }
-    a_hi = na_hi; a_lo = na_lo;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { b_hi[c] = nb_hi[c]; b_lo[c] = nb_lo[c]; }
   }
 
+  SSTAMP(2);
   // ---- skinning: lane (vertex = lane & 31, half = lane >> 5) holds bodies (r&3) + 8*(r>>2) + 4*half, r = 0..15
   const int v = 32 * vt + (lane & 31), half = lane >> 5;
   if (v >= S.V) return;
@@ -396,19 +422,18 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
   for (int r = 0; r < 16; ++r) {
     const int bb = (r & 3) + 8 * (r >> 2) + 4 * half;
     const float px = fmaf(acc[0][r], inv, t0), py = fmaf(acc[1][r], inv, t1), pz = fmaf(acc[2][r], inv, t2);
-    float T[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    typedef float sk_f32x2 __attribute__((ext_vector_type(2)));
+    sk_f32x2 T2[6];                                              // the blended 3 x 4 transform, two entries per register pair (v_pk_fma_f32)
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      const float wj = wsp[s4];
+      const sk_f32x2 wj = {wsp[s4], wsp[s4]};
       const int j = jsp[s4];
       const f32x4 r0 = *(const f32x4*)&sA[bb][j][0], r1 = *(const f32x4*)&sA[bb][j][4], r2 = *(const f32x4*)&sA[bb][j][8];
+      const sk_f32x2 q[6] = {{r0[0], r0[1]}, {r0[2], r0[3]}, {r1[0], r1[1]}, {r1[2], r1[3]}, {r2[0], r2[1]}, {r2[2], r2[3]}};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        T[e] = fmaf(wj, r0[e], T[e]); T[4 + e] = fmaf(wj, r1[e], T[4 + e]); T[8 + e] = fmaf(wj, r2[e], T[8 + e]);
-      }
+      for (int e = 0; e < 6; ++e) T2[e] = s4 == 0 ? wj * q[e] : __builtin_elementwise_fma(wj, q[e], T2[e]);
     }
+    const float T[12] = {T2[0][0], T2[0][1], T2[1][0], T2[1][1], T2[2][0], T2[2][1], T2[3][0], T2[3][1], T2[4][0], T2[4][1], T2[5][0], T2[5][1]};
     if (bb < nb) {
       float* o = verts + ((size_t)(b0 + bb) * S.V + v) * 3;
       const float ox = T[0] * px + T[1] * py + T[2] * pz + T[3], oy = T[4] * px + T[5] * py + T[6] * pz + T[7],
@@ -421,7 +446,11 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
       }
     }
   }
+  SSTAMP(3);
 }
+#ifdef EHM_STAMPS
+extern "C" int ehm_dbg_set_skin(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sdbg), &q, sizeof(q)); }
+#endif
 
 __global__ void extra_joints_kernel(const float* __restrict__ verts, const int32_t* __restrict__ idx, float* __restrict__ joints,
                                     int B, int V, int n_extra) {

@@ -6,8 +6,9 @@
 // Ci = 3 leaves nothing for an implicit GEMM to tile (K = 147), so the conv runs on the vector ALU in float32 with the roles
 // chosen so that nothing but FMAs sits in the inner loop:
 //   * lane = output channel (64 lanes = the 64 channels); the lane's 147 weights live in VGPRs for the wave's whole life;
-//   * the image is wave-uniform data: a (ci, kh) slice of the input row segment is fetched with SCALAR loads (s_load_dwordx8,
-//     K-cache) into SGPRs and enters v_fma_f32 as the scalar operand - no LDS, no per-lane address arithmetic;
+//   * the image is wave-uniform data: a (ci, kh) slice of the input row segment is fetched with SCALAR loads (s_load_dwordx16,
+//     K-cache) into SGPRs and enters v_pk_fma_f32 as an SGPR-pair operand (two taps of one pixel per instruction, two partial
+//     sums per pixel) - no LDS, no per-lane address arithmetic; 1428 packed FMAs per conv row of 17 pixels;
 //   * a wave walks down 17 conv rows of a 17-pixel-wide strip (16 + 1 halo each way for the pool), keeps the 17 accumulators of
 //     the current row in registers, folds bias / ReLU / the 3-wide column maximum and carries the 3-row maximum in 8 registers:
 //     the pool is register-local because a lane owns one channel; every pooled pixel leaves as one 256-byte row of 64 lanes.
@@ -49,9 +50,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __r
   const int n = b / strips;
   (void)Hc; (void)Wc;
 
-  float w[147];
+  // the lane's weights as 21 slices (ci, kh) of four register PAIRS (kw 0|1, 2|3, 4|5, 6|zero): one v_pk_fma_f32 multiplies two taps
+  // of one output pixel into two partial sums
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 w[21][4];
 #pragma unroll
-  for (int k = 0; k < 147; ++k) w[k] = Wt[k * 64 + lane];
+  for (int sl = 0; sl < 21; ++sl)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      w[sl][h][0] = Wt[(sl * 7 + 2 * h) * 64 + lane];
+      w[sl][h][1] = h < 3 ? Wt[(sl * 7 + 2 * h + 1) * 64 + lane] : 0.f;
+    }
   const float bs = bias[lane];
 
   // conv pixel i of the strip = conv column 16 strip - 1 + i; its taps are padded columns 32 strip + 2 i + kw (kw = 0..6)
@@ -68,26 +77,47 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __r
 #pragma unroll
       for (int j = 0; j < 8; ++j) cm[j] = 0.f;
     } else {
+      f32x2 acc2[17];
+#pragma unroll
+      for (int p = 0; p < 17; ++p) acc2[p] = f32x2{bs, 0.f};
+      // slice sl = (ci, kh): 40 wave-uniform floats (padded columns 32 strip .. + 39) in SGPRs, double buffered by hand - left to
+      // itself hipcc issues a slice's loads right in front of its FMAs and every slice eats a scalar-cache round trip
+      typedef float f32x16s __attribute__((ext_vector_type(16)));
+      typedef float f32x8s __attribute__((ext_vector_type(8)));
+      struct Slice { f32x16s a, b; f32x8s c; };
+      const float* row0 = img_n + (size_t)(2 * r + 2) * Wp;
+      auto slice_ptr = [&](int sl) { return row0 + ((size_t)(sl / 7) * Hp + (sl % 7)) * Wp; };
+      auto load_slice = [&](Slice& x, int sl) {
+        const float* q = slice_ptr(sl);
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80"
+                     : "=&s"(x.a), "=&s"(x.b), "=&s"(x.c) : "s"(q));
+      };
+      auto pair_of = [](const Slice& x, int j) -> f32x2 {          // padded columns 2 j, 2 j + 1
+        return j < 8 ? f32x2{x.a[2 * j], x.a[2 * j + 1]} : j < 16 ? f32x2{x.b[2 * j - 16], x.b[2 * j - 15]} : f32x2{x.c[2 * j - 32], x.c[2 * j - 31]};
+      };
+      auto fma_slice = [&](const Slice& x, int sl) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+          for (int p = 0; p < 17; ++p)                             // taps kw = 2 h, 2 h + 1 of pixel p: columns 2 p + 2 h, + 1 (column 39 only meets the zero weight)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[p]) : "s"(pair_of(x, p + h)), "v"(w[sl][h]));
+      };
+      Slice xa, xb;                                                // (scalar loads return out of order: only lgkmcnt(0) is a usable wait, so
+      load_slice(xa, 0);                                           //  the next slice is requested right behind the wait for the current one)
+#pragma unroll
+      for (int sl = 0; sl < 21; sl += 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sl + 1 < 21) load_slice(xb, sl + 1);
+        fma_slice(xa, sl);
+        if (sl + 1 < 21) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (sl + 2 < 21) load_slice(xa, sl + 2);
+          fma_slice(xb, sl + 1);
+        }
+      }
       float acc[17];
 #pragma unroll
-      for (int p = 0; p < 17; ++p) acc[p] = bs;
-#pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh) {
-          cfloat* xs = (cfloat*)(uintptr_t)(img_n + ((size_t)ci * Hp + (2 * r + 2 + kh)) * Wp);
-          float x[40];
-#pragma unroll
-          for (int j = 0; j < 40; ++j) x[j] = xs[j];
-#pragma unroll
-          for (int kw = 0; kw < 7; ++kw) {
-            const float wk = w[(ci * 7 + kh) * 7 + kw];
-#pragma unroll
-            for (int p = 0; p < 17; ++p) acc[p] = fmaf(x[2 * p + kw], wk, acc[p]);
-          }
-        }
-#pragma unroll
-      for (int p = 0; p < 17; ++p) acc[p] = fmaxf(acc[p], 0.f);
+      for (int p = 0; p < 17; ++p) acc[p] = fmaxf(acc2[p][0] + acc2[p][1], 0.f);
       if (strip == 0) acc[0] = 0.f;                                // conv column -1: pool padding
 #pragma unroll
       for (int j = 0; j < 8; ++j) cm[j] = fmaxf(fmaxf(acc[2 * j], acc[2 * j + 1]), acc[2 * j + 2]);

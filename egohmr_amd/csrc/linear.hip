@@ -354,6 +354,54 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   }
 }
 
+// Y[M,N] = act(X[M,K] . W[K,N] + bias) in exact float32 on the matrix cores (v_mfma_f32_32x32x2_f32) for SHORT M (a batch of feature
+// vectors): the conditioning projections of FusedSampler.prepare - the image / scene slices of the input graph conv
+// (modulated_gcn_conv.py:39-50 applied to the step-invariant features) and the beta head (egohmr.py:263-265).  The BLAS picked a
+// 256 x 256 macro-tile for M = 256, i.e. 4 - 8 workgroups and 170 - 450 us per GEMM.  Here one block owns a 32 x 32 output tile, its
+// four waves split K and reduce through LDS (deterministic, no atomics): 512 - 2048 blocks, a few microseconds.
+// A fragment: lane (row = l & 31, h = l >> 5) loads X[row][k + 4 h .. + 3]; MFMA i of an 8-k group contracts k + i and k + 4 + i.
+__global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                              float* __restrict__ Y, int M, int K, int N, int relu) {
+  __shared__ float red[3][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mi = lane & 31, h = lane >> 5;
+  const int n0 = 32 * blockIdx.x, m0 = 32 * blockIdx.y;
+  const int kq = K / 4, k_begin = wave * kq;
+  const int row = m0 + mi;
+  const bool row_ok = row < M;
+  const float* xa = X + (size_t)(row_ok ? row : 0) * K + k_begin + 4 * h;
+  const float* wb = W + (size_t)(k_begin + 4 * h) * N + n0 + mi;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8                                                   // 40 loads in flight per wave: the weights stream from HBM once
+  for (int k = 0; k < kq; k += 8) {
+    f32x4 a = *(const f32x4*)(xa + k);
+    if (!row_ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
+    float b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = wb[(size_t)(k + i) * N];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+  }
+  // accumulator layout: column = mi, row = (r & 3) + 8 (r >> 2) + 4 h
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][(r & 3) + 8 * (r >> 2) + 4 * h][mi] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float add = bias ? bias[n0 + mi] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = ((acc[r] + red[0][rr][mi]) + red[1][rr][mi]) + red[2][rr][mi] + add;
+      if (relu) v = fmaxf(v, 0.f);
+      if (m0 + rr < M) Y[(size_t)(m0 + rr) * N + n0 + mi] = v;
+    }
+  }
+}
+
 // relu(fc_pos(p)) in X2 format plus the raw points zero-padded to 32 columns (X2) for the folded stage-0 shortcut
 __global__ void pointnet_lift_kernel(const float* __restrict__ pts, const float* __restrict__ Wpos, const float* __restrict__ bpos,
                                      half_t* __restrict__ R0, half_t* __restrict__ P32, int B, int N, int Npad, int C) {
@@ -492,6 +540,18 @@ extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
   }
   if (d->relu_in0) hipLaunchKernelGGL(linear_tile_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(linear_tile_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_skinny_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int K, int N, int relu, void* stream) {
+  EHM_CHECK_ARG(X && W && Y && M > 0 && K > 0 && N > 0);
+  if (K % 32 != 0 || N % 32 != 0 || ((uintptr_t)X % 16) != 0) {
+    ehm_set_error("ehm_skinny_gemm_f32 needs K %% 32 == 0, N %% 32 == 0 and a 16-byte aligned X (K = %d, N = %d)", K, N);
+    return EHM_EINVAL;
+  }
+  hipLaunchKernelGGL(skinny_gemm_f32_kernel, dim3((unsigned)(N / 32), (unsigned)ceil_div(M, 32)), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, M,
+                     K, N, relu);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -236,8 +236,10 @@ class ResnetPointnet(nn.Module):
             W0, S = d(bl.fc_0.weight), d(bl.shortcut.weight)
             P[f"g1_{i}"] = self._pack(W0[:, :H], device)
             P[f"g3_{i}"] = self._pack(torch.cat([d(bl.fc_1.weight), S[:, :H]], dim=1), device) + (bl.fc_1.bias.detach().float().contiguous(),)
-            P[f"w0b_{i}"], P[f"b0_{i}"] = W0[:, H:].float().contiguous(), bl.fc_0.bias.detach().float()
-            P[f"sb_{i}"] = S[:, H:].float().contiguous()
+            # pooled halves: per-body bias vectors, [B,H] x [H,H] in exact float32 (ehm_skinny_gemm_f32 wants W as [K,N])
+            P[f"w0bT_{i}"], P[f"b0_{i}"] = W0[:, H:].t().float().contiguous().to(device), bl.fc_0.bias.detach().float().contiguous().to(device)
+            P[f"sbT_{i}"] = S[:, H:].t().float().contiguous().to(device)
+        P["fc_cT"], P["fc_cb"] = d(self.fc_c.weight).t().float().contiguous().to(device), self.fc_c.bias.detach().float().contiguous().to(device)
         self._packed, self._packed_key = P, key
         return P
 
@@ -267,6 +269,14 @@ class ResnetPointnet(nn.Module):
                                 relu_out=int(relu_out), w_scale=W[1])
             _lib.check(L.ehm_linear_split(d, st), "ehm_linear_split")
 
+        def small(x, Wt, bias):
+            """[B,K] x [K,N] (+ bias) in exact float32: the per-body vectors between the big GEMMs.  The BLAS ran each of these
+            256 x 256 x 256 products as one 256 x 256 workgroup (170 - 450 us, on the PointNet's critical path)."""
+            y = torch.empty(x.shape[0], Wt.shape[1], device=dev)
+            _lib.check(L.ehm_skinny_gemm_f32(x.contiguous().data_ptr(), Wt.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                             x.shape[0], Wt.shape[0], Wt.shape[1], 0, st), "ehm_skinny_gemm_f32")
+            return y
+
         neg_inf = float("-inf")
         # block_0 on net0 = fc_pos(p):  h = fc_0(relu(net0));  net1 = fc_1(relu(h)) + shortcut(net0)
         gemm(R0, 2 * H, None, 0, P["g1_0"], P["g1_0"][3], None, Hb, None, False, True)
@@ -274,11 +284,11 @@ class ResnetPointnet(nn.Module):
         gemm(Hb, H, P32, 32, P["g3_0"], P["g3_0"][3], None, netA, pooled, False, False)
         cur, nxt = netA, netB
         for i in (1, 2, 3):
-            v = (torch.relu(pooled) @ P[f"w0b_{i}"].t() + P[f"b0_{i}"]).contiguous()       # pooled half of fc_0(relu(cat[net, pooled]))
-            s = (pooled @ P[f"sb_{i}"].t()).contiguous()                                  # pooled half of shortcut(cat[net, pooled])
+            v = small(torch.relu(pooled), P[f"w0bT_{i}"], P[f"b0_{i}"])                    # pooled half of fc_0(relu(cat[net, pooled]))
+            s = small(pooled, P[f"sbT_{i}"], None)                                        # pooled half of shortcut(cat[net, pooled])
             gemm(cur, H, None, 0, P[f"g1_{i}"], None, v, Hb, None, True, True)
             pooled = torch.full((B, H), neg_inf, device=dev)
             gemm(Hb, H, cur, H, P[f"g3_{i}"], P[f"g3_{i}"][3], s, nxt if i < 3 else None, pooled, False, False)
             cur, nxt = nxt, cur
-        return self.fc_c(F.relu(pooled))
+        return small(F.relu(pooled), P["fc_cT"], P["fc_cb"])
 

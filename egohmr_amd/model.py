@@ -398,8 +398,17 @@ class FusedSampler:
             a, b, c, d = m.cond_split
             Wx = torch.einsum("ec,kef->kcf", Wp, W[:, b:c, :])                          # [2,6,hid]
             bx = torch.einsum("e,kef->kf", bp, W[:, b:c, :])                            # [2,hid]
+            # the image / scene+translation+camera slices as ONE [K, 2*hid] matrix each (both branches side by side, K padded to 32 with
+            # zero rows): operands of ehm_skinny_gemm_f32 in prepare()
+            hid = dm.hid_dim
+            Wd = gi.gconv.W.detach().float()
+            k_oth = (b - a + 31) // 32 * 32
+            W_img_cat = Wd[:, :a, :].permute(1, 0, 2).reshape(a, 2 * hid).contiguous()
+            W_oth_cat = torch.zeros(k_oth, 2 * hid, device=m.device)
+            W_oth_cat[:b - a] = Wd[:, a:b, :].permute(1, 0, 2).reshape(b - a, 2 * hid)
             self._folded = SimpleNamespace(Wx=Wx.float().contiguous(), bx=bx, W_img=gi.gconv.W.detach()[:, :a, :],
-                                           W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :])
+                                           W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :], W_img_cat=W_img_cat, W_oth_cat=W_oth_cat,
+                                           k_oth=k_oth)
         _lib.check(_lib.lib().ehm_gcn_set_uncond_mode(self._gcn, 0 if self.model.only_mask_img_cond else 1), "ehm_gcn_set_uncond_mode")
         mode = PRECISIONS[self.model.gcn_precision]
         if _lib.lib().ehm_gcn_get_precision(self._gcn) != mode:
@@ -477,9 +486,7 @@ class FusedSampler:
         other = torch.cat([scene_feats, transl_feat, cam], dim=1)                      # :220-221
         vis = m.visibility({"orig_keypoints_2d": batch["orig_keypoints_2d"].to(dev)})
         f = self._folded
-        h_img = torch.einsum("bi,kio->bko", img_feats, f.W_img).contiguous()           # [B,2,hid]
-        h_oth = torch.einsum("bi,kio->bko", other, f.W_oth).contiguous()
-        betas = m.beta_layer(torch.cat([img_feats, other], dim=1)).contiguous()        # :263-265
+        h_img, h_oth, betas = self._project(img_feats.contiguous(), other)
         self._prep = _Prepared(B=img_feats.shape[0], h_img=h_img, h_oth=h_oth, vis=vis.to(torch.uint8).contiguous(), vis_bool=vis,
                                betas=betas, scene=scene, transl=transl, fx=fx, cam_cx=cx, cam_cy=cy, img_feats=img_feats,
                                scene_feats=scene_feats)
@@ -491,6 +498,41 @@ class FusedSampler:
         self._prep.num_masked = int(self._prep.mask_items.numel())
         self._prep_key = key
         return self._prep
+
+    def _project(self, img_feats, other):
+        """The step-invariant slices of the input graph conv ([B,2,hid] each: image features, scene + translation + camera features)
+        and the beta head (egohmr.py:263-265) as exact-float32 matrix-core GEMMs built for M = B rows (ehm_skinny_gemm_f32)."""
+        m, f, L = self.model, self._folded, _lib.lib()
+        B, dev, hid = img_feats.shape[0], img_feats.device, m.diffusion_model.hid_dim
+        st = _lib.stream_ptr()
+        if img_feats.shape[1] % 32:
+            raise _lib.EgoHMRHipError(f"image feature width {img_feats.shape[1]} is not a multiple of 32")
+        oth = torch.zeros(B, f.k_oth, device=dev)
+        oth[:, :other.shape[1]] = other
+        h_img = torch.empty(B, 2, hid, device=dev)
+        h_oth = torch.empty(B, 2, hid, device=dev)
+        _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(img_feats), _lib.ptr(f.W_img_cat), None, _lib.ptr(h_img), B, img_feats.shape[1], 2 * hid, 0, st), "ehm_skinny_gemm_f32")
+        _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(oth), _lib.ptr(f.W_oth_cat), None, _lib.ptr(h_oth), B, f.k_oth, 2 * hid, 0, st), "ehm_skinny_gemm_f32")
+        # beta head: Linear(2048 + 646 -> 1024) + ReLU on the same kernel (weights transposed and padded once per weight version), the
+        # 1024 -> 10 layer and init_betas in torch
+        l1, l2 = m.beta_layer.layers[0], m.beta_layer.layers[2]
+        key = (l1.weight.data_ptr(), l1.weight._version, l1.bias.data_ptr(), l1.bias._version, str(dev))
+        if getattr(self, "_beta_key", None) != key:
+            a = img_feats.shape[1]
+            Wt = torch.zeros(a + f.k_oth, l1.out_features, device=dev)
+            w = l1.weight.detach().float().to(dev)
+            Wt[:a] = w[:, :a].t()
+            Wt[a:a + other.shape[1]] = w[:, a:].t()
+            self._beta_w1, self._beta_b1, self._beta_key = Wt.contiguous(), l1.bias.detach().float().to(dev).contiguous(), key
+        if l1.out_features % 32 == 0 and l1.in_features == img_feats.shape[1] + other.shape[1]:
+            xb = torch.cat([img_feats, oth], dim=1)
+            hb = torch.empty(B, l1.out_features, device=dev)
+            _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(xb), _lib.ptr(self._beta_w1), _lib.ptr(self._beta_b1), _lib.ptr(hb), B, xb.shape[1], l1.out_features, 1, st),
+                       "ehm_skinny_gemm_f32")
+            betas = (l2(hb) + m.beta_layer.init_betas).contiguous()
+        else:
+            betas = m.beta_layer(torch.cat([img_feats, other], dim=1)).contiguous()
+        return h_img, h_oth, betas
 
     def _cond_param_key(self):
         m = self.model

@@ -192,6 +192,12 @@ int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int K_padded, 
 int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
                       int C, void* stream);
 
+/* Y[M,N] = act(X[M,K] . W[K,N] + bias[N]) in exact float32 on the matrix cores, for short M (batches of feature vectors): the
+ * step-invariant slices of the input graph conv (models/egohmr/modulated_gcn/modulated_gcn_conv.py:39-50 on the image / scene
+ * features) and the beta head's first layer (models/egohmr/egohmr.py:263-265, fc_head_beta).  K % 32 == 0, N % 32 == 0, any M;
+ * X 16-byte aligned; bias may be NULL; relu != 0 applies max(., 0).  Deterministic (no atomics). */
+int ehm_skinny_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int K, int N, int relu, void* stream);
+
 /* In place y = act(y + bias[c] (+ residual)) over an NCHW float tensor (c = (i / HW) % C): the BatchNorm-folded bias,
  * the bottleneck's identity add and the ReLU of torchvision's ResNet-50 (`out = self.bn3(out); out += identity;
  * out = self.relu(out)`, used as EgoHMR's backbone at models/egohmr/egohmr.py:183) in ONE pass over the activation instead

@@ -368,6 +368,32 @@ def test_pointnet_vs_oracle(dev, model, synth_weights, B, N):
     assert err < 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 2048, 2048, False), (7, 672, 64, True), (33, 32, 32, False)])
+def test_skinny_gemm_f32_vs_torch_fp64(dev, shape):
+    """ehm_skinny_gemm_f32 (the conditioning projections of FusedSampler.prepare: modulated_gcn_conv.py:39-50 on the step-invariant
+    features, fc_head_beta egohmr.py:263-265) against torch float64; ragged M, bias + ReLU, smallest legal K / N."""
+    from egohmr_amd import _lib
+    M, K, N, act = shape
+    g = torch.Generator().manual_seed(3)
+    X, W, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = X.double() @ W.double() + (b.double() if act else 0)
+    if act:
+        ref = ref.clamp_min(0)
+    L = _lib.lib()
+    Xd, Wd, bd = X.to(dev), W.to(dev), b.to(dev)
+    Y = torch.full((M, N), float("nan"), device=dev)
+    _lib.check(L.ehm_skinny_gemm_f32(Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr() if act else None, Y.data_ptr(), M, K, N, int(act), None))
+    torch.cuda.synchronize()
+    err = (Y.cpu().double() - ref).abs().max().item()
+    print(f"[skinny gemm {shape}] max|err| vs fp64 = {err:.3e}")
+    assert err < 5e-6 * max(1.0, ref.abs().max().item())
+    Y2 = torch.empty_like(Y)
+    _lib.check(L.ehm_skinny_gemm_f32(Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr() if act else None, Y2.data_ptr(), M, K, N, int(act), None))
+    assert torch.equal(Y, Y2)                                                  # deterministic: no atomics
+    assert L.ehm_skinny_gemm_f32(Xd.data_ptr(), Wd.data_ptr(), None, Y.data_ptr(), M, 40, N, 0, None) != 0   # K % 32
+
+
 # --------------------------------------------------------------------------------------------- ResNet-50 backbone
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 96), (1, 32, 32)])

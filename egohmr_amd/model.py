@@ -215,9 +215,10 @@ class EgoHMR(nn.Module):
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
         # precision schedule: only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'),
-        # the earlier ones on plain f16 operands / f16 activations.  'auto' = max(10, ceil(T / 10)) (the last tenth of the schedule:
-        # errors of earlier steps are contracted away by the posterior mean, measured in tools/precision_schedule.py: final bodies
-        # within 7e-6 m of the all-f16x3 run at B=256 for DDPM-100 / DDIM-50; the parity bar is 1e-4 m); an int = that k; None = off
+        # the earlier ones on plain f16 operands / f16 activations.  'auto' = max(10, ceil(T / 10)) for T >= 20 (the last tenth of the
+        # schedule), ceil(T / 2) for 10 <= T < 20, off below (errors of earlier steps are contracted away by the posterior mean,
+        # measured in tools/precision_schedule.py: final bodies within 7e-6 m of the all-f16x3 run at B=256 for DDPM-100 / DDIM-50 /
+        # DDIM-10; the parity bar is 1e-4 m); an int = that k; None = off
         self.f16x3_last_steps = "auto"
         # hipGraph replay of the whole T-step loop (one graph launch instead of ~5 T kernel launches), unguided loops only.  Off by
         # default: measured on MI355X (tools/latency_small.py, profiles/r02_latency_b8_ddim5.json) the loop is GPU-bound even at B = 8
@@ -687,7 +688,9 @@ class FusedSampler:
         if k == "auto":
             if guided:
                 return 0
-            k = max(10, -(-T // 10))
+            if T < 10:
+                return 0                         # (not measured below ten steps)
+            k = max(10, -(-T // 10)) if T >= 20 else -(-T // 2)   # short loops: the last half (DDIM-10: k = 5 -> <= 4.6e-6 m, 3 seeds)
         return max(0, T - int(k))
 
     # ------------------------------------------------------------------ whole loop

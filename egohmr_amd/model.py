@@ -678,7 +678,7 @@ class FusedSampler:
             return 1.0
         return float(m.guide_denom_override) if m.guide_denom_override else float(B)
 
-    def lowprec_steps(self, T: int, guided: bool = False) -> int:
+    def lowprec_steps(self, T: int, guided: bool = False, ddim: bool = True) -> int:
         """How many LEADING steps of a T-step fused loop run on plain f16 operands (EgoHMR.f16x3_last_steps).  'auto' leaves
         collision-guided loops alone: the guidance feeds nearest-vertex switches back with gain, so the posterior mean no longer
         contracts the early steps' rounding away (an explicit int k still applies)."""
@@ -690,7 +690,12 @@ class FusedSampler:
                 return 0
             if T < 10:
                 return 0                         # (not measured below ten steps)
-            k = max(10, -(-T // 10)) if T >= 20 else -(-T // 2)   # short loops: the last half (DDIM-10: k = 5 -> <= 4.6e-6 m, 3 seeds)
+            if T < 20:
+                k = -(-T // 2)                   # short loops: the last half (DDIM-10: k = 5 -> <= 4.6e-6 m, 3 seeds x 2 respacings)
+            elif ddim:
+                k = max(10, -(-T // 10))         # DDIM-50: k = 10 -> 6.5e-6 m
+            else:
+                k = max(8, -(-2 * T // 25))      # ancestral sampling contracts harder: DDPM-100 k = 8 -> <= 3.9e-6 m over 4 seeds (k = 5: 7.4e-6)
         return max(0, T - int(k))
 
     # ------------------------------------------------------------------ whole loop
@@ -715,7 +720,7 @@ class FusedSampler:
         desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
                                guide_denom=self.guide_denom(B), tau=m.collision_tau, num_masked=num_masked,
-                               guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=self.lowprec_steps(T, any_guided))
+                               guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=self.lowprec_steps(T, any_guided, ddim))
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:
             raise _lib.EgoHMRHipError(f"ehm_sample_workspace_bytes rejected the descriptor (rc={nbytes})")

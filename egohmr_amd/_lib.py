@@ -69,6 +69,14 @@ class ConvDesc(C.Structure):
                 ("w_scale", C.c_float)]
 
 
+class ConvX2Desc(C.Structure):
+    """ehm_conv_x2_desc"""
+    _fields_ = [("x", C.c_void_p), ("x_rows", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
+                ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
+                ("w_scale", C.c_float)]
+
+
 class StepCoefs(C.Structure):
     """ehm_step_coefs"""
     _fields_ = [(n, C.c_float) for n in ("coef1", "coef2", "log_variance", "variance", "sqrt_recip_ac", "sqrt_recipm1_ac",
@@ -114,7 +122,10 @@ PROTOTYPES = {
     "ehm_bias_act": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "ehm_skinny_gemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_resnet_stem_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
-    "ehm_resnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ehm_resnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ehm_conv_x2_rows": (C.c_int64, [C.c_int64]),
+    "ehm_conv_x2": (_I, [C.POINTER(ConvX2Desc), _P]),
+    "ehm_x2_group_mean": (_I, [_P, _P, _I, _I, _I, _P]),
     "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
     "ehm_nonlocal_attention": (_I, [_P, _P, _L, _I, _P]),
     "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

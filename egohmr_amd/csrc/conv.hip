@@ -218,6 +218,321 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_split_kernel(ConvArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same convolution on activations that STAY in the X2 split format between the layers ([pixels][C], 128 bytes = 32 hi halves |
+// 32 lo halves per 32 channels; rows padded to the 192-row tile plus ONE all-zero row).  One K tile of the implicit GEMM =
+// (tap, 32-channel group) = exactly one 128-byte chunk of an input pixel, so the activation operand needs no registers at all: each
+// lane of a global_load_lds instruction points at its (output row, tap) pixel - or at the zero row when the tap falls outside the
+// image or the row is past M - and the DMA gathers the tile.  The float32 path above re-reads and re-SPLITS every input value once
+// per tap in the vector ALU.  Engine = linear.hip's linear_tile_kernel: persistent blocks, 192 x 128 tiles, next tile's DMA before
+// the epilogue, barrier-free epilogue through each wave's own pieces of stage 1, residual read and output written as X2 rows.
+constexpr int XBM = 192, XBN = 128, XRK = 32;
+constexpr int XA_T = XBM * XRK, XB_T = XBN * XRK, XSTG = XA_T + XB_T;   // floats; 40 KiB per stage
+
+struct ConvX2Args {
+  const float* x; const float* W; const float* bias; const char* res; char* y;   // x, W, res, y: X2 rows addressed as floats / bytes
+  int N, H, Wd, Ci, Ho, Wo, Co;
+  int KH, KW, stride, pad, relu;
+  float inv_scale;
+  long long M;
+  unsigned int zero_off;       // float offset of the all-zero row of x
+};
+
+struct XFrags {
+  half8 ah[3], al[3], bh[2], bl[2];
+};
+
+__global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 KiB; the ONLY LDS object
+
+  constexpr int KS = 2, NM = 18, NR = 10;
+  const int tid = threadIdx.x;
+  const int K = p.KH * p.KW * p.Ci;
+  const int cpt = p.Ci / XRK;                    // K tiles per tap
+  const int KT = p.KH * p.KW * cpt;
+  const int n_tiles = (p.Co + XBN - 1) / XBN;
+  const int m_tiles = (int)((p.M + XBM - 1) / XBM);
+
+  int lane, wave, wm, wn, mi, g, r0, swz;
+  int oA[KS][2], oB[KS][2];
+  auto thread_consts = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    lane = t & 63;
+    wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    wm = wave >> 1; wn = wave & 1;
+    mi = lane & 31; g = lane >> 5;
+    r0 = 8 * wave + (lane >> 3);
+    swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2;
+    const int rA = 96 * wm + mi, rB = 64 * wn + mi;
+    const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const int c = 4 * hl + 2 * s + g;
+        oA[s][hl] = rA * XRK + ((c ^ keyA) << 2);
+        oB[s][hl] = XA_T + rB * XRK + ((c ^ keyB) << 2);
+      }
+  };
+  thread_consts();
+
+  const int G = gridDim.x, b = blockIdx.x;
+  const bool xcd_order = (G % 8 == 0) && ((G / 8) % n_tiles == 0);
+  auto tile_of = [&](int it, int& m, int& n) -> bool {
+    if (xcd_order) {
+      const int x = b & 7, j = b >> 3, per = (G >> 3) / n_tiles;
+      m = (it * per + j / n_tiles) * 8 + x;
+      n = j % n_tiles;
+    } else {
+      const long long t = (long long)it * G + b;
+      m = (int)(t / n_tiles);
+      n = (int)(t % n_tiles);
+    }
+    return m < m_tiles;
+  };
+
+  // my six activation rows of the tile: float offset of the (kh = 0, kw = 0) tap pixel's channel 0 (+ my swizzled chunk) and the taps
+  // that lie inside the image
+  int pbase[6];
+  unsigned int pmask[6];
+  const float* pB;
+  const size_t brow32 = (size_t)32 * K;
+  auto set_tile = [&](int m, int n) {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const long long gm = (long long)m * XBM + r0 + 32 * i;
+      pmask[i] = 0u;
+      pbase[i] = 0;
+      if (gm < p.M) {
+        const int nimg = (int)(gm / hw), rem = (int)(gm % hw);
+        const int hi0 = (rem / p.Wo) * p.stride - p.pad, wi0 = (rem % p.Wo) * p.stride - p.pad;
+        pbase[i] = ((nimg * p.H + hi0) * p.Wd + wi0) * p.Ci + swz;
+        for (int kh = 0; kh < p.KH; ++kh)
+          for (int kw = 0; kw < p.KW; ++kw)
+            if (hi0 + kh >= 0 && hi0 + kh < p.H && wi0 + kw >= 0 && wi0 + kw < p.Wd) pmask[i] |= 1u << (kh * p.KW + kw);
+      }
+    }
+    pB = p.W + ((size_t)n * XBN + r0) * K + swz;
+  };
+  auto dma_a = [&](int buf, int kt, int i) {
+    const int tap = kt / cpt, cg = kt - tap * cpt;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int toff = (kh * p.Wd + kw) * p.Ci + cg * XRK;                       // (wave-uniform)
+    const unsigned int off = ((pmask[i] >> tap) & 1u) ? (unsigned int)(pbase[i] + toff) : p.zero_off + (unsigned int)swz;
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(p.x + off), (AS3 void*)(lds + buf * XSTG + (wave + 4 * i) * 256), 16, 0, 0);
+  };
+  auto dma_b = [&](int buf, int kt, int i) {
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * brow32 + (size_t)kt * XRK), (AS3 void*)(lds + buf * XSTG + XA_T + (wave + 4 * i) * 256), 16,
+                                     0, 0);
+  };
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
+  };
+  auto read_frags = [&](XFrags& f, int buf, int s) {
+    const float* S = lds + buf * XSTG;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      f.ah[t] = *(const half8*)(S + oA[s][0] + 32 * t * XRK);
+      f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * XRK);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f.bh[u] = *(const half8*)(S + oB[s][0] + 32 * u * XRK);
+      f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * XRK);
+    }
+  };
+  f32x16 acc[3][2];
+  auto mfmas = [&](const XFrags& f) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                             // small cross terms first, leading term last
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[u], acc[t][u], 0, 0, 0);
+      }
+  };
+  auto pin_reads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+  };
+  auto pin_reads_dma = [&]() {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+  };
+
+  int it = 0, m, n;
+  if (!tile_of(0, m, n)) return;
+  set_tile(m, n);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+
+  while (true) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // everything but stage 1's six activation pieces (the last instructions issued)
+    __syncthreads();
+    thread_consts();
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    XFrags f0, f1;
+    read_frags(f0, 0, 0);
+    auto first_phase = [&](int buf) {
+      read_frags(f1, buf, 1);
+      mfmas(f0);
+      pin_reads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    for (int kt = 0; kt < KT - 2; ++kt) {
+      const int buf = kt & 1;
+      first_phase(buf);
+      read_frags(f0, buf ^ 1, 0);
+      stage(buf, kt + 2);
+      mfmas(f1);
+      pin_reads_dma();
+    }
+    {
+      const int buf = (KT - 2) & 1;
+      first_phase(buf);
+      read_frags(f0, buf ^ 1, 0);
+      mfmas(f1);
+      pin_reads();
+    }
+    first_phase((KT - 1) & 1);
+
+    const int n0 = n * XBN;
+    const size_t row0 = (size_t)m * XBM;
+    const bool cols_live = n0 + 64 * wn < p.Co;                  // (Co = 64 layers: the upper column half of the 128-wide tile is padding)
+    float add[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + 64 * wn + 32 * u + mi;
+      add[u] = (p.bias && col < p.Co) ? p.bias[col] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f1);
+    int m_next, n_next;
+    const bool have_next = tile_of(it + 1, m_next, n_next);
+    if (have_next) {
+      set_tile(m_next, n_next);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+    }
+
+    if (cols_live) {
+      const unsigned int yrow = (unsigned int)p.Co * 4u;
+      const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(p.y + (row0 + 96 * wm) * (size_t)yrow);
+      const __amdgpu_buffer_rsrc_t rB = ehm_buffer_rsrc((p.res ? p.res : p.y) + (row0 + 96 * wm) * (size_t)yrow);
+      const bool relu = p.relu != 0, has_res = p.res != nullptr;
+      const int wbase = XSTG + wave * 256 + (4 * g) * 32 + mi;
+      const int rr = lane >> 3, oct = lane & 7;
+      const int rbase = XSTG + wave * 256 + (oct >> 2) * 1024 + rr * 32 + 8 * (oct & 3);
+      const int colw = n0 + 64 * wn + 8 * oct;
+      const unsigned int col_off = (unsigned int)(((colw >> 5) * 64 + (colw & 31)) * 2);
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        u32x4_t rq[3][2];
+        if (has_res) {
+#pragma unroll
+          for (int gi = 0; gi < 3; ++gi) {
+            const unsigned int vo = (unsigned int)(8 * (3 * ps + gi) + rr) * yrow + col_off;
+            rq[gi][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, 0, 0);
+            rq[gi][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo + 64u, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+          const int Gq = 3 * ps + gi, t = Gq >> 2, q = Gq & 3;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[wbase + (2 * gi + u) * 1024 + j * 32] = fmaf(acc[t][u][4 * q + j], p.inv_scale, add[u]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 tq[3][2];
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+          tq[gi][0] = *(const f32x4*)(lds + rbase + 2048 * gi);
+          tq[gi][1] = *(const f32x4*)(lds + rbase + 2048 * gi + 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+          float v[8] = {tq[gi][0][0], tq[gi][0][1], tq[gi][0][2], tq[gi][0][3], tq[gi][1][0], tq[gi][1][1], tq[gi][1][2], tq[gi][1][3]};
+          if (has_res) {
+            const half8 rh = __builtin_bit_cast(half8, rq[gi][0]), rl = __builtin_bit_cast(half8, rq[gi][1]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] += (float)rh[c] + (float)rl[c];
+          }
+          half8 hh, ll;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (relu) v[c] = fmaxf(v[c], 0.f);
+            hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
+            ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
+          }
+          const unsigned int vo = (unsigned int)(8 * (3 * ps + gi) + rr) * yrow + col_off;
+          if (colw < p.Co) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
+          }
+        }
+      }
+    }
+    if (!have_next) break;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+    m = m_next; n = n_next; ++it;
+  }
+}
+
+// X2 [rows, C] -> float32 mean over groups of `hw` consecutive rows: the global average pool behind the last bottleneck
+__global__ void x2_group_mean_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int hw, int C) {
+  const int img = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < hw; ++r) s += split_load<32>(X, (size_t)img * hw + r, c, C);
+    Y[(size_t)img * C + c] = s / (float)hw;
+  }
+}
+
 }  // namespace
 
 extern "C" int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream) {
@@ -236,6 +551,44 @@ extern "C" int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream) {
   const long long blocks = ceil_div(a.M, CBM) * ceil_div(d->Co, CBN);
   EHM_CHECK_ARG(blocks < (1ll << 31));
   hipLaunchKernelGGL(conv_nhwc_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t ehm_conv_x2_rows(int64_t pixels) { return round_up(pixels, XBM) + 1; }
+
+extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
+  EHM_CHECK_ARG(d && d->x && d->W && d->y);
+  EHM_CHECK_ARG(d->N > 0 && d->H > 0 && d->Wd > 0 && d->Ci > 0 && d->Co > 0 && d->Ci % XRK == 0 && d->Co % 32 == 0);
+  EHM_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 32 && (d->stride == 1 || d->stride == 2) && d->pad >= 0);
+  EHM_CHECK_ARG(d->w_scale > 0.f);
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Wd + 2 * d->pad - d->KW) / d->stride + 1;
+  EHM_CHECK_ARG(Ho > 0 && Wo > 0 && d->KH * d->KW * (d->Ci / XRK) >= 2);
+  const int64_t in_rows = (int64_t)d->N * d->H * d->Wd;
+  if (d->x_rows < ehm_conv_x2_rows(in_rows) || (ehm_conv_x2_rows(in_rows) * d->Ci) >= ((int64_t)1 << 31) ||
+      ehm_conv_x2_rows((int64_t)d->N * Ho * Wo) * d->Co >= ((int64_t)1 << 31)) {
+    ehm_set_error("ehm_conv_x2: x_rows = %lld, need ehm_conv_x2_rows(N*H*W) = %lld rows (tile padding + the zero row), and tensors below 2^31 elements",
+                  (long long)d->x_rows, (long long)ehm_conv_x2_rows(in_rows));
+    return EHM_EINVAL;
+  }
+  ConvX2Args a;
+  a.x = (const float*)d->x; a.W = (const float*)d->W; a.bias = d->bias; a.res = (const char*)d->residual; a.y = (char*)d->y;
+  a.N = d->N; a.H = d->H; a.Wd = d->Wd; a.Ci = d->Ci; a.Ho = Ho; a.Wo = Wo; a.Co = d->Co;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.relu = d->relu;
+  a.inv_scale = 1.f / d->w_scale;
+  a.M = (long long)d->N * Ho * Wo;
+  a.zero_off = (unsigned int)((d->x_rows - 1) * d->Ci);
+  const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(d->Co, XBN);
+  int64_t blocks = 2 * (int64_t)ehm_num_cus();
+  if (blocks > tiles) blocks = tiles;
+  hipLaunchKernelGGL(conv_x2_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, void* stream) {
+  EHM_CHECK_ARG(X && Y && groups > 0 && rows_per_group > 0 && C > 0 && C % 32 == 0);
+  hipLaunchKernelGGL(x2_group_mean_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, (const half_t*)X, Y, rows_per_group, C);
   EHM_LAUNCH_CHECK();
   return 0;
 }

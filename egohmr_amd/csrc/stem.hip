@@ -38,7 +38,7 @@ typedef const float __attribute__((address_space(4))) cfloat;
 // wave task = (image, strip of 16 conv columns, chunk of 16 conv rows); 4 tasks per block
 __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __restrict__ pad, const float* __restrict__ Wt,
                                                                  const float* __restrict__ bias, float* __restrict__ y, int H, int W,
-                                                                 int strips, int chunks, int tasks) {
+                                                                 int strips, int chunks, int tasks, int out_x2) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int Hc = H / 2, Wc = W / 2, Hq = H / 4, Wq = W / 4;      // conv / pooled extents
@@ -80,39 +80,46 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __r
       f32x2 acc2[17];
 #pragma unroll
       for (int p = 0; p < 17; ++p) acc2[p] = f32x2{bs, 0.f};
-      // slice sl = (ci, kh): 40 wave-uniform floats (padded columns 32 strip .. + 39) in SGPRs, double buffered by hand - left to
-      // itself hipcc issues a slice's loads right in front of its FMAs and every slice eats a scalar-cache round trip
-      typedef float f32x16s __attribute__((ext_vector_type(16)));
-      typedef float f32x8s __attribute__((ext_vector_type(8)));
-      struct Slice { f32x16s a, b; f32x8s c; };
+      // slice sl = (ci, kh): 40 wave-uniform floats (padded columns 32 strip .. + 39) in SGPR pairs, double buffered: the next slice is
+      // requested before the current one is multiplied and a scheduling barrier keeps it there (left alone, hipcc sinks every slice's
+      // loads down to its FMAs and each slice eats a scalar-cache round trip: 1.43 vs 1.14 ms).  The loads stay compiler-visible -
+      // its own lgkmcnt bookkeeping then also covers any SGPR it decides to spill (hand-written s_load + s_waitcnt asm did not: a spill
+      // of the not-yet-arrived registers corrupted pixels as soon as one more kernel argument raised the SGPR pressure).
+      typedef const f32x2 __attribute__((address_space(4))) cf32x2;
       const float* row0 = img_n + (size_t)(2 * r + 2) * Wp;
-      auto slice_ptr = [&](int sl) { return row0 + ((size_t)(sl / 7) * Hp + (sl % 7)) * Wp; };
-      auto load_slice = [&](Slice& x, int sl) {
-        const float* q = slice_ptr(sl);
-        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80"
-                     : "=&s"(x.a), "=&s"(x.b), "=&s"(x.c) : "s"(q));
+      auto load_slice = [&](f32x2 (&x)[20], int sl) {
+        cf32x2* q = (cf32x2*)(uintptr_t)(row0 + ((size_t)(sl / 7) * Hp + (sl % 7)) * Wp);
+#pragma unroll
+        for (int j = 0; j < 20; ++j) x[j] = q[j];
       };
-      auto pair_of = [](const Slice& x, int j) -> f32x2 {          // padded columns 2 j, 2 j + 1
-        return j < 8 ? f32x2{x.a[2 * j], x.a[2 * j + 1]} : j < 16 ? f32x2{x.b[2 * j - 16], x.b[2 * j - 15]} : f32x2{x.c[2 * j - 32], x.c[2 * j - 31]};
-      };
-      auto fma_slice = [&](const Slice& x, int sl) {
+      auto fma_slice = [&](const f32x2 (&x)[20], int sl, int first, int last) {   // FMAs number first .. last - 1 of the slice's 68
 #pragma unroll
         for (int h = 0; h < 4; ++h)
 #pragma unroll
           for (int p = 0; p < 17; ++p)                             // taps kw = 2 h, 2 h + 1 of pixel p: columns 2 p + 2 h, + 1 (column 39 only meets the zero weight)
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[p]) : "s"(pair_of(x, p + h)), "v"(w[sl][h]));
+            if (17 * h + p >= first && 17 * h + p < last)
+              asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[p]) : "s"(x[p + h]), "v"(w[sl][h]));
       };
-      Slice xa, xb;                                                // (scalar loads return out of order: only lgkmcnt(0) is a usable wait, so
-      load_slice(xa, 0);                                           //  the next slice is requested right behind the wait for the current one)
+      // Scalar loads return out of order, so every wait is lgkmcnt(0): the wait for slice k must come BEFORE slice k + 1 is requested
+      // or it waits for that one too.  Order per slice: first FMA of k (the compiler puts the wait in front of it), request k + 1,
+      // the other 67 FMAs.
+      f32x2 xa[20], xb[20];
+      load_slice(xa, 0);
 #pragma unroll
       for (int sl = 0; sl < 21; sl += 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        fma_slice(xa, sl, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (sl + 1 < 21) load_slice(xb, sl + 1);
-        fma_slice(xa, sl);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_slice(xa, sl, 1, 68);
         if (sl + 1 < 21) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          fma_slice(xb, sl + 1, 0, 1);
+          __builtin_amdgcn_sched_barrier(0);
           if (sl + 2 < 21) load_slice(xa, sl + 2);
-          fma_slice(xb, sl + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_slice(xb, sl + 1, 1, 68);
         }
       }
       float acc[17];
@@ -125,8 +132,19 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __r
     if ((i & 1) == 0) {                                            // row 2 j: closes pooled row j - 1, opens pooled row j
       if (i > 0) {
         float* dst = yrow + (size_t)(i / 2 - 1) * Wq * 64;
+        if (out_x2) {                                              // X2 rows for ehm_conv_x2: per 32 channels 32 hi halves | 32 lo halves
+          _Float16* d2 = (_Float16*)(dst - lane) + ((lane >> 5) * 64 + (lane & 31));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j * 64] = fmaxf(m[j], cm[j]);
+          for (int j = 0; j < 8; ++j) {
+            const float v = fmaxf(m[j], cm[j]);
+            const _Float16 hi = (_Float16)fminf(v, 65504.f);
+            d2[j * 128] = hi;
+            d2[j * 128 + 32] = (_Float16)(v - (float)hi);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dst[j * 64] = fmaxf(m[j], cm[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) m[j] = cm[j];
@@ -144,7 +162,7 @@ extern "C" size_t ehm_resnet_stem_scratch_bytes(int N, int H, int W) {
 }
 
 extern "C" int ehm_resnet_stem(const float* img, const float* Wt, const float* bias, float* scratch, float* y, int N, int H, int W,
-                               void* stream) {
+                               int out_x2, void* stream) {
   EHM_CHECK_ARG(img && Wt && bias && scratch && y && N > 0 && H > 0 && W > 0);
   if (H % 32 != 0 || W % 32 != 0) {
     ehm_set_error("ehm_resnet_stem needs H %% 32 == 0 and W %% 32 == 0 (got %d x %d)", H, W);
@@ -156,7 +174,7 @@ extern "C" int ehm_resnet_stem(const float* img, const float* Wt, const float* b
   EHM_LAUNCH_CHECK();
   const int strips = W / 32, chunks = H / 32, tasks = N * strips * chunks;
   hipLaunchKernelGGL(stem_conv_pool_kernel, dim3((unsigned)ceil_div(tasks, 4)), dim3(256), 0, st, scratch, Wt, bias, y, H, W, strips, chunks,
-                     tasks);
+                     tasks, out_x2);
   EHM_LAUNCH_CHECK();
   return 0;
 }

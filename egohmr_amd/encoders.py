@@ -60,7 +60,7 @@ class ResNet50Features(nn.Module):
     fold_batchnorm = True
 
     @torch.no_grad()
-    def folded(self, channels_last: bool = True, matrix_core: bool = True):
+    def folded(self, channels_last: bool = True, matrix_core: bool = True, x2_activations: bool = True):
         """Eval-mode equivalent with every BatchNorm2d folded into its convolution (w' = w * g/sqrt(v+eps),
         b' = beta - mean * g/sqrt(v+eps); exact up to float re-association) - removes 53 BatchNorm and most ReLU/add passes."""
         def fold(conv, bn):
@@ -145,22 +145,59 @@ class ResNet50Features(nn.Module):
         stem_wt = stem[0].reshape(64, 147).t().contiguous()                        # [147][64], k = (ci*7 + kh)*7 + kw
         stem_b = stem[1].contiguous()
 
-        def stem_mc(x):
-            """conv1 + bn1 + relu + maxpool in one pass, NCHW in -> NHWC out (csrc/stem.hip)"""
+        def x2_buffer(pixels, ch, dev):
+            """X2 activation matrix for ehm_conv_x2: pixels rounded up to the row tile + one all-zero row (out-of-image taps read it)"""
+            rows = int(_lib.lib().ehm_conv_x2_rows(pixels))
+            buf = torch.empty(rows, ch, device=dev)                                 # X2 rows have the byte size of float rows
+            buf[rows - 1].zero_()
+            return buf
+
+        def stem_mc(x, x2=False):
+            """conv1 + bn1 + relu + maxpool in one pass, NCHW in -> NHWC out (csrc/stem.hip); x2: output in the X2 split format"""
             N, _, H, W = x.shape
             lib = _lib.lib()
             if stem_wt.device != x.device:
                 raise _lib.EgoHMRHipError("ResNet50Features.folded(): weights and input live on different devices")
             scratch = torch.empty(lib.ehm_resnet_stem_scratch_bytes(N, H, W) // 4, device=x.device)
-            y = torch.empty(N, H // 4, W // 4, 64, device=x.device)
+            y = x2_buffer(N * (H // 4) * (W // 4), 64, x.device) if x2 else torch.empty(N, H // 4, W // 4, 64, device=x.device)
             _lib.check(lib.ehm_resnet_stem(x.data_ptr(), stem_wt.data_ptr(), stem_b.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W,
-                                           _lib.stream_ptr()), "ehm_resnet_stem")
+                                           1 if x2 else 0, _lib.stream_ptr()), "ehm_resnet_stem")
             return y
+
+        def conv_x2(x, shape, p, res=None, relu=True):
+            """one bottleneck conv on X2 activations (csrc/conv.hip conv_x2_tile_kernel); shape = (N, H, W) of x"""
+            buf, scale, bias, (Co, Ci, KH, KW), stride, pad = pack(p)
+            N, H, W = shape
+            Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+            y = x2_buffer(N * Ho * Wo, Co, x.device)
+            d = _lib.ConvX2Desc(x.data_ptr(), x.shape[0], buf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
+                                N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale)
+            _lib.check(_lib.lib().ehm_conv_x2(C.byref(d), _lib.stream_ptr()), "ehm_conv_x2")
+            return y, (N, Ho, Wo)
+
+        def run_x2(x):
+            """the whole trunk with the activations in the X2 split format between the layers (taps gathered by the LDS DMA)"""
+            N = x.shape[0]
+            x = stem_mc(x, x2=True)
+            shp = (N, x_shape_hw[0], x_shape_hw[1])
+            for c1, c2, c3, ds in blocks:
+                y, s1 = conv_x2(x, shp, c1)
+                y, s2 = conv_x2(y, s1, c2)
+                idn = x if ds is None else conv_x2(x, shp, ds, relu=False)[0]
+                x, shp = conv_x2(y, s2, c3, res=idn)
+            out = torch.empty(N, x.shape[1], device=x.device)
+            _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], _lib.stream_ptr()), "ehm_x2_group_mean")
+            return out
+
+        x_shape_hw = [0, 0]
 
         def run_mc(x):
             x = _lib.f32(x)
             if x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:               # (the reference always feeds 224 x 224 crops)
                 x = F.max_pool2d(cba(x.contiguous(), stem), 3, stride=2, padding=1).permute(0, 2, 3, 1).contiguous()
+            elif x2_activations:
+                x_shape_hw[0], x_shape_hw[1] = x.shape[2] // 4, x.shape[3] // 4
+                return run_x2(x)
             else:
                 x = stem_mc(x)                                                      # NHWC from here on
             for c1, c2, c3, ds in blocks:

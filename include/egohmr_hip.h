@@ -208,10 +208,11 @@ int ehm_bias_act(float* y, const float* bias, const float* residual, int64_t n, 
  * models/egohmr/egohmr.py:183): conv 7x7 stride 2 pad 3 (3 -> 64) + bias + ReLU + max-pool 3x3 stride 2 pad 1.
  *   img [N,3,H,W] float32 (NCHW), H % 32 == 0, W % 32 == 0;   y [N,H/4,W/4,64] float32 (NHWC)
  *   Wt [147][64]: the BatchNorm-folded weights transposed, row k = (ci*7 + kh)*7 + kw;   bias [64]
- *   scratch: ehm_resnet_stem_scratch_bytes(N,H,W) bytes of device memory (zero-padded copy of the image) */
+ *   scratch: ehm_resnet_stem_scratch_bytes(N,H,W) bytes of device memory (zero-padded copy of the image)
+ *   out_x2 != 0: y is written in the X2 split format instead (same byte size; the input format of ehm_conv_x2) */
 size_t ehm_resnet_stem_scratch_bytes(int N, int H, int W);
 int ehm_resnet_stem(const float* img, const float* Wt, const float* bias, float* scratch, float* y, int N, int H, int W,
-                    void* stream);
+                    int out_x2, void* stream);
 
 /* NHWC convolution + bias (+ identity) + ReLU as an implicit GEMM on the f16 matrix cores with f32-grade accuracy (hi/lo split
  * operands, f32 accumulate): y[n,ho,wo,co] = act(sum x[n, ho*s-p+kh, wo*s-p+kw, ci] w[co,kh,kw,ci] + bias[co] (+ residual)).
@@ -227,6 +228,23 @@ typedef struct ehm_conv_desc {
   float w_scale;
 } ehm_conv_desc;
 int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream);
+
+/* The same convolution with the activations kept in the X2 split format between the layers (the ResNet-50 trunk of
+ * models/resnet.py:139-150 / models/egohmr/egohmr.py:183 end to end): x, residual, y are X2 [rows, C] matrices (ehm_split_pack layout,
+ * pixel-major NHWC) whose row count is ehm_conv_x2_rows(N*H*W) = pixels rounded up to the 192-row tile + ONE extra row; the LAST
+ * row of x must be all zero (out-of-image taps read it).  Ci % 32 == 0, Co % 32 == 0, KH*KW*Ci >= 64; W, bias, relu, w_scale as
+ * in ehm_conv_desc.  y's padding rows receive don't-care values; its zero row is the caller's to clear. */
+typedef struct ehm_conv_x2_desc {
+  const void* x; int64_t x_rows; const void* W; const float* bias; const void* residual; void* y;
+  int N, H, Wd, Ci, Co;
+  int KH, KW, stride, pad, relu;
+  float w_scale;
+} ehm_conv_x2_desc;
+int64_t ehm_conv_x2_rows(int64_t pixels);
+int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream);
+/* Y[g, c] = mean over the rows_per_group consecutive rows of group g of the X2 matrix X [groups*rows_per_group (+ padding), C]:
+ * the global average pool behind the last bottleneck (models/resnet.py:148-149). */
+int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, void* stream);
 
 /* Attention core of the optional non-local block of ModulatedGCN (nonlocal_layer=True, modulated_gcn.py:93-110;
  * nets/non_local_embedded_gaussian.py:68-79): per body, y = softmax(theta phi^T, dim=-1) g over the 24 joints.

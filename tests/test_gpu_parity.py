@@ -413,17 +413,17 @@ def test_resnet_stem_vs_torch_fp64(dev, shape):
     x, wt, bd = img.to(dev), w.reshape(64, 147).t().contiguous().to(dev), b.to(dev)
     scratch = torch.empty(L.ehm_resnet_stem_scratch_bytes(N, H, W) // 4, device=dev)
     y = torch.full((N, H // 4, W // 4, 64), float("nan"), device=dev)
-    _lib.check(L.ehm_resnet_stem(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W, None))
+    _lib.check(L.ehm_resnet_stem(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W, 0, None))
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item()
     print(f"[stem {shape}] max|err| vs fp64 = {err:.3e} (|y|max = {ref.abs().max().item():.2f})")
     assert err < 2e-5
-    assert L.ehm_resnet_stem(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, 48, W, None) != 0   # H % 32
+    assert L.ehm_resnet_stem(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, 48, W, 0, None) != 0   # H % 32
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("matrix_core", [True, False])
-def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, matrix_core):
+@pytest.mark.parametrize("mode", ["x2", "f32act", "library"])
+def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, mode):
     """The BatchNorm-folded backbone (split-f16 implicit-GEMM convs of csrc/conv.hip, or library convs + ehm_bias_act) against the
     reference's own ResNet-50 output (G6, generated by oracle/make_golden.py from models/egohmr/egohmr.py's backbone)."""
     from egohmr_amd import synthetic as syn
@@ -433,15 +433,17 @@ def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, matrix_core):
     net = ResNet50Features()
     net.load_state_dict({k[len("backbone."):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if k.startswith("backbone.")})
     net = net.to(dev).eval()
+    # x2: activations in the split format between the layers (conv_x2_tile_kernel); f32act: float32 activations (conv_nhwc_split_kernel)
+    kw = {"x2": dict(matrix_core=True, x2_activations=True), "f32act": dict(matrix_core=True, x2_activations=False), "library": dict(matrix_core=False)}[mode]
     rng = np.random.Generator(np.random.PCG64(int(g["img_seed"])))
     rng.uniform(-1, 1, size=(2, 257, 3))          # same stream position as the generator script
     img = torch.from_numpy(rng.normal(size=(2, 3, 224, 224)).astype(np.float32)).to(dev)
     with torch.no_grad():
-        out = net.folded(channels_last=False, matrix_core=matrix_core)(img)
+        out = net.folded(channels_last=False, **kw)(img)
     np.testing.assert_allclose(out.cpu().numpy(), g["feat"], atol=3e-5)
     # ragged row count (M = 3*56*56 ... 3*7*7 is not a multiple of the 128-row tile) and batch consistency
     img3 = torch.cat([img, img[:1]], 0)
     with torch.no_grad():
-        out3 = net.folded(channels_last=False, matrix_core=matrix_core)(img3)
+        out3 = net.folded(channels_last=False, **kw)(img3)
     np.testing.assert_allclose(out3[:2].cpu().numpy(), out.cpu().numpy(), atol=5e-6)   # the library convs pick batch-dependent algorithms
     np.testing.assert_allclose(out3[2].cpu().numpy(), out[0].cpu().numpy(), atol=5e-6)

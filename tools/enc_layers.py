@@ -13,6 +13,7 @@ from egohmr_amd import _lib  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+X2 = (sys.argv[3] if len(sys.argv) > 3 else "x2") == "x2"      # x2: activations in the split format (conv_x2_tile_kernel); f32: conv_nhwc_split_kernel
 dev = torch.device("cuda:0")
 L = _lib.lib()
 
@@ -36,12 +37,12 @@ wt, bs = torch.randn(147, 64, device=dev) * 0.05, torch.zeros(64, device=dev)
 scr = torch.empty(L.ehm_resnet_stem_scratch_bytes(B, 224, 224) // 4, device=dev)
 ys = torch.empty(B, 56, 56, 64, device=dev)
 for _ in range(2):
-    _lib.check(L.ehm_resnet_stem(img.data_ptr(), wt.data_ptr(), bs.data_ptr(), scr.data_ptr(), ys.data_ptr(), B, 224, 224, None))
+    _lib.check(L.ehm_resnet_stem(img.data_ptr(), wt.data_ptr(), bs.data_ptr(), scr.data_ptr(), ys.data_ptr(), B, 224, 224, 0, None))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    _lib.check(L.ehm_resnet_stem(img.data_ptr(), wt.data_ptr(), bs.data_ptr(), scr.data_ptr(), ys.data_ptr(), B, 224, 224, None))
+    _lib.check(L.ehm_resnet_stem(img.data_ptr(), wt.data_ptr(), bs.data_ptr(), scr.data_ptr(), ys.data_ptr(), B, 224, 224, 0, None))
 e1.record()
 torch.cuda.synchronize()
 print(f"stem (pad + conv7x7 + ReLU + max-pool): {e0.elapsed_time(e1) / reps:.3f} ms  (VALU floor 2.1 M cycles/SIMD = 0.87 ms at 2.4 GHz)")
@@ -52,24 +53,39 @@ rows = []
 for name, Hin, Ci, Co, k, s, has_res in convs:
     pad = k // 2
     Ho = (Hin + 2 * pad - k) // s + 1
-    x = torch.randn(B, Hin, Hin, Ci, device=dev)
     K = k * k * Ci
     Co_pad = (Co + 127) // 128 * 128
     w = torch.randn(Co_pad, K, device=dev) * 0.02
     buf = torch.empty(Co_pad, K, device=dev)
     _lib.check(L.ehm_split_pack(w.data_ptr(), buf.data_ptr(), Co_pad, K, K, 1024.0, None))
     bias = torch.zeros(Co, device=dev)
-    res = torch.randn(B, Ho, Ho, Co, device=dev) if has_res else None
-    y = torch.empty(B, Ho, Ho, Co, device=dev)
-    d = _lib.ConvDesc(x.data_ptr(), buf.data_ptr(), bias.data_ptr(), res.data_ptr() if has_res else None, y.data_ptr(),
-                      B, Hin, Hin, Ci, Co, k, k, s, pad, 1, 1024.0)
+    if X2:
+        rin, rout = int(L.ehm_conv_x2_rows(B * Hin * Hin)), int(L.ehm_conv_x2_rows(B * Ho * Ho))
+        def x2_random(rows, ch):
+            src, dst = torch.randn(rows, ch, device=dev), torch.empty(rows, ch, device=dev)
+            src[rows - 1].zero_()
+            _lib.check(L.ehm_split_pack(src.data_ptr(), dst.data_ptr(), rows, ch, ch, 1.0, None))
+            return dst
+        x = x2_random(rin, Ci)
+        res = x2_random(rout, Co) if has_res else None
+        y = torch.empty(rout, Co, device=dev)
+        d = _lib.ConvX2Desc(x.data_ptr(), rin, buf.data_ptr(), bias.data_ptr(), res.data_ptr() if has_res else None, y.data_ptr(),
+                            B, Hin, Hin, Ci, Co, k, k, s, pad, 1, 1024.0)
+        call = lambda: _lib.check(L.ehm_conv_x2(C.byref(d), None))
+    else:
+        x = torch.randn(B, Hin, Hin, Ci, device=dev)
+        res = torch.randn(B, Ho, Ho, Co, device=dev) if has_res else None
+        y = torch.empty(B, Ho, Ho, Co, device=dev)
+        d = _lib.ConvDesc(x.data_ptr(), buf.data_ptr(), bias.data_ptr(), res.data_ptr() if has_res else None, y.data_ptr(),
+                          B, Hin, Hin, Ci, Co, k, k, s, pad, 1, 1024.0)
+        call = lambda: _lib.check(L.ehm_conv_nhwc_split(C.byref(d), None))
     for _ in range(2):
-        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), None))
+        call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), None))
+        call()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

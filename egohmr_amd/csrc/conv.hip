@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_split_kernel(ConvArgs p) {
 // image or the row is past M - and the DMA gathers the tile.  The float32 path above re-reads and re-SPLITS every input value once
 // per tap in the vector ALU.  Engine = linear.hip's linear_tile_kernel: persistent blocks, 192 x 128 tiles, next tile's DMA before
 // the epilogue, barrier-free epilogue through each wave's own pieces of stage 1, residual read and output written as X2 rows.
-constexpr int XBM = 192, XBN = 128, XRK = 32;
-constexpr int XA_T = XBM * XRK, XB_T = XBN * XRK, XSTG = XA_T + XB_T;   // floats; 40 KiB per stage
+constexpr int XBM = 192, XRK = 32;
+constexpr int XA_T = XBM * XRK;                                          // floats of a stage's activation region (24 KiB)
+constexpr int x_stage_floats(int nu) { return XA_T + 64 * nu * XRK; }    // + 8 KiB of weights per 64 output channels
 
 struct ConvX2Args {
   const float* x; const float* W; const float* bias; const char* res; char* y;   // x, W, res, y: X2 rows addressed as floats / bytes
@@ -239,14 +240,19 @@ struct ConvX2Args {
   unsigned int zero_off;       // float offset of the all-zero row of x
 };
 
+template <int NU>
 struct XFrags {
-  half8 ah[3], al[3], bh[2], bl[2];
+  half8 ah[3], al[3], bh[NU], bl[NU];
 };
 
+// NU = 2: 192 x 128 tiles (96 x 64 per wave); NU = 1: 192 x 64 tiles (96 x 32 per wave) for Co = 64 layers (no padding columns through
+// the matrix cores).
+template <int NU>
 __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 KiB; the ONLY LDS object
+  constexpr int XBN = 64 * NU, XSTG = x_stage_floats(NU);
+  __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 / 64 KiB; the ONLY LDS object
 
-  constexpr int KS = 2, NM = 18, NR = 10;
+  constexpr int KS = 2, NM = 9 * NU, NR = 6 + 2 * NU, NBD = 2 * NU;
   const int tid = threadIdx.x;
   const int K = p.KH * p.KW * p.Ci;
   const int cpt = p.Ci / XRK;                    // K tiles per tap
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     mi = lane & 31; g = lane >> 5;
     r0 = 8 * wave + (lane >> 3);
     swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2;
-    const int rA = 96 * wm + mi, rB = 64 * wn + mi;
+    const int rA = 96 * wm + mi, rB = 32 * NU * wn + mi;
     const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -332,27 +338,27 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
+    for (int i = 0; i < NBD; ++i) dma_b(buf, kt, i);
   };
-  auto read_frags = [&](XFrags& f, int buf, int s) {
+  auto read_frags = [&](XFrags<NU>& f, int buf, int s) {
     const float* S = lds + buf * XSTG;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       f.ah[t] = *(const half8*)(S + oA[s][0] + 32 * t * XRK);
       f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * XRK);
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
+ #pragma unroll
+    for (int u = 0; u < NU; ++u) {
       f.bh[u] = *(const half8*)(S + oB[s][0] + 32 * u * XRK);
       f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * XRK);
     }
   };
-  f32x16 acc[3][2];
-  auto mfmas = [&](const XFrags& f) {
+  f32x16 acc[3][NU];
+  auto mfmas = [&](const XFrags<NU>& f) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {                             // small cross terms first, leading term last
+      for (int u = 0; u < NU; ++u) {                             // small cross terms first, leading term last
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[u], acc[t][u], 0, 0, 0);
@@ -367,30 +373,42 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
   };
   auto pin_reads_dma = [&]() {
+    if constexpr (NU == 2) {                                      // 18 MFMAs, 10 reads, 10 DMAs
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
+      for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
-    }
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+      }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    } else {                                                      // 9 MFMAs, 8 reads, 8 DMAs
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
   };
 
+  if (blockIdx.x == 0)                                           // the output's own all-zero row (the next conv's out-of-image taps)
+    for (int c = tid; c < p.Co; c += 256) ((float*)p.y)[(size_t)m_tiles * XBM * p.Co + c] = 0.f;
   int it = 0, m, n;
   if (!tile_of(0, m, n)) return;
   set_tile(m, n);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+  for (int i = 0; i < NBD; ++i) dma_b(0, 0, i);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+  for (int i = 0; i < NBD; ++i) dma_b(1, 1, i);
 #pragma unroll
   for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
 #pragma unroll
@@ -403,10 +421,10 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-    XFrags f0, f1;
+    XFrags<NU> f0, f1;
     read_frags(f0, 0, 0);
     auto first_phase = [&](int buf) {
       read_frags(f1, buf, 1);
@@ -434,11 +452,11 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 
     const int n0 = n * XBN;
     const size_t row0 = (size_t)m * XBM;
-    const bool cols_live = n0 + 64 * wn < p.Co;                  // (Co = 64 layers: the upper column half of the 128-wide tile is padding)
-    float add[2];
+    const bool cols_live = n0 + 32 * NU * wn < p.Co;             // (NU = 2 with Co = 64: the upper column half of the tile is padding)
+    float add[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int col = n0 + 64 * wn + 32 * u + mi;
+    for (int u = 0; u < NU; ++u) {
+      const int col = n0 + 32 * NU * wn + 32 * u + mi;
       add[u] = (p.bias && col < p.Co) ? p.bias[col] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -448,56 +466,70 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     if (have_next) {
       set_tile(m_next, n_next);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+      for (int i = 0; i < NBD; ++i) dma_b(0, 0, i);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+      for (int i = 0; i < NBD; ++i) dma_b(1, 1, i);
 #pragma unroll
       for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
     }
 
+    // Epilogue per wave through its six 1 KiB pieces of stage 1's activation region.  Accumulator register r of acc[t][u] is row
+    // 32 t + 8 (r >> 2) + 4 g + (r & 3): row groups Gq = 4 t + (r >> 2) of 8 rows.  NU = 2: a pass turns 3 groups x 64 columns (piece
+    // 2 gi + u), 4 passes; NU = 1: 6 groups x 32 columns (piece gi), 2 passes.  Read items = (row, 8 columns), three per lane.
     if (cols_live) {
+      constexpr int GP = NU == 2 ? 3 : 6, NPASS = 12 / GP;       // row groups per pass
       const unsigned int yrow = (unsigned int)p.Co * 4u;
       const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(p.y + (row0 + 96 * wm) * (size_t)yrow);
       const __amdgpu_buffer_rsrc_t rB = ehm_buffer_rsrc((p.res ? p.res : p.y) + (row0 + 96 * wm) * (size_t)yrow);
       const bool relu = p.relu != 0, has_res = p.res != nullptr;
       const int wbase = XSTG + wave * 256 + (4 * g) * 32 + mi;
-      const int rr = lane >> 3, oct = lane & 7;
-      const int rbase = XSTG + wave * 256 + (oct >> 2) * 1024 + rr * 32 + 8 * (oct & 3);
-      const int colw = n0 + 64 * wn + 8 * oct;
+      int rbase, colw, irow;                                     // LDS offset of my item 0, its first column, its row inside the pass
+      if constexpr (NU == 2) {
+        const int rr = lane >> 3, oct = lane & 7;               // item it = group it: row rr, columns 8 oct .. + 7 of 64
+        rbase = XSTG + wave * 256 + (oct >> 2) * 1024 + rr * 32 + 8 * (oct & 3);
+        colw = n0 + 64 * wn + 8 * oct;
+        irow = rr;
+      } else {
+        const int lr = lane >> 2;                                // item it: row 16 it + lr of the pass's 48, columns 8 (lane & 3) .. + 7 of 32
+        rbase = XSTG + wave * 256 + (lr >> 3) * 1024 + (lr & 7) * 32 + 8 * (lane & 3);
+        colw = n0 + 32 * wn + 8 * (lane & 3);
+        irow = lr;
+      }
+      constexpr int ISTEP = NU == 2 ? 8 : 16;                    // rows between my consecutive items
       const unsigned int col_off = (unsigned int)(((colw >> 5) * 64 + (colw & 31)) * 2);
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
+      for (int ps = 0; ps < NPASS; ++ps) {
         u32x4_t rq[3][2];
         if (has_res) {
 #pragma unroll
-          for (int gi = 0; gi < 3; ++gi) {
-            const unsigned int vo = (unsigned int)(8 * (3 * ps + gi) + rr) * yrow + col_off;
-            rq[gi][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, 0, 0);
-            rq[gi][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo + 64u, 0, 0);
+          for (int it3 = 0; it3 < 3; ++it3) {
+            const unsigned int vo = (unsigned int)(8 * GP * ps + ISTEP * it3 + irow) * yrow + col_off;
+            rq[it3][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, 0, 0);
+            rq[it3][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo + 64u, 0, 0);
           }
         }
 #pragma unroll
-        for (int gi = 0; gi < 3; ++gi) {
-          const int Gq = 3 * ps + gi, t = Gq >> 2, q = Gq & 3;
+        for (int gi = 0; gi < GP; ++gi) {
+          const int Gq = GP * ps + gi, t = Gq >> 2, q = Gq & 3;
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lds[wbase + (2 * gi + u) * 1024 + j * 32] = fmaf(acc[t][u][4 * q + j], p.inv_scale, add[u]);
+            for (int j = 0; j < 4; ++j) lds[wbase + (NU * gi + u) * 1024 + j * 32] = fmaf(acc[t][u][4 * q + j], p.inv_scale, add[u]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         f32x4 tq[3][2];
 #pragma unroll
-        for (int gi = 0; gi < 3; ++gi) {
-          tq[gi][0] = *(const f32x4*)(lds + rbase + 2048 * gi);
-          tq[gi][1] = *(const f32x4*)(lds + rbase + 2048 * gi + 4);
+        for (int it3 = 0; it3 < 3; ++it3) {
+          tq[it3][0] = *(const f32x4*)(lds + rbase + 2048 * it3);
+          tq[it3][1] = *(const f32x4*)(lds + rbase + 2048 * it3 + 4);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int gi = 0; gi < 3; ++gi) {
-          float v[8] = {tq[gi][0][0], tq[gi][0][1], tq[gi][0][2], tq[gi][0][3], tq[gi][1][0], tq[gi][1][1], tq[gi][1][2], tq[gi][1][3]};
+        for (int it3 = 0; it3 < 3; ++it3) {
+          float v[8] = {tq[it3][0][0], tq[it3][0][1], tq[it3][0][2], tq[it3][0][3], tq[it3][1][0], tq[it3][1][1], tq[it3][1][2], tq[it3][1][3]};
           if (has_res) {
-            const half8 rh = __builtin_bit_cast(half8, rq[gi][0]), rl = __builtin_bit_cast(half8, rq[gi][1]);
+            const half8 rh = __builtin_bit_cast(half8, rq[it3][0]), rl = __builtin_bit_cast(half8, rq[it3][1]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] += (float)rh[c] + (float)rl[c];
           }
@@ -508,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
             hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
             ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
           }
-          const unsigned int vo = (unsigned int)(8 * (3 * ps + gi) + rr) * yrow + col_off;
+          const unsigned int vo = (unsigned int)(8 * GP * ps + ISTEP * it3 + irow) * yrow + col_off;
           if (colw < p.Co) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
@@ -578,10 +610,15 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   a.inv_scale = 1.f / d->w_scale;
   a.M = (long long)d->N * Ho * Wo;
   a.zero_off = (unsigned int)((d->x_rows - 1) * d->Ci);
-  const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(d->Co, XBN);
-  int64_t blocks = 2 * (int64_t)ehm_num_cus();
-  if (blocks > tiles) blocks = tiles;
-  hipLaunchKernelGGL(conv_x2_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  // 64-wide column tiles only when Co is not a multiple of 128 (Co = 64: no padding columns through the matrix cores; 0.42 -> 0.29 ms
+  // on the 3x3 convs of layer 1).  For layer 4's 264-tile convs they LOSE although they would give every CU two blocks (0.26 ->
+  // 0.31 ms): a 96 x 32 wave tile reads 8 fragments per 9 MFMAs.
+  const int64_t slots = 2 * (int64_t)ehm_num_cus();
+  const bool narrow = d->Co % 128 != 0;
+  const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(d->Co, narrow ? 64 : 128);
+  const int64_t blocks = tiles < slots ? tiles : slots;
+  if (narrow) hipLaunchKernelGGL(conv_x2_tile_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_x2_tile_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -145,11 +145,13 @@ class ResNet50Features(nn.Module):
         stem_wt = stem[0].reshape(64, 147).t().contiguous()                        # [147][64], k = (ci*7 + kh)*7 + kw
         stem_b = stem[1].contiguous()
 
-        def x2_buffer(pixels, ch, dev):
-            """X2 activation matrix for ehm_conv_x2: pixels rounded up to the row tile + one all-zero row (out-of-image taps read it)"""
+        def x2_buffer(pixels, ch, dev, clear_last=False):
+            """X2 activation matrix for ehm_conv_x2: pixels rounded up to the row tile + one all-zero row (out-of-image taps read it;
+            ehm_conv_x2 clears it in its output, the stem's buffer is cleared here)"""
             rows = int(_lib.lib().ehm_conv_x2_rows(pixels))
             buf = torch.empty(rows, ch, device=dev)                                 # X2 rows have the byte size of float rows
-            buf[rows - 1].zero_()
+            if clear_last:
+                buf[rows - 1].zero_()
             return buf
 
         def stem_mc(x, x2=False):
@@ -159,7 +161,7 @@ class ResNet50Features(nn.Module):
             if stem_wt.device != x.device:
                 raise _lib.EgoHMRHipError("ResNet50Features.folded(): weights and input live on different devices")
             scratch = torch.empty(lib.ehm_resnet_stem_scratch_bytes(N, H, W) // 4, device=x.device)
-            y = x2_buffer(N * (H // 4) * (W // 4), 64, x.device) if x2 else torch.empty(N, H // 4, W // 4, 64, device=x.device)
+            y = x2_buffer(N * (H // 4) * (W // 4), 64, x.device, clear_last=True) if x2 else torch.empty(N, H // 4, W // 4, 64, device=x.device)
             _lib.check(lib.ehm_resnet_stem(x.data_ptr(), stem_wt.data_ptr(), stem_b.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W,
                                            1 if x2 else 0, _lib.stream_ptr()), "ehm_resnet_stem")
             return y

@@ -233,7 +233,7 @@ int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream);
  * models/resnet.py:139-150 / models/egohmr/egohmr.py:183 end to end): x, residual, y are X2 [rows, C] matrices (ehm_split_pack layout,
  * pixel-major NHWC) whose row count is ehm_conv_x2_rows(N*H*W) = pixels rounded up to the 192-row tile + ONE extra row; the LAST
  * row of x must be all zero (out-of-image taps read it).  Ci % 32 == 0, Co % 32 == 0, KH*KW*Ci >= 64; W, bias, relu, w_scale as
- * in ehm_conv_desc.  y's padding rows receive don't-care values; its zero row is the caller's to clear. */
+ * in ehm_conv_desc.  y's padding rows receive don't-care values; its last row is cleared by the call. */
 typedef struct ehm_conv_x2_desc {
   const void* x; int64_t x_rows; const void* W; const float* bias; const void* residual; void* y;
   int N, H, Wd, Ci, Co;

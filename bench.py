@@ -261,7 +261,7 @@ def main():
         hid = model.diffusion_model.hid_dim
         flops = hidden_layer_flops(passes * B, hid)
         n_hidden = 2 * model.diffusion_model.num_layers
-        lowprec = fs.lowprec_steps(T, guided, ddim) if args.precision == "f16x3" else 0           # leading steps on plain f16 operands
+        lowprec = fs.lowprec_steps(T, min(T, 11) if guided else 0, ddim) if args.precision == "f16x3" else 0   # (the reference guides the last 11 steps: t <= 10)           # leading steps on plain f16 operands
         kernels = {}                                                                # live HIP-event timing of each conv kernel this job runs
 
         def time_kernel(prec):

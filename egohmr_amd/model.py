@@ -678,16 +678,21 @@ class FusedSampler:
             return 1.0
         return float(m.guide_denom_override) if m.guide_denom_override else float(B)
 
-    def lowprec_steps(self, T: int, guided: bool = False, ddim: bool = True) -> int:
-        """How many LEADING steps of a T-step fused loop run on plain f16 operands (EgoHMR.f16x3_last_steps).  'auto' leaves
-        collision-guided loops alone: the guidance feeds nearest-vertex switches back with gain, so the posterior mean no longer
-        contracts the early steps' rounding away (an explicit int k still applies)."""
+    def lowprec_steps(self, T: int, guided=False, ddim: bool = True) -> int:
+        """How many LEADING steps of a T-step fused loop run on plain f16 operands (EgoHMR.f16x3_last_steps).  `guided` = number of
+        collision-guided steps at the END of the loop (True = unknown).  The guidance feeds nearest-vertex switches back with gain, so
+        the f16 steps must end well before the first guided one: the last 0.4 T steps ahead of it also run in f16x3.  Measured
+        (tools/precision_schedule.py --guided, profiles/r02_precision_schedule_ddpm100_guided_b128.jsonl): DDPM-100 at B=128 stays
+        within 1.3e-5 m of the all-f16x3 run for every k >= 12 (1e-6 for two seeds of three; the third has one body at a
+        nearest-vertex switch and shows the same 1.2e-5 at k = 60), and x_t inside the guided steps within 8e-5 at k = 50; on the
+        DDPM-50 guided golden the guided-step trace moves by 3.5e-3 at k = 20 and by 2.2e-4 at k = 30 (final vertices 6e-6 / 2e-6)."""
         k = self.model.f16x3_last_steps
         if k is None or self.model.gcn_precision != "f16x3":
             return 0
         if k == "auto":
-            if guided:
+            if guided is True:
                 return 0
+            n_guided = int(guided)
             if T < 10:
                 return 0                         # (not measured below ten steps)
             if T < 20:
@@ -696,6 +701,8 @@ class FusedSampler:
                 k = max(10, -(-T // 10))         # DDIM-50: k = 10 -> 6.5e-6 m
             else:
                 k = max(8, -(-2 * T // 25))      # ancestral sampling contracts harder: DDPM-100 k = 8 -> <= 3.9e-6 m over 4 seeds (k = 5: 7.4e-6)
+            if n_guided:
+                k = max(k, n_guided + -(-2 * T // 5))
         return max(0, T - int(k))
 
     # ------------------------------------------------------------------ whole loop
@@ -713,6 +720,8 @@ class FusedSampler:
         assert noise.shape[0] >= T + 1 and noise.shape[1] == B and noise.shape[2] == 144, noise.shape
         steps = (_lib.StepCoefs * T)(*[diffusion.step_coefs(i, ddim, 0.0, cond_grad_weight, guided) for i in range(T - 1, -1, -1)])
         any_guided = any(s.grad_scale != 0.0 for s in steps)
+        first_guided = next((i for i, s in enumerate(steps) if s.grad_scale != 0.0), T)
+        n_guided = T - first_guided                       # (the reference guides a contiguous tail: t < 10, gaussian_diffusion.py:378-385)
         tmap = torch.tensor([diffusion.timestep_map[i] for i in range(T - 1, -1, -1)], device=m.device, dtype=torch.long)
         tvecs = self.timestep_vectors(tmap)                                            # [T,2,hid]
         passes = 2 if m.diffuse_fuse else 1
@@ -720,7 +729,7 @@ class FusedSampler:
         desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
                                guide_denom=self.guide_denom(B), tau=m.collision_tau, num_masked=num_masked,
-                               guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=self.lowprec_steps(T, any_guided, ddim))
+                               guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=self.lowprec_steps(T, n_guided, ddim))
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:
             raise _lib.EgoHMRHipError(f"ehm_sample_workspace_bytes rejected the descriptor (rc={nbytes})")

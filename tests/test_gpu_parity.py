@@ -394,6 +394,71 @@ def test_skinny_gemm_f32_vs_torch_fp64(dev, shape):
     assert L.ehm_skinny_gemm_f32(Xd.data_ptr(), Wd.data_ptr(), None, Y.data_ptr(), M, 40, N, 0, None) != 0   # K % 32
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # N, H, W, Ci, Co, k, stride, residual, relu
+    (2, 9, 9, 64, 64, 3, 1, False, True),      # Co = 64: narrow column tiles; 3x3 with image borders; M = 162 < one row tile
+    (3, 14, 10, 64, 96, 1, 1, True, True),     # Co = 96: second column tile half padding; residual; non-square; K = 64 (two K tiles: the minimum)
+    (2, 15, 15, 64, 128, 3, 2, False, False),  # stride 2, odd size, no ReLU
+    (5, 8, 8, 128, 256, 1, 2, True, True),     # strided 1x1 (downsample), two 128-wide column tiles, 80 rows
+    (1, 20, 20, 32, 128, 3, 1, True, True),    # M = 400: three row tiles, ragged tail
+])
+def test_conv_x2_vs_torch_fp64(dev, case):
+    """ehm_conv_x2 (torchvision Bottleneck convs on X2 activations, models/resnet.py:139-150 via egohmr.py:183) against torch float64
+    conv2d + bias (+ identity) + ReLU: borders, strides, ragged row tiles, both column-tile widths, the zero row and padding rows."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from egohmr_amd import _lib
+    N, H, W, Ci, Co, k, stride, has_res, relu = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, Ci, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Ho, Wo, Co, generator=g) if has_res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if has_res:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    L = _lib.lib()
+
+    def to_x2(t, pixels, ch):
+        rows = int(L.ehm_conv_x2_rows(pixels))
+        src = torch.zeros(rows, ch)
+        src[:pixels] = t.reshape(pixels, ch)
+        src[pixels:rows - 1] = 7.0                      # padding rows: garbage the kernel must never let through
+        src, dst = src.to(dev), torch.empty(rows, ch, device=dev)
+        _lib.check(L.ehm_split_pack(src.data_ptr(), dst.data_ptr(), rows, ch, ch, 1.0, None))
+        return dst
+
+    xd = to_x2(x, N * H * W, Ci)
+    rd = to_x2(res, N * Ho * Wo, Co) if has_res else None
+    K, Co_pad = k * k * Ci, (Co + 127) // 128 * 128
+    w2 = torch.zeros(Co_pad, K)
+    w2[:Co] = w.permute(0, 2, 3, 1).reshape(Co, K)
+    wd, wbuf = w2.to(dev), torch.empty(Co_pad, K, device=dev)
+    scale = 256.0
+    _lib.check(L.ehm_split_pack(wd.data_ptr(), wbuf.data_ptr(), Co_pad, K, K, scale, None))
+    bd = bias.to(dev)
+    rows_out = int(L.ehm_conv_x2_rows(N * Ho * Wo))
+    y = torch.full((rows_out, Co), float("nan"), device=dev)
+    d = _lib.ConvX2Desc(xd.data_ptr(), xd.shape[0], wbuf.data_ptr(), bd.data_ptr(), rd.data_ptr() if has_res else None, y.data_ptr(),
+                        N, H, W, Ci, Co, k, k, stride, pad, int(relu), scale)
+    _lib.check(L.ehm_conv_x2(C.byref(d), None), "ehm_conv_x2")
+    out = torch.empty(rows_out, Co, device=dev)
+    _lib.check(L.ehm_gcn_unpack_activations(y.data_ptr(), out.data_ptr(), rows_out, Co, 32, None))
+    torch.cuda.synchronize()
+    got = out[:N * Ho * Wo].cpu().double().reshape(N, Ho, Wo, Co)
+    err = (got - ref).abs().max().item()
+    print(f"[conv_x2 {case}] max|err| vs fp64 = {err:.3e} (|y|max = {ref.abs().max().item():.2f})")
+    assert err < 1e-5
+    assert float(out[rows_out - 1].abs().max()) == 0.0          # the output's own zero row is cleared by the call
+    d.x_rows = xd.shape[0] - 1                                   # a buffer without the zero row is refused
+    assert L.ehm_conv_x2(C.byref(d), None) != 0
+
+
 # --------------------------------------------------------------------------------------------- ResNet-50 backbone
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 96), (1, 32, 32)])

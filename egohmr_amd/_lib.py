@@ -35,7 +35,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS for the in-kernel time stamps (tools/stamp_hidden.py)
+    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS for the in-kernel time stamps (tools/stamp_tiles.py, tools/stamp_skin.py)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}", *extra,
            *srcs, "-o", LIB_PATH]
     if verbose:

@@ -1,5 +1,5 @@
 // NHWC convolution (1x1 / 3x3, stride 1 or 2) as an implicit GEMM on the f16 matrix cores with f32-grade accuracy
-// (split-f16 "f16x3": both operands as hi + lo f16, three v_mfma_f32_32x32x16_f16 per product, f32 accumulate - gcn_f16r.hip),
+// (split-f16 "f16x3": both operands as hi + lo f16, three v_mfma_f32_32x32x16_f16 per product, f32 accumulate - gcn_tile.hip),
 // with the BatchNorm-folded bias, the bottleneck's identity add and the ReLU fused into the epilogue.
 //
 // Serves the ResNet-50 backbone of the conditioning path (torchvision Bottleneck as used by models/egohmr/egohmr.py:183): the

@@ -1,4 +1,4 @@
-// Device-side structures of the Modulated-GCN kernels, shared by gcn.hip (f32 MFMA) and gcn_f16.hip (split-f16 MFMA).
+// Device-side structures of the Modulated-GCN kernels, shared by gcn.hip (f32 MFMA) and gcn_tile.hip (f16 / split-f16 MFMA).
 #pragma once
 #include "common.h"
 
@@ -161,7 +161,7 @@ static __device__ __forceinline__ void gcn_mix_store(const float (&d0)[kJ], cons
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // dp[j] / gp[j] = {body a, body b} values of joint j (diagonal branch incl. shift / off-diagonal branch): one v_pk_fma_f32 per
 // coefficient.  Kernels whose accumulator layout already holds the two bodies in adjacent registers pass sub-vectors of the
-// accumulators and pay no register moves (gcn_f16r.hip).
+// accumulators and pay no register moves (gcn_tile.hip).
 template <class Store>
 static __device__ __forceinline__ void gcn_mix2(const f32x2 (&dp)[kJ], const f32x2 (&gp)[kJ], const float* __restrict__ Aoff, bool relu,
                                                 Store store) {

@@ -9,7 +9,7 @@
 // two 40 KiB stages, XOR-swizzled on the source address so every ds_read_b128 fragment read is bank-conflict free; register
 // double-buffered fragments, one barrier per K tile.
 //
-// What is new relative to round 1 (gcn_f16r.hip): the tile loop is software-pipelined ACROSS tiles and the epilogue no longer
+// What is new relative to round 1's kernel (gcn_f16r.hip, deleted): the tile loop is software-pipelined ACROSS tiles and the epilogue no longer
 // touches LDS or a barrier.
 //   * After the last barrier of a tile's K loop every operand fragment is in registers, so both LDS stages are dead: the block
 //     immediately issues the operand DMA of its NEXT tile (weights always; activations when the producers of that tile were seen

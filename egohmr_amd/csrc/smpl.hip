@@ -672,18 +672,38 @@ __global__ __launch_bounds__(64) void step_body_kernel(StepBodyArgs a, SmplDev S
   __shared__ float Rl[kJ * 9];
   const int b = blockIdx.x, lane = threadIdx.x;
   const int slot = a.mask_slot ? a.mask_slot[b] : b;            // row block of my second pass: B + slot (slot < 0: pruned, every joint visible)
-  for (int i = lane; i < a.passes * kJ * 12; i += 64) {
-    const int p = i / (kJ * 12), rem = i % (kJ * 12);
-    sh[p][rem / 12][rem % 12] = (p == 1 && slot < 0) ? 0.f : a.hs[((size_t)(p ? a.B + slot : b) * kJ) * 12 + rem];
+  // stage the body's output-conv responses and the (tiny) adjacency / modulation tables: every global load of the kernel's first
+  // phase is requested before the first one is consumed (as an element-wise loop this was nine dependent round trips, and the mix
+  // below fetched its coefficients from global memory inside the inner loop)
+  __shared__ float sAo[kJ * kJ], sMo[kJ * 6];
+  {
+    float tmp[9], ta[9], tm[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = lane + 64 * k, p = i / (kJ * 12), rem = i % (kJ * 12);
+      tmp[k] = (i < a.passes * kJ * 12 && !(p == 1 && slot < 0)) ? a.hs[((size_t)(p ? a.B + slot : b) * kJ) * 12 + rem] : 0.f;
+      ta[k] = a.O.A[i < kJ * kJ ? i : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tm[k] = a.O.M[lane + 64 * k < kJ * 6 ? lane + 64 * k : 0];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = lane + 64 * k;
+      if (i < a.passes * kJ * 12) (&sh[0][0][0])[i] = tmp[k];
+      if (i < kJ * kJ) sAo[i] = ta[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (lane + 64 * k < kJ * 6) sMo[lane + 64 * k] = tm[k];
   }
   __syncthreads();
   for (int e = lane; e < kPoseDim; e += 64) {
     const int j = e / 6, c = e % 6;
     const int p = (a.passes == 2 && !a.vis[(size_t)b * kJ + j]) ? 1 : 0;          // egohmr.py:249-254
-    const float s = a.O.A[j * kJ + j] * (a.O.M[j * 6 + c] * sh[p][j][c]);
+    const float s = sAo[j * kJ + j] * (sMo[j * 6 + c] * sh[p][j][c]);
     float t = 0.f;
     for (int jp = 0; jp < kJ; ++jp)
-      if (jp != j) t = fmaf(a.O.A[j * kJ + jp], a.O.M[jp * 6 + c] * sh[p][jp][6 + c], t);
+      if (jp != j) t = fmaf(sAo[j * kJ + jp], sMo[jp * 6 + c] * sh[p][jp][6 + c], t);
     const float x0 = s + t + a.O.bias[c];
     const size_t i = (size_t)b * kPoseDim + e;
     a.x0[i] = x0;

@@ -397,16 +397,43 @@ __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restric
   const int row = lane & 15, q = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK;
   const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
-  const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: whole 16-k groups)
-  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-  const float* xr = X + r * K + (size_t)wave * kq + 4 * q;
-  const half_t* xh = (const half_t*)X + r * K + (size_t)wave * kq + 4 * q;
-  const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 4 * q;
+  const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: a multiple of 16)
+  // a lane owns 8 consecutive k of every 32-k group (16 bytes of f16 / 32 bytes of float32 per load: the four lanes of a row cover a
+  // 64 / 128-byte segment); MFMA c of the group contracts element c of all lanes, i.e. k = c, 8 + c, 16 + c, 24 + c
+  const float* xr = X + r * K + (size_t)wave * kq + 8 * q;
+  const half_t* xh = (const half_t*)X + r * K + (size_t)wave * kq + 8 * q;
+  const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 8 * q;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: the dependent-accumulator latency (40 cyc) exceeds the issue interval
 #pragma unroll 4
-  for (int k = 0; k < kq; k += 16) {                                 // 16 k = four MFMA steps per float4 pair
+  for (int k = 0; k + 32 <= kq; k += 32) {
+    float xv[8];
+    if (HALF_IN) {
+      const half8 hv = *(const half8*)(xh + k);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xv[c] = (float)hv[c];
+    } else {
+      const f32x4 x0 = *(const f32x4*)(xr + k), x1 = *(const f32x4*)(xr + k + 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xv[c] = x0[c]; xv[4 + c] = x1[c]; }
+    }
+    f32x4 w0 = *(const f32x4*)(wr + k), w1 = *(const f32x4*)(wr + k + 4);
+    if (row >= 12) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], w0[c], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], w0[c + 1], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[4 + c], w1[c], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[5 + c], w1[c + 1], acc2, 0, 0, 0);
+    }
+  }
+  if (kq & 16) {                                                      // hid % 128 != 0: one last 16-k group, four k per lane
+    const int k = kq - 16 - 4 * q;                                    // (undo the 8 q of the pointers: this group's lane stride is 4)
     f32x4 xv;
     if (HALF_IN) {
+      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
       const half4_t hv = *(const half4_t*)(xh + k);
       xv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
     } else {

@@ -186,6 +186,35 @@ def test_gcn_hidden_layer_vs_oracle(L, dev, hid, bodies, prec):
     L.ehm_gcn_destroy(h)
 
 
+@pytest.mark.parametrize("hid,bodies", [(192, 5), (1024, 9), (320, 3)])   # 192 / 320: hid % 128 != 0 (the output GEMM's 16-k tail group)
+def test_gcn_output_layer_vs_oracle(L, dev, hid, bodies):
+    """gconv_output (_GraphConv hid -> 6 without BatchNorm, modulated_gcn.py:112-113) = ehm_gcn_output_layer (exact-f32 MFMA responses +
+    adjacency mix) against the eager restatement, including widths that are not a multiple of 128."""
+    from egohmr_amd import _lib
+    from egohmr_amd.model import PRECISIONS
+    from oracle import model as om
+    sd_h = _gconv_sd(40, hid, hid)
+    sd_o = _gconv_sd(42, hid, 6, bn=False)
+    h, keep = _native_gcn(L, dev, sd_h, [sd_h, sd_h], sd_o, hid)
+    _lib.check(L.ehm_gcn_set_precision(h, PRECISIONS["f32"]))
+    g = np.random.Generator(np.random.PCG64(9))
+    x = torch.from_numpy(g.normal(size=(bodies, 24, hid)).astype(np.float32))
+    tile = L.ehm_gcn_row_tile()
+    rows = bodies * 24
+    rows_pad = (rows + tile - 1) // tile * tile
+    X = torch.zeros(rows_pad, hid, device=dev)
+    X[:rows] = x.reshape(rows, hid).to(dev)
+    vis = torch.ones(bodies, 24, dtype=torch.uint8, device=dev)
+    x0 = torch.full((bodies, 144), float("nan"), device=dev)
+    _lib.check(L.ehm_gcn_output_layer(h, X.data_ptr(), vis.data_ptr(), x0.data_ptr(), bodies, 1, None))
+    torch.cuda.synchronize()
+    ref = om.modulated_graph_conv({k.replace("l.", "a."): v.double() for k, v in sd_o.items()}, "a.gconv", x.double(), om.smpl_adjacency().double())
+    err = (x0.cpu().double() - ref.reshape(bodies, 144)).abs().max().item()
+    print(f"[gcn output hid={hid}] max|err| vs fp64 = {err:.3e} (|y|max = {ref.abs().max().item():.2f})")
+    assert err < 2e-5 * max(1.0, ref.abs().max().item())
+    L.ehm_gcn_destroy(h)
+
+
 def test_gcn_hidden_layer_vs_reference_golden(L, dev, golden_dir):
     """Full-width ModulatedGraphConv output of the reference (g4_gconv_1024) through the MFMA kernel
     (identity BatchNorm, ReLU applied to the golden)."""

@@ -169,17 +169,24 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
                                                             const int* __restrict__ idx, const int* __restrict__ count,
                                                             const float* __restrict__ bbox, float* __restrict__ loss,
                                                             float* __restrict__ gverts, int* __restrict__ hits, int V, int N, float tau) {
+  // grid = (bodies, slices): the selected points of a body are dealt out in runs of 1024 to gridDim.y blocks, each of which builds the
+  // body's (cheap) cell grid for itself - the per-point search is 93 % of the kernel (in-kernel stamps) and one block per body left
+  // half of the chip idle at B = 128
   extern __shared__ __attribute__((aligned(16))) float sv[];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int slice = blockIdx.y, slices = gridDim.y;
   const int cnt = count[b];
-  if (cnt == 0) return;                                  // block-uniform
+  if (cnt <= 1024 * slice) return;                       // block-uniform: nothing for this slice (cnt == 0 included)
   const int Vp = (V + 3) & ~3;
   float* sx = sv;
   float* sy = sv + Vp;
   float* sz = sv + 2 * Vp;
   int* cstart = (int*)(sv + 3 * Vp);                     // [kMaxCells + 1] exclusive offsets
   int* cursor = cstart + kMaxCells + 1;                  // [kMaxCells]
-  unsigned short* order = (unsigned short*)(cursor + kMaxCells);   // [Vp] vertex ids sorted by cell
+  unsigned short* order = (unsigned short*)(cursor + kMaxCells);   // [Vp] vertex id of sorted slot i
+  // sx / sy / sz hold the vertices SORTED BY CELL (slot i = vertex order[i]): the search streams a cell's slots with independent loads;
+  // with the positions in vertex order every candidate cost two dependent LDS round trips (order[i] -> sx[order[i]]) and the per-point
+  // search was 93 % of the kernel (in-kernel stamps)
   __shared__ int part[1024];
   __shared__ float wred[16];
   __shared__ int hred[16];
@@ -201,17 +208,26 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
     cy = min(ny - 1, max(0, (int)((y - lo[1]) * ih)));
     cz = min(nz - 1, max(0, (int)((z - lo[2]) * ih)));
   };
-  for (int v = tid; v < V; v += 1024) {
-    const float* p = verts + ((size_t)b * V + v) * 3;
-    sx[v] = p[0]; sy[v] = p[1]; sz[v] = p[2];
+  constexpr int kVPT = 8;                                // vertices per thread kept in registers across the build (V <= 8192)
+  float vx[kVPT], vy[kVPT], vz[kVPT];
+  int vc[kVPT];
+#pragma unroll
+  for (int i = 0; i < kVPT; ++i) {
+    const int v = tid + 1024 * i;
+    vc[i] = -1;
+    if (v < V) {
+      const float* p = verts + ((size_t)b * V + v) * 3;
+      vx[i] = p[0]; vy[i] = p[1]; vz[i] = p[2];
+      int cx, cy, cz;
+      cell_of(vx[i], vy[i], vz[i], cx, cy, cz);
+      vc[i] = cx + nx * (cy + ny * cz);
+    }
   }
   for (int c = tid; c < nc; c += 1024) cursor[c] = 0;
   __syncthreads();
-  for (int v = tid; v < V; v += 1024) {                  // histogram
-    int cx, cy, cz;
-    cell_of(sx[v], sy[v], sz[v], cx, cy, cz);
-    atomicAdd(&cursor[cx + nx * (cy + ny * cz)], 1);
-  }
+#pragma unroll
+  for (int i = 0; i < kVPT; ++i)                         // histogram
+    if (vc[i] >= 0) atomicAdd(&cursor[vc[i]], 1);
   __syncthreads();
   {                                                      // exclusive scan of up to 4096 counts: 4 per thread + block scan
     int loc[4], sum = 0;
@@ -233,33 +249,37 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
   __syncthreads();
   for (int c = tid; c < nc; c += 1024) cursor[c] = cstart[c];
   __syncthreads();
-  for (int v = tid; v < V; v += 1024) {                  // scatter (order inside a cell is arbitrary; the search below does not care)
-    int cx, cy, cz;
-    cell_of(sx[v], sy[v], sz[v], cx, cy, cz);
-    order[atomicAdd(&cursor[cx + nx * (cy + ny * cz)], 1)] = (unsigned short)v;
-  }
+#pragma unroll
+  for (int i = 0; i < kVPT; ++i)                         // scatter (order inside a cell is arbitrary; the search below does not care)
+    if (vc[i] >= 0) {
+      const int slot = atomicAdd(&cursor[vc[i]], 1);
+      order[slot] = (unsigned short)(tid + 1024 * i);
+      sx[slot] = vx[i]; sy[slot] = vy[i]; sz[slot] = vz[i];
+    }
   __syncthreads();
 
   float contrib = 0.f;
   int nhit = 0;
-  for (int k = tid; k < cnt; k += 1024) {
+  for (int k = tid + 1024 * slice; k < cnt; k += 1024 * slices) {
     const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + k]) * 3;
     const float px = p[0], py = p[1], pz = p[2];
     int cx, cy, cz;
     cell_of(px, py, pz, cx, cy, cz);
     float best = 3.4e38f;
-    int bi = 0x7fffffff;
+    int bi = 0x7fffffff, bslot = 0;
     for (int dz = max(cz - 1, 0); dz <= min(cz + 1, nz - 1); ++dz)
-      for (int dy = max(cy - 1, 0); dy <= min(cy + 1, ny - 1); ++dy)
-        for (int dx = max(cx - 1, 0); dx <= min(cx + 1, nx - 1); ++dx) {
-          const int c = dx + nx * (dy + ny * dz);
-          for (int i = cstart[c]; i < cstart[c + 1]; ++i) {
+      for (int dy = max(cy - 1, 0); dy <= min(cy + 1, ny - 1); ++dy) {
+        // the (up to three) cells of one x-run are adjacent in the sorted order: one contiguous slot range
+        const int c0 = max(cx - 1, 0) + nx * (dy + ny * dz), c1 = min(cx + 1, nx - 1) + nx * (dy + ny * dz);
+        for (int i = cstart[c0]; i < cstart[c1 + 1]; ++i) {
+          const float ex = px - sx[i], ey = py - sy[i], ez = pz - sz[i];
+          const float d2 = ex * ex + ey * ey + ez * ez;
+          if (d2 <= best) {                               // (rare path) first minimum by vertex index, like torch.min
             const int v = order[i];
-            const float ex = px - sx[v], ey = py - sy[v], ez = pz - sz[v];
-            const float d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 < best || (d2 == best && v < bi)) { best = d2; bi = v; }   // first minimum by vertex index, like torch.min
+            if (d2 < best || v < bi) { best = d2; bi = v; bslot = i; }
           }
         }
+      }
     if (bi != 0x7fffffff) {
       const float d = sqrtf(best + 1e-12f);
       const float hh = tau - d;
@@ -269,9 +289,9 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
         if (gverts) {
           const float s = 2.f * hh / d;                   // d(h^2)/dv = 2h (p - v)/d
           float* g = gverts + ((size_t)b * V + bi) * 3;
-          atomicAdd(g + 0, s * (px - sx[bi]));
-          atomicAdd(g + 1, s * (py - sy[bi]));
-          atomicAdd(g + 2, s * (pz - sz[bi]));
+          atomicAdd(g + 0, s * (px - sx[bslot]));
+          atomicAdd(g + 1, s * (py - sy[bslot]));
+          atomicAdd(g + 2, s * (pz - sz[bslot]));
         }
       }
     }
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
 #pragma unroll
     for (int w = 0; w < 16; ++w) { s += wred[w]; nh += hred[w]; }
     if (s != 0.f) atomicAdd(loss + b, s);
-    if (hits && nh) hits[b] = nh;
+    if (hits && nh) atomicAdd(hits + b, nh);
   }
 }
 
@@ -671,9 +691,13 @@ int collision_impl(const float* verts, const float* scene, float* loss, float* g
     return EHM_EINVAL;
   }
   const size_t lds_grid = lds + (size_t)(2 * kMaxCells + 1) * sizeof(int) + (size_t)Vp * sizeof(unsigned short) + 16;
-  if (V <= 65535 && lds_grid <= 160 * 1024 - 4608) {
+  if (V <= 8192 && lds_grid <= 160 * 1024 - 4608) {          // (the grid kernel keeps 8 vertices per thread in registers)
     EHM_HIP(hipFuncSetAttribute((const void*)nearest_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608));
-    hipLaunchKernelGGL(nearest_grid_kernel, dim3(B), dim3(1024), lds_grid, st, verts, scene, s.idx, s.count, s.bbox, loss, gverts, hits, V, N, tau);
+    int slices = ehm_num_cus() / (B > 0 ? B : 1);         // one block per CU (the vertex arrays take half of its LDS)
+    slices = slices < 1 ? 1 : (slices > 4 ? 4 : slices);
+    if (slices > (N + 1023) / 1024) slices = (N + 1023) / 1024;
+    hipLaunchKernelGGL(nearest_grid_kernel, dim3(B, slices), dim3(1024), lds_grid, st, verts, scene, s.idx, s.count, s.bbox, loss, gverts, hits, V,
+                       N, tau);
   } else {   // bodies too large for the in-LDS grid: brute force over an LDS-resident copy of the vertices
     hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)ceil_div(N, 1024), B), dim3(1024), lds, st, verts, scene, s.idx, s.count, loss,
                        gverts, hits, V, N, tau);

@@ -457,6 +457,15 @@ class FusedSampler:
             scene = scene - transl.unsqueeze(1)                                        # :211
         scene = scene.contiguous()
         img = g("img")
+        # pass pruning map (ehm_gcn_set_pass_map): items with an invisible joint need the second pass.  Its count is the ONE host
+        # read-back of a batch, so it comes first: everything below - the encoders and, in run(), the whole sampling loop - is then
+        # enqueued without the host ever waiting for the GPU again (with the read-back at the end of prepare() the GPU idled while
+        # Python built the step table after every batch's encoders).
+        vis = m.visibility({"orig_keypoints_2d": batch["orig_keypoints_2d"].to(dev)})
+        need = ~vis.all(dim=1)
+        mask_items = torch.nonzero(need).flatten().to(torch.int32).contiguous()
+        mask_slot = torch.where(need, torch.cumsum(need.to(torch.int32), 0) - 1, torch.full_like(need, -1, dtype=torch.int32)).to(torch.int32).contiguous()
+        num_masked = int(mask_items.numel())
         # The two encoders are independent, and complementary on the chip: ResNet-50's early layers stream 0.8 GB float32 activations
         # per conv (HBM-bound, matrix cores idle), the PointNet's GEMMs are matrix-core bound.  Run them on two HIP streams.
         if m.overlap_encoders:
@@ -485,18 +494,13 @@ class FusedSampler:
             cam = [torch.stack([cx / ofx, cy / ofx], -1)] + cam
         cam = torch.cat(cam, dim=1)
         other = torch.cat([scene_feats, transl_feat, cam], dim=1)                      # :220-221
-        vis = m.visibility({"orig_keypoints_2d": batch["orig_keypoints_2d"].to(dev)})
         f = self._folded
         h_img, h_oth, betas = self._project(img_feats.contiguous(), other)
         self._prep = _Prepared(B=img_feats.shape[0], h_img=h_img, h_oth=h_oth, vis=vis.to(torch.uint8).contiguous(), vis_bool=vis,
                                betas=betas, scene=scene, transl=transl, fx=fx, cam_cx=cx, cam_cy=cy, img_feats=img_feats,
                                scene_feats=scene_feats)
         self._prep.inputs = ins                  # strong references (see the key above)
-        # pass pruning map (ehm_gcn_set_pass_map): items with an invisible joint need the second pass.  One host read-back per batch.
-        need = ~vis.all(dim=1)
-        self._prep.mask_items = torch.nonzero(need).flatten().to(torch.int32).contiguous()
-        self._prep.mask_slot = torch.where(need, torch.cumsum(need.to(torch.int32), 0) - 1, torch.full_like(need, -1, dtype=torch.int32)).to(torch.int32).contiguous()
-        self._prep.num_masked = int(self._prep.mask_items.numel())
+        self._prep.mask_items, self._prep.mask_slot, self._prep.num_masked = mask_items, mask_slot, num_masked
         self._prep_key = key
         return self._prep
 

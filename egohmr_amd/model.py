@@ -791,13 +791,15 @@ class FusedSampler:
                 o = SimpleNamespace(**ins, **out_bufs())
                 tr = torch.empty(T, B, 144, device=dev) if trace else None
                 launch(o, self._workspace(nbytes, dev), tr)
-            # a chained launch that gave up on a producer wait (GPU shared / preempted) flags the handle instead of hanging: one
-            # read-back per sampling call turns that into an exception rather than silently wrong bodies
-            _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
         x_final, x0, verts, joints, R, pose6d = o.x_final, o.x0, o.verts, o.joints, o.R, o.pose6d
         self.last_trace = tr
         if tr is not None:
             batch["x_t"] = tr[-1]
         batch["vis_mask_smpl"] = st.vis_bool
         out = m._pack_output(batch, st, x0, pose6d, R, verts, joints)
+        # a chained launch that gave up on a producer wait (GPU shared / preempted) flags the handle instead of hanging: one read-back
+        # per sampling call (the call's only host wait, after everything has been enqueued) turns that into an exception rather than
+        # silently wrong bodies
+        with torch.cuda.device(dev):
+            _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
         return {"sample": x_final, "pred_xstart": x0, "other_outputs": out}

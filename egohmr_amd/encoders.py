@@ -258,7 +258,10 @@ class ResnetPointnet(nn.Module):
         return buf, scale, w
 
     def _prepare(self, device):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        if getattr(self, "_tkey", None) is None:
+            from . import _lib
+            self._tkey = _lib.TensorKey(self)
+        key = self._tkey() + (str(device),)
         if self._packed is not None and self._packed_key == key:
             return self._packed
         H = self.hidden_dim

@@ -356,9 +356,9 @@ class FusedSampler:
 
     # ------------------------------------------------------------------ weights -> native handle
     def _param_key(self):
-        dm = self.model.diffusion_model
-        return tuple((p.data_ptr(), p._version) for p in dm.parameters()) + tuple((b.data_ptr(), b._version) for b in dm.buffers()) \
-            + tuple((p.data_ptr(), p._version) for p in self.model.input_process.parameters())
+        if getattr(self, "_pk", None) is None:
+            self._pk = _lib.TensorKey(self.model.diffusion_model, self.model.input_process)
+        return self._pk()
 
     def gcn(self):
         key = self._param_key()
@@ -430,7 +430,9 @@ class FusedSampler:
     def _backbone_fn(self):
         """ResNet-50 with BatchNorm folded into the convolutions, rebuilt when the backbone weights change."""
         bb = self.model.backbone
-        key = tuple((t.data_ptr(), t._version) for t in list(bb.parameters()) + list(bb.buffers()))
+        if getattr(self, "_bbk", None) is None or self._bbk.modules[0] is not bb:
+            self._bbk = _lib.TensorKey(bb)
+        key = self._bbk()
         if getattr(self, "_bb_key", None) != key:
             self._bb_fn, self._bb_key = bb.folded(channels_last=False, matrix_core=self.model.backbone_matrix_core), key
         return self._bb_fn
@@ -541,8 +543,9 @@ class FusedSampler:
 
     def _cond_param_key(self):
         m = self.model
-        mods = (m.backbone, m.scene_enc, m.transl_enc, m.beta_layer, m.embed_timestep)
-        return tuple((t.data_ptr(), t._version) for mod in mods for t in list(mod.parameters()) + list(mod.buffers()))
+        if getattr(self, "_ck", None) is None:
+            self._ck = _lib.TensorKey(m.backbone, m.scene_enc, m.transl_enc, m.beta_layer, m.embed_timestep)
+        return self._ck()
 
     def _apply_pass_map(self, st, passes):
         """(virtual bodies, num_masked for the descriptor) after telling the handle which items still need the second pass."""
@@ -554,9 +557,12 @@ class FusedSampler:
         _lib.check(L.ehm_gcn_set_pass_map(h, None, None, -1), "ehm_gcn_set_pass_map")
         return passes * st.B, -1
 
-    def invalidate(self):
-        """Drop the cached conditioning (bench.py: the encoders are part of every timed call)."""
+    def invalidate(self, structure: bool = False):
+        """Drop the cached conditioning (bench.py: the encoders are part of every timed call).  structure=True also re-collects the
+        parameter slots behind the weight-version keys (needed only after sub-modules or parameters were ADDED to the model)."""
         self._prep, self._prep_key = None, None
+        if structure:
+            self._pk = self._ck = self._bbk = None
 
     @torch.no_grad()
     def timestep_vectors(self, t_orig: torch.Tensor) -> torch.Tensor:

@@ -117,6 +117,41 @@ def test_multiple_samples_share_conditioning(dev, model):
     assert float((betas - betas[:, :1]).abs().max()) == 0.0                             # betas do not depend on the sample
 
 
+def test_conditioning_cache_sees_weight_changes(dev):
+    """The conditioning cached by FusedSampler.prepare is keyed on the version of every weight it passes through (_lib.TensorKey): an
+    in-place update, a replaced Parameter object and a load_state_dict each force a re-encode; an untouched model does not."""
+    from egohmr_amd.factory import build_synthetic_model
+    m = build_synthetic_model(dev, 3)
+    fs = m.fused_sampler
+    b = _batch(dev, 2)
+    p0 = fs.prepare(b)
+    assert fs.prepare(b) is p0                                               # unchanged: cache hit
+    f0 = p0.img_feats.clone()
+    with torch.no_grad():
+        m.backbone.layer4[2].conv3.weight.mul_(1.5)                          # in-place: _version bump
+    p1 = fs.prepare(b)
+    assert p1 is not p0 and float((p1.img_feats - f0).abs().max()) > 0
+    f1 = p1.img_feats.clone()
+    w = m.backbone.layer4[2].conv3.weight
+    m.backbone.layer4[2].conv3.weight = torch.nn.Parameter((w.detach() / 1.5).clone())   # replaced Parameter object
+    p2 = fs.prepare(b)
+    assert p2 is not p1
+    np.testing.assert_allclose(p2.img_feats.cpu().numpy(), f0.cpu().numpy(), atol=2e-5)   # back to the original weights
+    s0 = p2.scene_feats.clone()
+    sd = {k: v.clone() for k, v in m.scene_enc.state_dict().items()}
+    sd["fc_c.bias"] += 1.0
+    m.scene_enc.load_state_dict(sd)                                          # load_state_dict copies in place
+    p3 = fs.prepare(b)
+    assert p3 is not p2
+    np.testing.assert_allclose((p3.scene_feats - s0).cpu().numpy(), 1.0, atol=1e-5)
+    h0 = p3.h_img.clone()
+    with torch.no_grad():
+        m.diffusion_model.gconv_input[0].gconv.W.mul_(2.0)                   # denoiser weights: the projections are re-folded
+    p4 = fs.prepare(b)
+    assert p4 is not p3 and float((p4.h_img - 2.0 * h0).abs().max()) < 1e-4 * float(h0.abs().max())
+    assert float((f1 - f0).abs().max()) > 0
+
+
 def test_error_behaviour(dev, model):
     from egohmr_amd import _lib
     from egohmr_amd.diffusion import create_gaussian_diffusion

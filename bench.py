@@ -195,11 +195,11 @@ def main():
 
     def one_step():
         fs.invalidate()                                                              # conditioning is part of the job: re-encode
-        packs = []
-        for k in range(S):                                                           # samples of one item share its conditioning
-            res = fs.run(diffusion, batch, noises[k], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0)
-            packs.append(edist.pack_params(res["other_outputs"]["pred_smpl_params"]))
-        return edist.gather_packed(torch.cat(packs, 0)), res
+        # the S samples of an item share its conditioning and are independent given it: one fused loop over S*B bodies
+        # (FusedSampler.run_samples; bit-equal to S sequential loops, tests/test_gpu_api.py)
+        outs = fs.run_samples(diffusion, batch, noises[:S], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0)
+        packs = [edist.pack_params(o["other_outputs"]["pred_smpl_params"]) for o in outs]
+        return edist.gather_packed(torch.cat(packs, 0)), outs[-1]
 
     for _ in range(args.warmup):
         one_step()
@@ -314,7 +314,7 @@ def main():
                                "final bodies within 1e-5 m of the all-split run, measured below)",
                       "f16": "f16 denoiser GEMMs and activations (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": S, "collision_guided": guided, "denoising_steps": T,
+            "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": S, "samples_in_one_loop": bool(S > 1), "collision_guided": guided, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
                        "gcn_precision": args.precision, "f16x3_last_steps": (T - lowprec) if args.precision == "f16x3" else None,
                        "f16x3_last_steps_policy": str(model.f16x3_last_steps),

@@ -25,7 +25,8 @@ from .geometry import perspective_projection
 class Stage2Driver:
     def __init__(self, model, diffusion, smpl_neutral, smpl_male, smpl_female, num_samples: int = 5, timestep_respacing: str = "",
                  with_coap_grad: bool = False, cond_grad_weight: float = 2.0, eval_coll_loss: bool = False,
-                 eval_contact_score: bool = True, eval_with_vis_mask_pa: bool = False, fx_norm_coeff: float = 1500.0):
+                 eval_contact_score: bool = True, eval_with_vis_mask_pa: bool = False, fx_norm_coeff: float = 1500.0,
+                 batch_samples: bool = True):
         if eval_with_vis_mask_pa:
             raise NotImplementedError("reconstruction_error_with_vis_mask (utils/pose_utils.py) is not on the default path (test_egohmr.py:76)")
         self.model, self.diffusion = model, diffusion
@@ -34,6 +35,7 @@ class Stage2Driver:
         self.guided, self.w = bool(with_coap_grad), float(cond_grad_weight)
         self.eval_coll_loss, self.eval_contact = bool(eval_coll_loss), bool(eval_contact_score)
         self.fx_norm_coeff = fx_norm_coeff
+        self.batch_samples = bool(batch_samples)   # the S samples of a batch as one fused loop over S*B bodies (FusedSampler.run_samples)
         self._acc = {}
         self._lists = {k: [] for k in ("pred_betas", "pred_global_orient", "pred_body_pose", "gt_cam_full", "coll", "contact")}
         self._vis_counts = dict(joint_vis=0, joint_invis=0, vertex_vis=0, vertex_invis=0)
@@ -45,10 +47,23 @@ class Stage2Driver:
         B = batch["img"].shape[0]
         out = {"betas": [], "global_orient": [], "body_pose": []}
         coll = np.zeros((B, self.S))
+        batched = None
+        ddim = self.respacing[0:4] == "ddim"
+        if self.S > 1 and self.batch_samples and self.diffusion._fused_ok(self.model, 0, None, None, False, 0.0) and not (ddim and self.guided):
+            # the S loops of the reference (test_egohmr.py:251-266) as ONE loop over S*B bodies (FusedSampler.run_samples): same noise
+            # draws in the same order, same per-body arithmetic
+            self.model.validation_setup()
+            dev = self.model.device
+            stacks = noise_stacks if noise_stacks is not None else [self.diffusion._draw_stack([B, 144], dev, None) for _ in range(self.S)]
+            batched = self.model.fused_sampler.run_samples(self.diffusion, batch, list(stacks[: self.S]), ddim=ddim, guided=self.guided,
+                                                           cond_grad_weight=self.w)
         for n in range(self.S):
-            o = self.diffusion.val_losses(model=self.model, batch=batch, shape=[B, 144], progress=False, clip_denoised=False, cur_epoch=0,
-                                          timestep_respacing=self.respacing, cond_fn_with_grad=self.guided, cond_grad_weight=self.w,
-                                          noise_stack=None if noise_stacks is None else noise_stacks[n])
+            if batched is not None:
+                o = batched[n]["other_outputs"]
+            else:
+                o = self.diffusion.val_losses(model=self.model, batch=batch, shape=[B, 144], progress=False, clip_denoised=False, cur_epoch=0,
+                                              timestep_respacing=self.respacing, cond_fn_with_grad=self.guided, cond_grad_weight=self.w,
+                                              noise_stack=None if noise_stacks is None else noise_stacks[n])
             if self.eval_coll_loss:
                 coll[:, n] = np.array(self.model.eval_coll(o))
             for k in out:

@@ -715,9 +715,54 @@ class FusedSampler:
                 k = max(k, n_guided + -(-2 * T // 5))
         return max(0, T - int(k))
 
+    # ------------------------------------------------------------------ S samples of one batch in ONE loop
+    @torch.no_grad()
+    def run_samples(self, diffusion, batch, noise_stacks, ddim=False, guided=False, cond_grad_weight=1.0):
+        """The reference draws S samples per item with S sequential sampling loops over the same batch (test_egohmr.py:251-266).  The
+        samples are independent given the conditioning, so this runs them as ONE loop over S*B bodies (sample-major: body s*B + b) with
+        the conditioning replicated by index - the same arithmetic per body (the guidance denominator stays B), S times fewer launches
+        and full-size conv tiles for small B.  noise_stacks: S tensors [T+1,B,144].  Returns a list of S result dicts like run()."""
+        S = len(noise_stacks)
+        st = self.prepare(batch)
+        if S == 1:
+            return [self.run(diffusion, batch, noise_stacks[0], ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=st)]
+        B = st.B
+        rep = lambda t: t.repeat(S, *([1] * (t.dim() - 1))).contiguous()
+        fields = {k: (rep(v) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B and k not in ("mask_items", "mask_slot") else v)
+                  for k, v in vars(st).items()}
+        r = _Prepared(**fields)
+        r.B = S * B
+        off = torch.arange(S, device=st.mask_slot.device, dtype=torch.int32)
+        nm = max(st.num_masked, 0)
+        r.mask_items = (st.mask_items.view(1, -1) + off.view(-1, 1) * B).reshape(-1).contiguous()
+        r.mask_slot = torch.where(st.mask_slot.view(1, -1) >= 0, st.mask_slot.view(1, -1) + off.view(-1, 1) * nm,
+                                  torch.full((1, 1), -1, device=off.device, dtype=torch.int32)).reshape(-1).to(torch.int32).contiguous()
+        r.num_masked = S * st.num_masked if st.num_masked >= 0 else st.num_masked
+        r.inputs = st.inputs
+        T = diffusion.num_timesteps
+        noise = torch.cat([_lib.f32(n, self.model.device)[: T + 1] for n in noise_stacks], dim=1)
+        res = self.run(diffusion, dict(batch), noise, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=r, denom_items=B)
+
+        def split(x):
+            if torch.is_tensor(x):
+                return list(x.reshape(S, B, *x.shape[1:]).unbind(0)) if x.dim() >= 1 and x.shape[0] == S * B else [x] * S
+            if isinstance(x, dict):
+                parts = {k: split(v) for k, v in x.items()}
+                return [{k: parts[k][i] for k in x} for i in range(S)]
+            return [x] * S
+        outs = split(res)
+        # leave the model's per-call attributes as S sequential calls would: un-replicated inputs, the last sample's bodies
+        m = self.model
+        m.scene_pcd_verts, m.input_transl = st.scene, st.transl
+        m.focal_length, m.camera_center_full = m.focal_length[:B], m.camera_center_full[:B]
+        last = outs[-1]["other_outputs"]
+        m.smpl_output = smpl_mod.SMPLOutput(vertices=last["pred_vertices"], joints=last["pred_keypoints_3d"],
+                                            full_pose=torch.cat([last["pred_smpl_params"]["global_orient"], last["pred_smpl_params"]["body_pose"]], dim=1))
+        return outs
+
     # ------------------------------------------------------------------ whole loop
     @torch.no_grad()
-    def run(self, diffusion, batch, noise_stack, ddim=False, guided=False, cond_grad_weight=1.0, trace=False, prepared=None):
+    def run(self, diffusion, batch, noise_stack, ddim=False, guided=False, cond_grad_weight=1.0, trace=False, prepared=None, denom_items=None):
         """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
         Returns the reference's dict(sample, pred_xstart, other_outputs)."""
         m, L = self.model, _lib.lib()
@@ -738,7 +783,7 @@ class FusedSampler:
         _, num_masked = self._apply_pass_map(st, passes)
         desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
-                               guide_denom=self.guide_denom(B), tau=m.collision_tau, num_masked=num_masked,
+                               guide_denom=self.guide_denom(denom_items or B), tau=m.collision_tau, num_masked=num_masked,
                                guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=self.lowprec_steps(T, n_guided, ddim))
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:

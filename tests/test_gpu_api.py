@@ -152,6 +152,37 @@ def test_conditioning_cache_sees_weight_changes(dev):
     assert float((f1 - f0).abs().max()) > 0
 
 
+@pytest.mark.parametrize("guided", [False, True])
+def test_run_samples_equals_sequential_runs(dev, model, guided):
+    """FusedSampler.run_samples (S samples of a batch as one loop over S*B bodies, conditioning replicated by index) against the
+    reference's structure - S sequential loops over the same batch (test_egohmr.py:251-266): bit-equal without guidance (the per-body
+    arithmetic does not depend on the batch), within the float-atomics noise of the collision gradient with it."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=20, timestep_respacing="")
+    B, S, T = 5, 3, 20
+    b = _batch(dev, B, N=600)
+    if guided:
+        b["scene_pcd_verts_full"][:, :200, 1] = b["smpl_params"]["transl"][:, None, 1] - 0.6
+    noises = [torch.from_numpy(syn.make_noise_stack(T, B, seed=300 + s)).to(dev) for s in range(S)]
+    fs = model.fused_sampler
+    seq = [fs.run(d, b, noises[s], ddim=False, guided=guided, cond_grad_weight=2.0 if guided else 1.0) for s in range(S)]
+    keys_before = set(b.keys())
+    bat = fs.run_samples(d, b, noises, ddim=False, guided=guided, cond_grad_weight=2.0 if guided else 1.0)
+    assert len(bat) == S and set(b.keys()) == keys_before                               # the caller's batch is not touched
+    for s in range(S):
+        for k in ("pred_x_start", "pred_vertices", "pred_keypoints_3d", "pred_keypoints_2d_full", "pred_pose_6d"):
+            x, y = bat[s]["other_outputs"][k], seq[s]["other_outputs"][k]
+            assert x.shape == y.shape
+            if guided:
+                np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), atol=2e-5)
+            else:
+                assert torch.equal(x, y), k
+        assert torch.equal(bat[s]["other_outputs"]["pred_smpl_params"]["betas"], seq[s]["other_outputs"]["pred_smpl_params"]["betas"])
+        if not guided:
+            assert torch.equal(bat[s]["sample"], seq[s]["sample"])
+    assert float((seq[0]["sample"] - seq[1]["sample"]).abs().max()) > 1e-3              # different noise, different samples
+
+
 def test_error_behaviour(dev, model):
     from egohmr_amd import _lib
     from egohmr_amd.diffusion import create_gaussian_diffusion

@@ -691,10 +691,10 @@ class FusedSampler:
     def lowprec_steps(self, T: int, guided=False, ddim: bool = True) -> int:
         """How many LEADING steps of a T-step fused loop run on plain f16 operands (EgoHMR.f16x3_last_steps).  `guided` = number of
         collision-guided steps at the END of the loop (True = unknown).  The guidance feeds nearest-vertex switches back with gain, so
-        the f16 steps must end well before the first guided one: the last 0.4 T steps ahead of it also run in f16x3.  Measured
+        the f16 steps must end well before the first guided one: the 20 steps ahead of it also run in f16x3.  Measured
         (tools/precision_schedule.py --guided, profiles/r02_precision_schedule_ddpm100_guided_b128.jsonl): DDPM-100 at B=128 stays
         within 1.3e-5 m of the all-f16x3 run for every k >= 12 (1e-6 for two seeds of three; the third has one body at a
-        nearest-vertex switch and shows the same 1.2e-5 at k = 60), and x_t inside the guided steps within 8e-5 at k = 50; on the
+        nearest-vertex switch and shows the same 1.2e-5 at k = 60), and x_t inside the guided steps within 1.4e-4 at k = 30; on the
         DDPM-50 guided golden the guided-step trace moves by 3.5e-3 at k = 20 and by 2.2e-4 at k = 30 (final vertices 6e-6 / 2e-6)."""
         k = self.model.f16x3_last_steps
         if k is None or self.model.gcn_precision != "f16x3":
@@ -712,7 +712,7 @@ class FusedSampler:
             else:
                 k = max(8, -(-2 * T // 25))      # ancestral sampling contracts harder: DDPM-100 k = 8 -> <= 3.9e-6 m over 4 seeds (k = 5: 7.4e-6)
             if n_guided:
-                k = max(k, n_guided + -(-2 * T // 5))
+                k = max(k, n_guided + 20)
         return max(0, T - int(k))
 
     # ------------------------------------------------------------------ S samples of one batch in ONE loop

@@ -32,7 +32,8 @@ WORKLOADS = {
     "c2_ddim10": (100, "ddim10", "BASELINE config 2: B256 S1 DDIM-10 N4096 ResNet50+PointNet cond, diffuse_fuse, LBS every step"),
     "c1_ddim5": (50, "ddim5", "BASELINE config 1 shape: DDIM-5 of 50"),
     # BASELINE config 3: B128 items x 10 samples, full 100-step DDPM, collision guidance on the last 11 steps (proxy loss);
-    # a "step" = one batch of items = 10 guided sampling loops over ONE conditioning pass (the reference re-encodes per sample)
+    # a "step" = one batch of items = its 10 guided samples, run as ONE fused loop over 1280 bodies on ONE conditioning pass (the reference
+    # runs 10 sequential loops and re-encodes in every step of each)
     "c3_guided": (100, "", "BASELINE config 3: B128 x S10 DDPM-100, collision-guided (last 11 steps), conditioning encoded once per item"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak

@@ -91,6 +91,33 @@ def test_smpl_forward_vs_oracle(dev, smpl_asset, B):
     np.testing.assert_allclose(out.joints.cpu().numpy(), ref.joints.numpy(), atol=5e-6)
 
 
+@pytest.mark.parametrize("B", [3, 40])
+def test_smpl_forward_dense_skinning_weights(dev, smpl_asset, B):
+    """An asset whose vertices carry MORE than four non-zero skinning weights (not true of SMPL, true of some derived models): the
+    library must notice (no sparse-4 packing, no matrix-core skinning fragments) and still match the oracle through the dense path."""
+    from egohmr_amd import smpl as smpl_mod
+    from oracle import geometry as ogeo
+    from oracle.smpl import SMPLOracle
+    asset = dict(smpl_asset)
+    g = np.random.Generator(np.random.PCG64(77))
+    w = np.array(asset["lbs_weights"], dtype=np.float64).copy()
+    rows = g.choice(w.shape[0], size=w.shape[0] // 3, replace=False)          # a third of the vertices: six non-zeros
+    for v in rows:
+        js = g.choice(w.shape[1], size=6, replace=False)
+        w[v] = 0.0
+        w[v, js] = g.uniform(0.05, 1.0, size=6)
+        w[v] /= w[v].sum()
+    asset["lbs_weights"] = w.astype(np.float32)
+    assert int((w > 0).sum(1).max()) == 6
+    R = ogeo.rot6d_to_rotmat(torch.from_numpy(g.normal(size=(B * 24, 6)).astype(np.float32)), "diffusion").view(B, 24, 3, 3)
+    betas = torch.from_numpy(g.normal(size=(B, 10)).astype(np.float32))
+    ref = SMPLOracle(asset)(betas=betas, body_pose=R[:, 1:], global_orient=R[:, [0]])
+    m = smpl_mod.create(asset=asset).to(dev)
+    out = m(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, [0]].to(dev), pose2rot=False)
+    np.testing.assert_allclose(out.vertices.cpu().numpy(), ref.vertices.numpy(), atol=5e-6)
+    np.testing.assert_allclose(out.joints.cpu().numpy(), ref.joints.numpy(), atol=5e-6)
+
+
 def test_smpl_identity_pose_properties(dev, smpl_asset):
     """Algebraic pins for the (reference-unpinned) LBS: identity pose => verts = v_shaped, joints = J;
     a global rotation rotates everything rigidly about the root joint."""

@@ -198,7 +198,9 @@ def main():
         fs.invalidate()                                                              # conditioning is part of the job: re-encode
         # the S samples of an item share its conditioning and are independent given it: one fused loop over S*B bodies
         # (FusedSampler.run_samples; bit-equal to S sequential loops, tests/test_gpu_api.py)
-        outs = fs.run_samples(diffusion, batch, noises[:S], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0)
+        # defer_status: the chain-status word of this call is read when the next call starts (and by check_status() behind the timed
+        # region) instead of with a host wait at the end of every call
+        outs = fs.run_samples(diffusion, batch, noises[:S], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0, defer_status=True)
         packs = [edist.pack_params(o["other_outputs"]["pred_smpl_params"]) for o in outs]
         return edist.gather_packed(torch.cat(packs, 0)), outs[-1]
 
@@ -211,6 +213,7 @@ def main():
     for _ in range(args.steps):
         gathered, res = one_step()
     torch.cuda.synchronize()
+    fs.check_status()                                                                # (inside the timed region: the last call's status word)
     edist.barrier()
     torch.cuda.synchronize()
     dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
@@ -234,6 +237,7 @@ def main():
                 t1 = time.perf_counter()
                 _, r = one_step()
                 torch.cuda.synchronize()
+                fs.check_status()
                 d = time.perf_counter() - t1
             finally:
                 model.gcn_precision, model.f16x3_last_steps = old

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "ehm_gcn_hidden_layer": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "ehm_gcn_hidden_stack": (_I, [_P, C.POINTER(C.c_void_p), _L, C.POINTER(C.c_int), _P]),
     "ehm_gcn_stack_status": (_I, [_P, _P]),
+    "ehm_gcn_stack_status_async": (_I, [_P, _P, _P]),
     "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "ehm_linear_split": (_I, [C.POINTER(LinearDesc), _P]),
     "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),

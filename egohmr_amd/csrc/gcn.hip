@@ -709,6 +709,13 @@ extern "C" int ehm_gcn_stack_status(ehm_gcn* h, void* stream) {
   return 0;
 }
 
+extern "C" int ehm_gcn_stack_status_async(ehm_gcn* h, uint32_t* host_flag, void* stream) {
+  EHM_CHECK_ARG(h && host_flag);
+  if (h->chain_sticky) EHM_HIP(hipMemcpyAsync(host_flag, h->chain_sticky, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  else *host_flag = 0u;
+  return 0;
+}
+
 int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad) {
   if (rows_pad <= h->reserved_rows) return 0;
   const size_t need = 8 + (size_t)(h->num_hidden > 0 ? h->num_hidden : 1) * (size_t)ceil_div(rows_pad, BM) + 8;

@@ -717,7 +717,7 @@ class FusedSampler:
 
     # ------------------------------------------------------------------ S samples of one batch in ONE loop
     @torch.no_grad()
-    def run_samples(self, diffusion, batch, noise_stacks, ddim=False, guided=False, cond_grad_weight=1.0):
+    def run_samples(self, diffusion, batch, noise_stacks, ddim=False, guided=False, cond_grad_weight=1.0, defer_status=False):
         """The reference draws S samples per item with S sequential sampling loops over the same batch (test_egohmr.py:251-266).  The
         samples are independent given the conditioning, so this runs them as ONE loop over S*B bodies (sample-major: body s*B + b) with
         the conditioning replicated by index - the same arithmetic per body (the guidance denominator stays B), S times fewer launches
@@ -725,7 +725,8 @@ class FusedSampler:
         S = len(noise_stacks)
         st = self.prepare(batch)
         if S == 1:
-            return [self.run(diffusion, batch, noise_stacks[0], ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=st)]
+            return [self.run(diffusion, batch, noise_stacks[0], ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=st,
+                             defer_status=defer_status)]
         B = st.B
         rep = lambda t: t.repeat(S, *([1] * (t.dim() - 1))).contiguous()
         fields = {k: (rep(v) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B and k not in ("mask_items", "mask_slot") else v)
@@ -741,7 +742,8 @@ class FusedSampler:
         r.inputs = st.inputs
         T = diffusion.num_timesteps
         noise = torch.cat([_lib.f32(n, self.model.device)[: T + 1] for n in noise_stacks], dim=1)
-        res = self.run(diffusion, dict(batch), noise, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=r, denom_items=B)
+        res = self.run(diffusion, dict(batch), noise, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=r, denom_items=B,
+                       defer_status=defer_status)
 
         def split(x):
             if torch.is_tensor(x):
@@ -762,13 +764,17 @@ class FusedSampler:
 
     # ------------------------------------------------------------------ whole loop
     @torch.no_grad()
-    def run(self, diffusion, batch, noise_stack, ddim=False, guided=False, cond_grad_weight=1.0, trace=False, prepared=None, denom_items=None):
+    def run(self, diffusion, batch, noise_stack, ddim=False, guided=False, cond_grad_weight=1.0, trace=False, prepared=None, denom_items=None,
+            defer_status=False):
         """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
         Returns the reference's dict(sample, pred_xstart, other_outputs)."""
         m, L = self.model, _lib.lib()
         if m.diffusion_model.nonlocal_layer:
             raise _lib.EgoHMRHipError("the one-call sampling loop does not carry the optional non-local GCN block; "
                                       "use GaussianDiffusion.p_sample_loop / ddim_sample_loop (they take the step-wise route for such a model)")
+        ev = getattr(self, "_status_event", None)
+        if ev is not None and ev.query():                 # a deferred status word of an earlier call has arrived: look at it now
+            self.check_status()
         st = prepared if prepared is not None else self.prepare(batch)
         B, T, hid, V = st.B, diffusion.num_timesteps, m.diffusion_model.hid_dim, m.smpl.num_verts
         noise = _lib.f32(noise_stack, m.device)
@@ -851,6 +857,27 @@ class FusedSampler:
         # a chained launch that gave up on a producer wait (GPU shared / preempted) flags the handle instead of hanging: one read-back
         # per sampling call (the call's only host wait, after everything has been enqueued) turns that into an exception rather than
         # silently wrong bodies
+        # defer_status (throughput pipelines that keep batches in flight): the word is copied to pinned memory in stream order and
+        # looked at by the NEXT call / by check_status(); the host does not wait here.  The flag is sticky on the device.
         with torch.cuda.device(dev):
-            _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
+            if defer_status:
+                if getattr(self, "_status_host", None) is None:
+                    self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                _lib.check(L.ehm_gcn_stack_status_async(gcn, self._status_host.data_ptr(), _lib.stream_ptr()), "ehm_gcn_stack_status_async")
+                self._status_event = torch.cuda.Event()
+                self._status_event.record()
+            else:
+                _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
         return {"sample": x_final, "pred_xstart": x0, "other_outputs": out}
+
+    def check_status(self):
+        """Raise if a sampling call issued with defer_status=True flagged its chained launches (see run()).  Waits for that call."""
+        ev = getattr(self, "_status_event", None)
+        if ev is None:
+            return
+        ev.synchronize()
+        self._status_event = None
+        if int(self._status_host[0]) != 0:
+            self._status_host.zero_()
+            with torch.cuda.device(self.model.device):
+                _lib.check(_lib.lib().ehm_gcn_stack_status(self.gcn(), _lib.stream_ptr()), "ehm_gcn_stack_status")

@@ -155,6 +155,10 @@ int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t rows_pad, int
  * producer wait or an unproduced tile (never expected; the kernel gives up instead of hanging the device, and audits its own
  * completion).  0 = fine, -5 = the results computed since the previous call are invalid. */
 int ehm_gcn_stack_status(ehm_gcn* h, void* stream);
+/* The same word copied to *host_flag (pinned host memory owned by the caller) in stream order WITHOUT synchronising: a pipeline that
+ * keeps batches in flight looks at *host_flag once the stream has passed this point (an event), and calls ehm_gcn_stack_status to
+ * report and clear when it is non-zero.  The flag is sticky on the device, so nothing is lost by looking late. */
+int ehm_gcn_stack_status_async(ehm_gcn* h, uint32_t* host_flag, void* stream);
 
 /* gconv_output (modulated_gcn.py:113) + the visibility fuse of egohmr.py:247-256:
  *   x0[b, j*6+c] = vis[b,j] ? out_cond[b,j,c] : out_uncond[b,j,c]      (passes == 2)

@@ -183,6 +183,25 @@ def test_run_samples_equals_sequential_runs(dev, model, guided):
     assert float((seq[0]["sample"] - seq[1]["sample"]).abs().max()) > 1e-3              # different noise, different samples
 
 
+def test_deferred_status_pipeline(dev, model):
+    """run(..., defer_status=True): no host wait at the end of the call; the chain-status word is looked at by the next call or by
+    check_status().  Same results as the synchronous route."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    B = 4
+    b = _batch(dev, B)
+    noise = torch.from_numpy(syn.make_noise_stack(5, B, seed=41)).to(dev)
+    fs = model.fused_sampler
+    ref = fs.run(d, b, noise, ddim=True)
+    outs = [fs.run(d, b, noise, ddim=True, defer_status=True) for _ in range(3)]
+    assert fs._status_event is not None
+    fs.check_status()
+    assert fs._status_event is None and int(fs._status_host[0]) == 0
+    for o in outs:
+        assert torch.equal(o["other_outputs"]["pred_vertices"], ref["other_outputs"]["pred_vertices"])
+    fs.check_status()                                                        # idempotent
+
+
 def test_error_behaviour(dev, model):
     from egohmr_amd import _lib
     from egohmr_amd.diffusion import create_gaussian_diffusion

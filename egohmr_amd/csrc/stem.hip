@@ -23,14 +23,24 @@ namespace {
 
 constexpr int SP_L = 5, SP_X = 8;     // left / top padding, total extra columns / rows of the scratch image
 
-__global__ void stem_pad_kernel(const float* __restrict__ img, float* __restrict__ pad, int H, int W, long long total) {
+// one thread = four consecutive columns of the padded image (W + 8 is a multiple of 4: one 16-byte store)
+__global__ __launch_bounds__(256) void stem_pad_kernel(const float* __restrict__ img, float* __restrict__ pad, int H, int W, long long total4) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int Wp = W + SP_X, Hp = H + SP_X;
-  const int c = (int)(i % Wp), r = (int)((i / Wp) % Hp);
-  const long long plane = i / ((long long)Wp * Hp);
-  const int sr = r - SP_L, sc = c - SP_L;
-  pad[i] = (sr >= 0 && sr < H && sc >= 0 && sc < W) ? img[(plane * H + sr) * W + sc] : 0.f;
+  if (i >= total4) return;
+  const int Wp4 = (W + SP_X) / 4, Hp = H + SP_X;
+  const int c0 = 4 * (int)(i % Wp4), r = (int)((i / Wp4) % Hp);
+  const long long plane = i / ((long long)Wp4 * Hp);
+  const int sr = r - SP_L;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (sr >= 0 && sr < H) {
+    const float* src = img + (plane * H + sr) * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int sc = c0 + k - SP_L;
+      if (sc >= 0 && sc < W) v[k] = src[sc];
+    }
+  }
+  *(f32x4*)(pad + 4 * i) = v;
 }
 
 typedef const float __attribute__((address_space(4))) cfloat;
@@ -169,8 +179,8 @@ extern "C" int ehm_resnet_stem(const float* img, const float* Wt, const float* b
     return EHM_EINVAL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const long long total = (long long)N * 3 * (H + SP_X) * (W + SP_X);
-  hipLaunchKernelGGL(stem_pad_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, img, scratch, H, W, total);
+  const long long total4 = (long long)N * 3 * (H + SP_X) * ((W + SP_X) / 4);
+  hipLaunchKernelGGL(stem_pad_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, img, scratch, H, W, total4);
   EHM_LAUNCH_CHECK();
   const int strips = W / 32, chunks = H / 32, tasks = N * strips * chunks;
   hipLaunchKernelGGL(stem_conv_pool_kernel, dim3((unsigned)ceil_div(tasks, 4)), dim3(256), 0, st, scratch, Wt, bias, y, H, W, strips, chunks,

@@ -256,126 +256,10 @@ __global__ __launch_bounds__(256, 2) void gcn_hidden_kernel(const float* __restr
 // input conv with the step-invariant projections hoisted (see ehm_gcn_input_layer in the header)
 // one wave = one virtual body x 64 channels; 4 waves per block = 4 channel groups
 // ------------------------------------------------------------------------------------------------
-template <int OUT>   // 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows
-__global__ __launch_bounds__(256) void gcn_input_kernel(const float* __restrict__ h_img, const float* __restrict__ h_oth,
-                                                        const uint8_t* __restrict__ vis, const float* __restrict__ x,
-                                                        const float* __restrict__ Wx, const float* __restrict__ tvec,
-                                                        LayerDev L, float* __restrict__ Y, int B, int passes, int mask_all,
-                                                        const int32_t* __restrict__ mask_items) {
-  const int N = L.N;
-  const int vb = blockIdx.x;           // virtual body: [0, B) = conditional pass of item vb; B + k = second pass of item mask_items[k] (or k)
-  const int p = vb >= B ? 1 : 0, b = p ? (mask_items ? mask_items[vb - B] : vb - B) : vb;
-  const int n_raw = blockIdx.y * 256 + threadIdx.x;
-  const int n = n_raw < N ? n_raw : N - 1;                        // lanes past N recompute the last channel; their stores are dropped
-  float base[2], img[2], wx[2][6];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    base[k] = ((p == 1 && mask_all) ? 0.f : h_oth[((size_t)b * 2 + k) * N + n]) + tvec[k * N + n];   // egohmr.py:150-158 force_mask: image part only / whole condition
-    img[k] = (p == 0) ? h_img[((size_t)b * 2 + k) * N + n] : 0.f;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) wx[k][c] = Wx[(k * 6 + c) * N + n];
-  }
-  const float* xb = x + (size_t)b * kPoseDim;   // wave-uniform -> scalar loads
-  const uint8_t* vb_ = vis + (size_t)b * kJ;
-  float h0[kJ], h1[kJ];
-  const float sh = L.shift[n];
-#pragma unroll
-  for (int j = 0; j < kJ; ++j) {
-    const float v = vb_[j] ? 1.f : 0.f;
-    float s0 = fmaf(v, img[0], base[0]), s1 = fmaf(v, img[1], base[1]);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const float xv = xb[j * 6 + c];
-      s0 = fmaf(xv, wx[0][c], s0);
-      s1 = fmaf(xv, wx[1][c], s1);
-    }
-    h0[j] = fmaf(L.D[j * N + n], s0, sh);
-    h1[j] = L.M1[j * N + n] * s1;
-  }
-  // 24x24 adjacency mix per lane (one channel), then through a float [24][256] LDS tile so that the rows leave as 16-byte stores
-  // (one dword per lane and joint is store-issue bound: 30 us for 48 MiB).
+template <int OUT>
+__global__ __launch_bounds__(256) void gcn_input_kernel(GcnInputArgs a) {
   __shared__ __attribute__((aligned(16))) float T[kJ * 256];
-  if constexpr (OUT == 2) {
-    // 'f16' mode: the mix on the matrix cores, [Aoff | I] (24 x 48) x [h1; h0] (48 x channels) like the hidden convs' epilogue (gcn_tile.hip).
-    // A lane owns all 48 k of ONE channel; v_permlane32_swap of its k-blocks 2s / 2s+1 yields the B fragments of the wave's lower 32
-    // channels (P) and upper 32 channels (Q).  6 MFMA + ~100 VALU per wave instead of 576 v_fmac per lane.
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    f32x16 DA, DB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { DA[r] = 0.f; DB[r] = 0.f; }
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-      const half8 af = ((const half8*)L.AoffH)[s3 * 64 + lane];
-      u32x4_t Pw, Qw;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kp = 16 * s3 + 2 * e, kq = kp + 8;             // < 24: h1[k], else h0[k - 24]
-        const float p0 = kp < kJ ? h1[kp] : h0[kp - kJ], p1 = kp + 1 < kJ ? h1[kp + 1] : h0[kp + 1 - kJ];
-        const float q0 = kq < kJ ? h1[kq] : h0[kq - kJ], q1 = kq + 1 < kJ ? h1[kq + 1] : h0[kq + 1 - kJ];
-        const half2_t hp = {(half_t)fminf(fmaxf(p0, -65504.f), 65504.f), (half_t)fminf(fmaxf(p1, -65504.f), 65504.f)};
-        const half2_t hq = {(half_t)fminf(fmaxf(q0, -65504.f), 65504.f), (half_t)fminf(fmaxf(q1, -65504.f), 65504.f)};
-        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, hp), __builtin_bit_cast(unsigned int, hq), false, false);
-        Pw[e] = sw[0];
-        Qw[e] = sw[1];
-      }
-      DA = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, Pw), DA, 0, 0, 0);
-      DB = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, Qw), DB, 0, 0, 0);
-    }
-    const bool relu = L.relu != 0;
-    const int cA = 64 * wv + (lane & 31), half = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 12; ++r) {                               // D row = (r&3) + 8 (r>>2) + 4 half = joint; r >> 2 == 3 is padding
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float va = relu ? fmaxf(DA[r], 0.f) : DA[r], vb = relu ? fmaxf(DB[r], 0.f) : DB[r];
-      T[j * 256 + cA] = va;
-      T[j * 256 + cA + 32] = vb;
-    }
-  } else {
-    typedef const float __attribute__((address_space(4))) cfloat;
-    const cfloat* Ac = (const cfloat*)(uintptr_t)L.Aoff;
-    const bool relu = L.relu != 0;
-#pragma unroll
-    for (int j = 0; j < kJ; ++j) {
-      float sacc = h0[j];
-#pragma unroll
-      for (int jp = 0; jp < kJ; ++jp) sacc = fmaf(Ac[j * kJ + jp], h1[jp], sacc);
-      if (relu) sacc = fmaxf(sacc, 0.f);
-      T[j * 256 + threadIdx.x] = sacc;
-    }
-  }
-  __syncthreads();
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int nb = blockIdx.y * 256;                               // first channel of this block (N % 256 may leave a partial block)
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int u = threadIdx.x + 256 * i, j = u >> 5, c8 = (u & 31) * 8;   // (joint, 8 consecutive channels)
-    if (nb + c8 >= N) continue;
-    const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
-    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    const size_t row = (size_t)vb * kJ + j;
-    if (OUT != 0) {
-      half8 hh, ll;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
-        hh[k] = (half_t)c;
-        ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
-      }
-      if (OUT == 1) {
-        half_t* p = (half_t*)Y + split_off<32>(row, nb + c8, N);   // the eight hi halves are contiguous, the lo halves 32 further
-        *(u32x4*)p = __builtin_bit_cast(u32x4, hh);
-        *(u32x4*)(p + 32) = __builtin_bit_cast(u32x4, ll);
-      } else {
-        *(u32x4*)((half_t*)Y + row * (size_t)N + nb + c8) = __builtin_bit_cast(u32x4, hh);
-      }
-    } else {
-      float* p = Y + row * (size_t)N + nb + c8;
-      *(f32x4*)p = v0;
-      *(f32x4*)(p + 4) = v1;
-    }
-  }
+  gcn_input_body<OUT>(T, blockIdx.x, blockIdx.y, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,18 +520,30 @@ extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
   delete h;
 }
 
+// fills the launch arguments of the input conv for the handle's current precision / pass map (shared with smpl.hip's fused launch)
+int ehm_gcn_input_args(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x, const float* Wx, const float* tvec,
+                       float* out, int B, int passes, GcnInputArgs* a) {
+  EHM_CHECK_ARG(h && h_img && h_oth && vis && x && Wx && tvec && out && a);
+  EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
+  a->h_img = h_img; a->h_oth = h_oth; a->vis = vis; a->x = x; a->Wx = Wx; a->tvec = tvec;
+  a->L = h->input;
+  a->Y = out;
+  a->B = B; a->passes = passes; a->mask_all = h->uncond_masks_all;
+  a->mask_items = (passes == 2 && h->num_masked >= 0) ? h->mask_items : nullptr;
+  a->total_vb = ehm_gcn_virtual_bodies(h, B, passes);
+  a->ny = (int)ceil_div(h->hid, 256);
+  return 0;
+}
+
 extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x,
                                    const float* Wx, const float* tvec, float* out, int B, int passes, void* stream) {
-  EHM_CHECK_ARG(h && h_img && h_oth && vis && x && Wx && tvec && out);
-  EHM_CHECK_ARG(B > 0 && (passes == 1 || passes == 2));
-  dim3 grid((unsigned)ehm_gcn_virtual_bodies(h, B, passes), (unsigned)ceil_div(h->hid, 256));
-  const int32_t* mi = (passes == 2 && h->num_masked >= 0) ? h->mask_items : nullptr;
-  if (h->precision == EHM_PREC_F32)
-    hipLaunchKernelGGL(gcn_input_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes, h->uncond_masks_all, mi);
-  else if (h->precision == EHM_PREC_F16X3)   // the activation matrices travel in the X2 split format (same byte size as float32)
-    hipLaunchKernelGGL(gcn_input_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes, h->uncond_masks_all, mi);
-  else                                       // plain f16 rows
-    hipLaunchKernelGGL(gcn_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, h_img, h_oth, vis, x, Wx, tvec, h->input, out, B, passes, h->uncond_masks_all, mi);
+  GcnInputArgs a;
+  const int rc = ehm_gcn_input_args(h, h_img, h_oth, vis, x, Wx, tvec, out, B, passes, &a);
+  if (rc != 0) return rc;
+  dim3 grid((unsigned)a.total_vb, (unsigned)a.ny);
+  if (h->precision == EHM_PREC_F32) hipLaunchKernelGGL(gcn_input_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL(gcn_input_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);   // X2 split rows
+  else hipLaunchKernelGGL(gcn_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);                                        // plain f16 rows
   EHM_LAUNCH_CHECK();
   return 0;
 }

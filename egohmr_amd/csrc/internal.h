@@ -14,10 +14,14 @@ int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const fl
 int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
                        const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int do_pose,
                        const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
-                       float* pose6d, int B, hipStream_t st);
+                       float* pose6d, int B, hipStream_t st, const struct GcnInputArgs* next_input = nullptr, int next_prec = 0,
+                       int* fused = nullptr);
 int ehm_smpl_num_verts(const ehm_smpl* h);
 int ehm_smpl_num_extra(const ehm_smpl* h);
 // gcn.hip
+struct GcnInputArgs;
+int ehm_gcn_input_args(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x, const float* Wx, const float* tvec,
+                       float* out, int B, int passes, GcnInputArgs* a);
 int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
 int ehm_gcn_virtual_bodies(const ehm_gcn* h, int B, int passes);   // B + second passes after pruning (ehm_gcn_set_pass_map)

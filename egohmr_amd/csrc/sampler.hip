@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "egohmr_hip.h"
+#include "gcn_dev.h"
 #include "internal.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -164,9 +165,11 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   int rc = 0;
   const int base_prec = ehm_gcn_get_precision(gcn);
   const int lowprec = base_prec == 1 /* f16x3 */ ? d->lowprec_steps : 0;
+  auto prec_of = [&](int k) { return (lowprec > 0 && k < lowprec) ? 2 : base_prec; };
+  bool input_done = false;          // step k's input conv already ran inside step k-1's skinning launch
   for (int k = 0; k < d->num_steps && rc == 0; ++k) {
     const ehm_step_coefs& c = steps[k];
-    if (lowprec > 0) ehm_gcn_set_precision(gcn, k < lowprec ? 2 : base_prec);   // host-side kernel choice only; same X2 buffers
+    if (lowprec > 0) ehm_gcn_set_precision(gcn, prec_of(k));   // host-side kernel choice only; same X2 buffers
     const bool last = k == d->num_steps - 1;
     if (trace) EHM_HIP(hipMemcpyAsync(trace + (int64_t)k * n, w.x_cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     // ---- collision guidance on x_t (gaussian_diffusion.py:378-385, egohmr.py:517-570): depends on x_t and betas only, so it runs first
@@ -177,7 +180,8 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
       grad = w.g_grad;
     }
     // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257): input conv, chained hidden convs, output conv responses ----
-    if (rc == 0) rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
+    if (rc == 0 && !input_done) rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
+    input_done = false;
     int in = 0;
     if (rc == 0) rc = ehm_gcn_hidden_stack(gcn, w.X, w.rows_pad, &in, st);
     const float* hs = nullptr;
@@ -185,12 +189,24 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     if (rc == 0) rc = ehm_gcn_output_dot_impl(gcn, w.X[in], B, d->passes, &hs, &out_dev, st);
     // ---- per body, one launch: output-conv mix + visibility fuse -> x0 (egohmr.py:247-256), x_{t-1} (gaussian_diffusion.py:298-337 /
     //      :511-556), de-normalise + rot6d + kinematic chain (egohmr.py:258-260); then the skinning launch (egohmr.py:276) ----
+    //      When the step is not the last one, the NEXT step's input conv (it needs x_{t-1} only) rides in the skinning launch.
     if (rc == 0) {
       const float* eps = noise + (int64_t)(1 + k) * n;
       float* dst = last ? x_final : w.x_cur;
-      rc = ehm_step_body_impl(smpl, hs, out_dev, vis, w.x_cur, eps, grad, dst, x0_final, &c, d->ddim, d->passes, ehm_gcn_mask_slot(gcn, d->passes),
-                              (d->lbs_every_step || last) ? 1 : 0,
-                              betas, mean, std_, verts, joints, R, w.A, pose6d, B, st);
+      GcnInputArgs nin;
+      const GcnInputArgs* pnin = nullptr;
+      if (!last && d->lbs_every_step) {              // X[0] is free: the chain has consumed it and, if its result landed there, so has the output conv
+        if (lowprec > 0) ehm_gcn_set_precision(gcn, prec_of(k + 1));   // the activation format the next step's convs will read
+        rc = ehm_gcn_input_args(gcn, h_img, h_oth, vis, dst, Wx, tvecs + (int64_t)(k + 1) * 2 * hid, w.X[0], B, d->passes, &nin);
+        if (lowprec > 0) ehm_gcn_set_precision(gcn, prec_of(k));
+        pnin = &nin;
+      }
+      int fused = 0;
+      if (rc == 0)
+        rc = ehm_step_body_impl(smpl, hs, out_dev, vis, w.x_cur, eps, grad, dst, x0_final, &c, d->ddim, d->passes, ehm_gcn_mask_slot(gcn, d->passes),
+                                (d->lbs_every_step || last) ? 1 : 0,
+                                betas, mean, std_, verts, joints, R, w.A, pose6d, B, st, pnin, prec_of(k + 1), &fused);
+      input_done = fused != 0;
     }
   }
   if (lowprec > 0) ehm_gcn_set_precision(gcn, base_prec);

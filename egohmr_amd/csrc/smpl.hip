@@ -344,12 +344,21 @@ __device__ unsigned long long* g_sdbg = nullptr;
 #define SSTAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restrict__ PF, const float* __restrict__ A, SmplDev S,
-                                                        float* __restrict__ verts, float* __restrict__ joints, int B, int v_tiles, int vt_groups) {
-  __shared__ __attribute__((aligned(16))) float sA[32][kJ][12];   // 36 KiB: skinning transforms of the block's 32 bodies
+struct SkinArgs {
+  const sk_half8* PF; const float* A; SmplDev S;
+  float* verts; float* joints;
+  int B, v_tiles, vt_groups;
+};
+
+// One block (256 threads) of the matrix-core skinning; sA = 32 * 24 * 12 floats (36 KiB) of LDS: the skinning transforms of the block's
+// 32 bodies.  `bid` = block index within the skinning grid (also launched as part of skin_input_kernel below).
+__device__ __forceinline__ void skin_mfma_body(float (*sA)[kJ][12], int bid, const SkinArgs& a) {
+  const sk_half8* __restrict__ PF = a.PF; const float* __restrict__ A = a.A; const SmplDev& S = a.S;
+  float* __restrict__ verts = a.verts; float* __restrict__ joints = a.joints;
+  const int B = a.B, v_tiles = a.v_tiles, vt_groups = a.vt_groups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order: the blocks of one XCD walk the body tiles of the same vertex-tile group back to back (basis fragments from L2)
-  const int bid = blockIdx.x, xcd = bid & 7, kk = bid >> 3;
+  const int xcd = bid & 7, kk = bid >> 3;
   const int b_tiles = (B + 31) / 32;
   const int vg = (kk / b_tiles) * 8 + xcd, bt = kk % b_tiles;
   if (vg >= vt_groups) return;
@@ -447,6 +456,26 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(const sk_half8* __restri
     }
   }
   SSTAMP(3);
+}
+
+__global__ __launch_bounds__(256) void skin_mfma_kernel(SkinArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[32][kJ][12];
+  skin_mfma_body(sA, blockIdx.x, a);
+}
+
+// The skinning of step t and the input conv of step t + 1 in ONE launch: both depend only on step_body_kernel(t), neither on the other,
+// and both are latency-shaped (25 us and 20 us at B = 256 for 21 MB / 25 MB of output).  Blocks [0, skin_blocks) skin, the rest
+// run the input conv (gcn_dev.h: gcn_input_body); one 36 KiB LDS buffer serves either.  Separate streams for the two cost more in
+// cross-stream events than they overlapped (measured: -7 %), a second kernel boundary costs 2.6 us.
+template <int OUT>
+__global__ __launch_bounds__(256) void skin_input_kernel(SkinArgs a, GcnInputArgs g, int skin_blocks) {
+  __shared__ __attribute__((aligned(16))) float sbuf[32 * kJ * 12];
+  if ((int)blockIdx.x < skin_blocks) {
+    skin_mfma_body((float (*)[kJ][12])sbuf, blockIdx.x, a);
+  } else {
+    const int i = blockIdx.x - skin_blocks;
+    gcn_input_body<OUT>(sbuf, i / g.ny, i % g.ny, g);
+  }
 }
 #ifdef EHM_STAMPS
 extern "C" int ehm_dbg_set_skin(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sdbg), &q, sizeof(q)); }
@@ -624,8 +653,8 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
                        (sk_half8*)h->pf, B, b_tiles);
     const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
     const int blocks = (int)round_up(vt_groups, 8) * b_tiles;
-    hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B,
-                       v_tiles, vt_groups);
+    SkinArgs sa{(const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B, v_tiles, vt_groups};
+    hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, sa);
   } else {
     const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
     const int blocks = (int)round_up(v_tiles, 8) * b_groups;
@@ -749,8 +778,9 @@ __global__ __launch_bounds__(64) void step_body_kernel(StepBodyArgs a, SmplDev S
 int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
                        const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int do_pose,
                        const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
-                       float* pose6d, int B, hipStream_t st) {
+                       float* pose6d, int B, hipStream_t st, const GcnInputArgs* next_input, int next_prec, int* fused) {
   const SmplDev& d = h->d;
+  if (fused) *fused = 0;
   static const int mfma_min = getenv("EHM_SKIN_MFMA_MIN_B") ? atoi(getenv("EHM_SKIN_MFMA_MIN_B")) : 24;
   const bool mfma = d.PDf && B >= mfma_min;
   const int b_tiles = (int)ceil_div(B, 32);
@@ -773,8 +803,16 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
     if (mfma) {
       const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
       const int blocks = (int)round_up(vt_groups, 8) * b_tiles;
-      hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B,
-                         v_tiles, vt_groups);
+      SkinArgs sa{(const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B, v_tiles, vt_groups};
+      if (next_input) {                                       // + the next step's input conv in the same launch
+        const int in_blocks = next_input->total_vb * next_input->ny;
+        if (next_prec == EHM_PREC_F32) hipLaunchKernelGGL(skin_input_kernel<0>, dim3(blocks + in_blocks), dim3(256), 0, st, sa, *next_input, blocks);
+        else if (next_prec == EHM_PREC_F16X3) hipLaunchKernelGGL(skin_input_kernel<1>, dim3(blocks + in_blocks), dim3(256), 0, st, sa, *next_input, blocks);
+        else hipLaunchKernelGGL(skin_input_kernel<2>, dim3(blocks + in_blocks), dim3(256), 0, st, sa, *next_input, blocks);
+        *fused = 1;
+      } else {
+        hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, sa);
+      }
     } else {
       const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
       hipLaunchKernelGGL(skin_kernel, dim3((int)round_up(v_tiles, 8) * b_groups), dim3(kVT), 0, st, betas, Rws, Aws, d, verts, B, v_tiles, b_groups);

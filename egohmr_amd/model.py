@@ -216,7 +216,7 @@ class EgoHMR(nn.Module):
         self.gcn_precision = "f16x3"
         # precision schedule: only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'),
         # the earlier ones on plain f16 operands / f16 activations.  'auto' = max(10, ceil(T / 10)) for T >= 20 (the last tenth of the
-        # schedule), ceil(T / 2) for 10 <= T < 20, off below (errors of earlier steps are contracted away by the posterior mean,
+        # schedule), ceil(0.4 T) for 10 <= T < 20, off below (errors of earlier steps are contracted away by the posterior mean,
         # measured in tools/precision_schedule.py: final bodies within 7e-6 m of the all-f16x3 run at B=256 for DDPM-100 / DDIM-50 /
         # DDIM-10; the parity bar is 1e-4 m); an int = that k; None = off
         self.f16x3_last_steps = "auto"
@@ -706,7 +706,7 @@ class FusedSampler:
             if T < 10:
                 return 0                         # (not measured below ten steps)
             if T < 20:
-                k = -(-T // 2)                   # short loops: the last half (DDIM-10: k = 5 -> <= 4.6e-6 m, 3 seeds x 2 respacings)
+                k = -(-2 * T // 5)               # short loops: the last 40 % (DDIM-10: k = 4 -> <= 5.1e-6 m, k = 5 -> <= 4.6e-6, k = 3 -> <= 7.4e-6; 3 seeds x 2 respacings)
             elif ddim:
                 k = max(10, -(-T // 10))         # DDIM-50: k = 10 -> 6.5e-6 m
             else:

@@ -63,8 +63,15 @@ def test_dump_steps_and_progressive_loop(dev, model):
     assert isinstance(dump, list) and len(dump) == 3
     for got, k in zip(dump, (0, 4, 9)):
         np.testing.assert_allclose(got.cpu().numpy(), steps[k]["sample"].cpu().numpy(), atol=1e-6)
-    fused = model.fused_sampler.run(d, _batch(dev, B), noise, ddim=False)
+    old = model.f16x3_last_steps
+    model.f16x3_last_steps = None                        # route equivalence: the step-wise route has no precision schedule
+    try:
+        fused = model.fused_sampler.run(d, _batch(dev, B), noise, ddim=False)
+    finally:
+        model.f16x3_last_steps = old
     np.testing.assert_allclose(fused["sample"].cpu().numpy(), steps[-1]["sample"].cpu().numpy(), atol=2e-6)
+    sched = model.fused_sampler.run(d, _batch(dev, B), noise, ddim=False)              # default schedule (k = 4 of 10): within its measured error
+    np.testing.assert_allclose(sched["sample"].cpu().numpy(), steps[-1]["sample"].cpu().numpy(), atol=2e-5)
 
 
 def test_skip_timesteps_and_init_data(dev, model):

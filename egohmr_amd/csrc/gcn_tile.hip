@@ -39,7 +39,8 @@ namespace {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RK = 32;                                            // floats per row and K tile = 128 bytes
-constexpr int A_T = 192 * RK, B_T = 128 * RK, STG = A_T + B_T;    // floats; one stage = 40 KiB
+constexpr int A_T = 192 * RK;                                      // floats of a stage's activation region (24 KiB)
+constexpr int stage_floats(int nw) { return A_T + 32 * nw * RK; }  // + weights: 64 channels x 2 branches per 4 waves -> 40 KiB (4 waves) / 56 KiB (8 waves)
 constexpr int kStoreAux = 16;                                     // sc1: activation stores write through to L2 (chained launch hand-off)
 constexpr int kLoadAux = 16;                                      // sc1: activation loads never hit a stale CU-L1 line
 
@@ -99,8 +100,17 @@ __device__ __forceinline__ const float* layer_weights(const LayerDev& L) {
 
 // The engine.  CHAIN = true: persistent blocks, per-XCD ticket queues over (layer, row tile, channel tile) with per-row-tile
 // completion counters (see the header of ehm_gcn_tile_chain_impl); CHAIN = false: one tile per block, one conv per launch.
-template <int P, bool CHAIN, class Args>
+// NW = waves per block.  4: 192 rows x 64 channels per block, two blocks per CU.  8 (f16 chain only): ONE block per CU owns 192 rows x 128
+// channels - the activation tile is staged once for both channel halves, 56 KiB instead of 80 KiB of operands per K tile and CU; with
+// one MFMA per product the K loop is bound by LDS bandwidth (writes + fragment reads), see DESIGN.md 3.2.
+template <int P, bool CHAIN, int NW, class Args>
 __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
+  static_assert(NW == 4 || (NW == 8 && P == 1 && CHAIN), "the 8-wave tile exists for the chained f16 kernel (f16x3 is power-bound: 8 waves measured 150 vs 152 us)");
+  constexpr int NWN = NW / 2;                 // waves across the channels
+  constexpr int NT = 32 * NWN;                // channels per tile
+  constexpr int BROWS = 2 * NT;               // weight rows per stage (W0 | W1 per 64 channels)
+  constexpr int STG = stage_floats(NW);
+  constexpr int NDA = 24 / NW, NDB = BROWS / (8 * NW);   // DMA instructions per wave and stage: activations 6 / 3, weights 4 / 4
   constexpr int KS = P == 3 ? 2 : 4;          // 16-wide k-steps per K tile
   constexpr int NM = P == 3 ? 18 : 6;         // MFMAs per k-step
   constexpr int NR = P == 3 ? 10 : 5;         // ds_read_b128 per k-step
@@ -117,7 +127,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 
   // ---- DMA: one wave instruction = 8 rows x 128 B; physical 16-byte chunk c of row r holds logical chunk c ^ ((r>>1)&7)
   int r0, swz;                                               // r0 = 8 wave + lane / 8; swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2; r0 + 32 i keeps the key
-  const size_t row32 = (size_t)32 * rowf;                    // a wave's consecutive DMA instructions are 32 rows apart
+  const size_t row32 = (size_t)(8 * NW) * rowf;              // a wave's consecutive DMA instructions are 32 (64) rows apart
   const float* pA;
   const float* pB;
   auto io_of = [&](const Tile& t) -> TileIO {
@@ -143,31 +153,45 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   auto set_tile_ptrs = [&](const Tile& t) {
     const TileIO o = io_of(t);
     pA = o.X + ((size_t)t.m_tile * 192 + r0) * rowf + swz;
-    pB = o.W + ((size_t)t.n_tile * 128 + r0) * rowf + swz;
+    pB = o.W + ((size_t)t.n_tile * BROWS + r0) * rowf + swz;
   };
   auto dma_a = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + (wave + 4 * i) * 256), 16, 0, kLoadAux);
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + (wave + NW * i) * 256), 16, 0, kLoadAux);
   };
   auto dma_b = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + A_T + (wave + 4 * i) * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + A_T + (wave + NW * i) * 256), 16, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+    for (int i = 0; i < NDA; ++i) dma_a(buf, kt, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
+    for (int i = 0; i < NDB; ++i) dma_b(buf, kt, i);
   };
-  auto issue_b01 = [&]() {
+  // The first two K tiles of a tile are fetched around the previous tile's epilogue: both weight stages and activation stage 0 before it,
+  // activation stage 1 (whose pieces are the epilogue's scratch) after it = "late" = what a wave issues last = what the head of the K
+  // loop leaves in flight.  (NW = 8: a wave owns only three 1 KiB activation pieces; the other half of its scratch is a dedicated 24 KiB
+  // region behind the stages - 136 KiB of LDS per block - so that the weights of stage 1 need not wait for the epilogue.)
+  constexpr bool B1_LATE = false;
+  constexpr int LATE = NDA + (B1_LATE ? NDB : 0);
+  auto issue_b_early = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
+    for (int i = 0; i < NDB; ++i) dma_b(0, 0, i);
+    if constexpr (!B1_LATE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+      for (int i = 0; i < NDB; ++i) dma_b(1, 1, i);
+    }
   };
-  auto issue_a01 = [&]() {
+  auto issue_a0 = [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+    for (int i = 0; i < NDA; ++i) dma_a(0, 0, i);
+  };
+  auto issue_late = [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+    for (int i = 0; i < NDA; ++i) dma_a(1, 1, i);
+    if constexpr (B1_LATE) {
+#pragma unroll
+      for (int i = 0; i < NDB; ++i) dma_b(1, 1, i);
+    }
   };
 
   // ---- fragments (v_mfma_f32_32x32x16_f16: lane l holds row l&31, k = 8*(l>>5) .. +7 of a 16-wide step = one 16-byte chunk)
@@ -183,13 +207,13 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     asm volatile("" : "+v"(t));                              // opaque: keeps hipcc from hoisting what follows out of the tile loop
     lane = t & 63;
     wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    wm = wave >> 1; wn = wave & 1;
+    wm = wave / NWN; wn = wave % NWN;
     mi = lane & 31; g = lane >> 5;
     odd = lane & 1;
     r0 = 8 * wave + (lane >> 3);
     swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2;
     const int rA = 96 * wm + 48 * ((mi >> 2) & 1) + 24 * (mi & 1) + ((mi >> 1) & 1) + 2 * (mi >> 3);
-    const int rB = 32 * wn + mi;
+    const int rB = NW == 8 ? 128 * (wn >> 1) + 32 * (wn & 1) + mi : 32 * wn + mi;   // 8 waves: 64-channel weight group wn >> 1 of the pair
     const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -261,12 +285,26 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-    } else {                                    // 6 MFMAs: 5 x (MFMA, read, 2 DMA), MFMA
+    } else if constexpr (NW == 4) {             // 6 MFMAs: 5 x (MFMA, read, 2 DMA), MFMA
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    } else {                                    // 7 DMAs: 2 x (MFMA, read, 2 DMA), 3 x (MFMA, read, DMA), MFMA
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+      }
+#pragma unroll
+      for (int i = 2; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
@@ -323,7 +361,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     t_cur = __builtin_amdgcn_readfirstlane(slot[0]);
     __syncthreads();
   } else {
-    const int n_tiles = N / 64, tot = a.m_tiles * n_tiles, bid = blockIdx.x;
+    const int n_tiles = N / NT, tot = a.m_tiles * n_tiles, bid = blockIdx.x;
     const int lin = ((tot & 7) == 0) ? (bid & 7) * (tot >> 3) + (bid >> 3) : bid;   // XCD-aware tile order
     cur.m_tile = lin / n_tiles; cur.n_tile = lin % n_tiles; cur.layer = 0;
   }
@@ -333,9 +371,10 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   if (!CHAIN || t_cur < total) {
     if constexpr (CHAIN) decode(t_cur, cur);
     set_tile_ptrs(cur);
-    issue_b01();
+    issue_b_early();
     poll_deps(cur);
-    issue_a01();
+    issue_a0();
+    issue_late();
   }
 
 #ifdef EHM_STAMPS
@@ -354,7 +393,9 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 #ifdef EHM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stamp stores of lane 0 sit behind the six DMAs)
 #else
-    if (pending_publish) {
+    if constexpr (NW == 8) {
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                         // everything but the three late pieces (the stores are older)
+    } else if (pending_publish) {
       if constexpr (P == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // 12 sixteen-byte stores per wave and tile (X2 hi + lo, or float32)
       else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                   // 6
     } else {
@@ -421,7 +462,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     }
     // ---- last K tile; the per-channel epilogue constants are fetched under its MFMAs
     const TileIO io = io_of(cur);
-    const int n = 64 * cur.n_tile + 32 * wn + mi;
+    const int n = NT * cur.n_tile + 32 * wn + mi;
     const unsigned int n4 = (unsigned int)n * 4u;
     const unsigned int tblrow = (unsigned int)N * 4u;
     float dj[kJ], mj[kJ], sh;
@@ -459,10 +500,9 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
       if (have_next) {
         decode(nt, nxt);
         set_tile_ptrs(nxt);
-        issue_b01();
-        if (ready) {                          // stage 0 now; stage 1's activation pieces serve as the epilogue's scratch first
-#pragma unroll
-          for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+        issue_b_early();
+        if (ready) {                          // stage 0 now; stage 1's pieces serve as the epilogue's scratch first
+          issue_a0();
           a_issued = true;
         }
       }
@@ -482,7 +522,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     // item (it, lane), it = 0..2 per pass: scratch row rl = 16 it + (lane>>2), channels 8 (lane&3) .. +7 of the wave's 32: 16 bytes of f16
     // (32 of float32) per lane, 4 lanes per 64-byte row segment, 16 rows per wave instruction
     const int lr = lane >> 2, c8 = 8 * (lane & 3);
-    const int ch0 = 64 * cur.n_tile + 32 * wn + c8;                        // first channel of my items
+    const int ch0 = NT * cur.n_tile + 32 * wn + c8;                        // first channel of my items
     unsigned int col_in, col_out;                                           // byte offsets of the item's columns: residual / output
     if constexpr (P == 3) col_in = (unsigned int)(((ch0 >> 5) * 64 + (ch0 & 31)) * 2);   // X2: 8 hi halves here, 8 lo halves 64 B on
     else col_in = (unsigned int)ch0 * 2u;
@@ -528,9 +568,12 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     // V[p][k]: value k of pass p; scratch offset of value k = lane part + vimm(k) floats
     float V[2][24];
     int wbase;                                                              // lane part of the scratch write offset (floats)
-    auto vimm = [](int k) {
-      if constexpr (P == 1) { const int beta = k / 12, r = k % 12, c = 24 * beta + (r & 3) + 8 * (r >> 2); return (c >> 3) * 1024 + (c & 7) * 32; }
-      else return (k >> 3) * 1024 + (k & 7) * 32;
+    // a wave's scratch = the 1 KiB pieces of stage 1 that its own late DMA instructions fill: piece p at float offset poff(p) from
+    // STG + wave * 256 (4 waves: six activation pieces; 8 waves: three activation pieces + three of the dedicated region)
+    auto poff = [](int p) { return NW == 8 ? (p < 3 ? p * 2048 : STG + (p - 3) * 2048) : p * 1024; };   // (8 waves: pieces 3..5 in the region behind the stages)
+    auto vimm = [&](int k) {
+      if constexpr (P == 1) { const int beta = k / 12, r = k % 12, c = 24 * beta + (r & 3) + 8 * (r >> 2); return poff(c >> 3) + (c & 7) * 32; }
+      else return poff(k >> 3) + (k & 7) * 32;
     };
     if constexpr (P == 1) {
       // ---- 'f16' mode: the 24 x 24 adjacency mix on the matrix cores.  Per body: out[j][ch] = sum_k [Aoff | I][j][k] * [gp; dp][k][ch], K = 48 =
@@ -601,10 +644,11 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
           V[1][j] = relu ? fmaxf(s1, 0.f) : s1;
         }
       }
-      wbase = STG + wave * 256 + 3072 * g + mi;                  // scratch row 24 g + joint
+      wbase = STG + wave * 256 + (NW == 8 ? STG : 3072) * g + mi;   // scratch row 24 g + joint: pieces 3 g + (joint >> 3) (8 waves: poff(3 + x) - poff(x) = STG)
     }
     TSTAMP(7);
-    const int rbase = STG + wave * 256 + (lr >> 3) * 1024 + (lr & 7) * 32 + c8;   // item it at + 2048 it floats
+    const int rbase = STG + wave * 256 + (lr & 7) * 32 + c8;                      // item it: + piece 2 it + (lr >> 3)
+    auto roff = [&](int it) { return rbase + ((lr >> 3) ? poff(2 * it + 1) : poff(2 * it)); };
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (P == 3) { if (p == 1) load_res_pass(1); }
@@ -614,8 +658,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
       f32x4 t[3][2];
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
-        t[it][0] = *(const f32x4*)(lds + rbase + 2048 * it);
-        t[it][1] = *(const f32x4*)(lds + rbase + 2048 * it + 4);
+        t[it][0] = *(const f32x4*)(lds + roff(it));
+        t[it][1] = *(const f32x4*)(lds + roff(it) + 4);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -650,10 +694,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     }
     // stage 1's activation pieces are free again: fetch them for the next tile
     if constexpr (CHAIN) {
-      if (a_issued) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
-      }
+      if (a_issued) issue_late();
     }
     TSTAMP(4);
 
@@ -672,7 +713,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
         __syncthreads();
         publish(prev);
         poll_deps(nxt);
-        issue_a01();
+        issue_a0();
+        issue_late();
       } else {
         pending_publish = true;                               // bumped at the head of the next tile, behind its vmcnt(0) + barrier
       }
@@ -693,14 +735,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     __syncthreads();
     if (slot[0]) {
       bool ok = true;
-      for (int m = tid; m < a.m_tiles; m += 256)
+      for (int m = tid; m < a.m_tiles; m += 64 * NW)
         ok = ok && __hip_atomic_load(&a.done[(size_t)(a.nl - 1) * a.m_tiles + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)a.n_tiles;
       if (!ok) {
         __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
-      for (int i = tid; i < a.nl * a.m_tiles; i += 256) a.done[i] = 0u;
+      for (int i = tid; i < a.nl * a.m_tiles; i += 64 * NW) a.done[i] = 0u;
       if (tid < 8) a.tickets[tid] = 0u;
       if (tid == 0) *a.finished = 0u;
     }
@@ -709,14 +751,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 
 template <int P>
 __global__ __launch_bounds__(256, 2) void gcn_hidden_tile_kernel(OneArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * STG];   // 80 KiB, the only LDS object: 2 blocks per CU
-  run_tiles<P, false>(lds, a);
+  __shared__ __attribute__((aligned(16))) float lds[2 * stage_floats(4)];   // 80 KiB, the only LDS object: 2 blocks per CU
+  run_tiles<P, false, 4>(lds, a);
 }
 
-template <int P>
-__global__ __launch_bounds__(256, 2) void gcn_hidden_chain_kernel(ChainArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * STG];
-  run_tiles<P, true>(lds, a);
+template <int P, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gcn_hidden_chain_kernel(ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * stage_floats(NW) + (NW == 8 ? 24 * 256 : 0)];   // 80 KiB x 2 blocks, or 112 + 24 KiB x 1 block per CU
+  run_tiles<P, true, NW>(lds, a);
 }
 
 // float32 [rows, K] <-> plain f16 [rows, K]
@@ -798,7 +840,8 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
     ehm_set_error("chained hidden convs need an even number (>= 2) of them");
     return EHM_EINVAL;
   }
-  const int m_tiles = (int)(rows_pad / 192), n_tiles = h->hid / 64;
+  const bool wide = h->precision != EHM_PREC_F16X3 && h->hid % 128 == 0;   // f16 mode: one 8-wave block per CU, 128-channel tiles
+  const int m_tiles = (int)(rows_pad / 192), n_tiles = h->hid / (wide ? 128 : 64);
   const size_t need = 8 + (size_t)nl * m_tiles + 8;   // tickets | done | err, finished
   if (h->chain_sync_words < need) {
     const int rc = ehm_gcn_reserve_rows(h, rows_pad);
@@ -822,13 +865,14 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   a.finished = a.err + 1;
   a.sticky = h->chain_sticky;
   const int total = nl * m_tiles * n_tiles;
-  int blocks = 2 * ehm_num_cus();                      // what is co-resident (80 KiB LDS per block)
+  int blocks = (wide ? 1 : 2) * ehm_num_cus();         // what is co-resident (80 KiB LDS per 4-wave block, 112 KiB per 8-wave block)
   if (blocks > total) blocks = total;
   a.nq = ehm_num_cus() / 32;
   if (a.nq < 1) a.nq = 1;
   if (a.nq > 8) a.nq = 8;
-  if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL(gcn_hidden_chain_kernel<3>, dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(gcn_hidden_chain_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+  if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 4>), dim3(blocks), dim3(256), 0, st, a);
+  else if (wide) hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 8>), dim3(blocks), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 4>), dim3(blocks), dim3(256), 0, st, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -213,6 +213,42 @@ def test_gcn_hidden_layer_vs_oracle(L, dev, hid, bodies, prec):
     L.ehm_gcn_destroy(h)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("hid,bodies", [(192, 40), (320, 9), (256, 33)])
+def test_hidden_stack_chain_tile_shapes(L, dev, hid, bodies, prec):
+    """The chained launch picks its tile by width: hid % 128 == 0 in f16 mode runs the 8-wave 192 x 128 tile, everything else the
+    4-wave 192 x 64 tile (ehm_gcn_tile_chain_impl).  Both must reproduce the per-conv launches (always 192 x 64) bit for bit."""
+    import ctypes as C
+    from egohmr_amd import _lib
+    from egohmr_amd.model import PRECISIONS
+    sds = [_gconv_sd(60 + i, hid, hid) for i in range(4)]
+    h, keep = _native_gcn(L, dev, sds[0], sds, _gconv_sd(42, hid, 6, bn=False), hid)
+    _lib.check(L.ehm_gcn_set_precision(h, PRECISIONS[prec]))
+    tile = L.ehm_gcn_row_tile()
+    rows = bodies * 24
+    rows_pad = (rows + tile - 1) // tile * tile
+    g = torch.Generator(device=dev).manual_seed(5)
+    x0 = torch.relu(torch.randn(rows_pad, hid, device=dev, generator=g)) * 0.5
+    x0[rows:] = 0
+    X0 = torch.empty_like(x0)
+    _lib.check(L.ehm_gcn_pack_activations(x0.data_ptr(), X0.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))
+    ref = [X0.clone(), torch.zeros_like(X0), torch.zeros_like(X0)]
+    cur = 0
+    for blk in range(2):
+        y2 = 2 if cur == 0 else 0
+        _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk, ref[cur].data_ptr(), None, ref[1].data_ptr(), rows_pad, None))
+        _lib.check(L.ehm_gcn_hidden_layer(h, 2 * blk + 1, ref[1].data_ptr(), ref[cur].data_ptr(), ref[y2].data_ptr(), rows_pad, None))
+        cur = y2
+    bufs_t = [X0.clone(), torch.full_like(X0, float("nan")), torch.full_like(X0, float("nan"))]
+    bufs = (C.c_void_p * 3)(*[t.data_ptr() for t in bufs_t])
+    res = C.c_int(-1)
+    _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), None))
+    _lib.check(L.ehm_gcn_stack_status(h, None))
+    assert res.value == cur
+    assert torch.equal(bufs_t[res.value].view(torch.int32), ref[cur].view(torch.int32))
+    L.ehm_gcn_destroy(h)
+
+
 @pytest.mark.parametrize("hid,bodies", [(192, 5), (1024, 9), (320, 3)])   # 192 / 320: hid % 128 != 0 (the output GEMM's 16-k tail group)
 def test_gcn_output_layer_vs_oracle(L, dev, hid, bodies):
     """gconv_output (_GraphConv hid -> 6 without BatchNorm, modulated_gcn.py:112-113) = ehm_gcn_output_layer (exact-f32 MFMA responses +

@@ -279,9 +279,9 @@ def main():
             peak = PEAK_F32_MFMA_TFLOPS if prec == "f32" else PEAK_F16_MFMA_TFLOPS
             per_prod = 3 if prec == "f16x3" else 1
             name = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue), one launch per conv",
-                    "f16x3": "gcn_hidden_chain_kernel<3> (csrc/gcn_tile.hip): the 8 hidden convs of a GCN forward chained in one launch; split-f16 operands, "
+                    "f16x3": "gcn_hidden_chain_kernel<3, 4> (csrc/gcn_tile.hip): the 8 hidden convs of a GCN forward chained in one launch (4-wave 192x64 tiles); split-f16 operands, "
                              "3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue",
-                    "f16": "gcn_hidden_chain_kernel<1> (csrc/gcn_tile.hip): the 8 hidden convs chained in one launch; plain f16 operands and f16 "
+                    "f16": "gcn_hidden_chain_kernel<1, 8> (csrc/gcn_tile.hip): the 8 hidden convs chained in one launch (8-wave 192x128 tiles); plain f16 operands and f16 "
                            "activations, f32 accumulate, adjacency mix on the matrix cores, fused BN/ReLU/residual epilogue"}[prec]
             return {"bound": "mfma", "kernel": name, "achieved": flops / kd / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / kd / 1e12 / peak,
                     "mfma_flops_per_algorithmic_flop": per_prod, "issued_mfma_frac": flops * per_prod / kd / 1e12 / peak,

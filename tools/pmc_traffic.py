@@ -16,12 +16,12 @@ d = sys.argv[1]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sha = hashlib.sha1(open(os.path.join(repo, "egohmr_amd", "csrc", "gcn_tile.hip"), "rb").read()).hexdigest()
 out = {}
-for prec, tmpl in (("f16", "gcn_hidden_chain_kernel<1>"), ("f16x3", "gcn_hidden_chain_kernel<3>")):
+for prec, tmpl in (("f16", "gcn_hidden_chain_kernel<1, 8>"), ("f16x3", "gcn_hidden_chain_kernel<3, 4>")):
     vals = collections.defaultdict(list)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(f"{d}/pmc_{prec}_{c}/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if "gcn_hidden_chain_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                if tmpl in r["Kernel_Name"] and r["Counter_Name"] == c:
                     vals[c].append(float(r["Counter_Value"]))
     if vals["FETCH_SIZE"] and vals["WRITE_SIZE"]:
         fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024 * 2      # gfx950 correction

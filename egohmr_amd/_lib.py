@@ -58,7 +58,7 @@ class LinearDesc(C.Structure):
     _fields_ = [("A0", C.c_void_p), ("A1", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("group_bias", C.c_void_p),
                 ("Y", C.c_void_p), ("colmax", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K0", C.c_int), ("K1", C.c_int),
                 ("rows_per_group", C.c_int), ("valid_rows_per_group", C.c_int), ("relu_in0", C.c_int), ("relu_out", C.c_int),
-                ("w_scale", C.c_float)]
+                ("w_scale", C.c_float), ("lift_points", C.c_void_p), ("lift_W4", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):

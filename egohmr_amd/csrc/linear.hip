@@ -28,6 +28,7 @@ struct LinArgs {
   const float* A0; const float* A1; const float* W;    // X2 rows addressed as floats (K floats per row)
   const float* bias; const float* gbias;
   char* Y; float* colmax;
+  const float* pts; const float* W4;                    // LIFT: A0 is generated, see linear_tile_kernel
   int K0, K1, M, N;
   int rows_per_group, valid_rows_per_group;
   int relu_in0, relu_out;
@@ -69,8 +70,17 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // and epilogue were more than half of a block's life (435 TFLOP/s issued on the PointNet at B = 256 x 4096 points).
 // Tile order: block b sits on XCD b % 8; the N / 128 column tiles of one row tile go to neighbouring blocks of ONE XCD in the same
 // iteration, so the row tile's activations come from HBM once.
-template <bool RELU_A>
+//
+// LIFT = the first layer of the PointNet folded into the loader (respointnet.py:35,:90: net = fc_pos(p); fc_0(actvn(net))): the
+// operand A0 = relu(points . Wpos^T + bpos) [M, K0] is a function of 12 bytes per row, so instead of writing it to HBM in X2 format
+// (2.3 GB at 256 x 4096 points, the former pointnet_lift kernel: 0.9 ms) and reading it back, every K tile of it is produced in
+// place: wave w evaluates k-chunk w (8 channels, weights and bias wave-uniform -> scalar loads, operands of the FMAs) for the
+// tile's 192 rows (three per lane, their points stay in nine registers for the whole tile), splits the values exactly like
+// split_store and writes the hi / lo chunks at the loader's swizzled positions.  Stage 1 is written behind the head barrier of the
+// tile (its rows are other waves' epilogue scratch until then); its values are visible after the first K tile's barrier.
+template <bool RELU_A, bool LIFT>
 __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
+  static_assert(!(RELU_A && LIFT), "the generated operand is already rectified");
   __shared__ __attribute__((aligned(16))) float lds[2 * LSTG];   // 80 KiB; the ONLY LDS object
 
   constexpr int KS = 2, NM = 18, NR = 10;
@@ -134,9 +144,47 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * brow32 + (size_t)kt * RK), (AS3 void*)(lds + buf * LSTG + LA_T + (wave + 4 * i) * 256), 16,
                                      0, 0);
   };
-  auto stage = [&](int buf, int kt) {
+  float px[3], py[3], pz[3];                                    // LIFT: the points of rows lane + 64 j of the current tile
+  auto load_points = [&](int m) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+    for (int j = 0; j < 3; ++j) {
+      const size_t row = (size_t)m * LBM + (tid & 63) + 64 * j;
+      const int grp = (int)(row / p.rows_per_group), i = (int)(row % p.rows_per_group);
+      px[j] = py[j] = pz[j] = 0.f;                               // padding rows: relu(bias), like the unfused kernel; they never reach the maximum
+      if (i < p.valid_rows_per_group) {
+        const float* q = p.pts + ((size_t)grp * p.valid_rows_per_group + i) * 3;
+        px[j] = q[0]; py[j] = q[1]; pz[j] = q[2];
+      }
+    }
+  };
+  auto gen_a = [&](int buf, int kt) {
+    typedef const f32x4 __attribute__((address_space(4))) cf32x4;
+    cf32x4* w4 = (cf32x4*)(uintptr_t)(p.W4 + (size_t)(kt * RK + 8 * wave) * 4);   // (w_x, w_y, w_z, bias) of my eight channels
+    f32x4 wk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wk[e] = w4[e];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int row = lane + 64 * j, key = (row >> 1) & 7;
+      half8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = fmaxf(fmaf(wk[e][2], pz[j], fmaf(wk[e][1], py[j], fmaf(wk[e][0], px[j], wk[e][3]))), 0.f);
+        hi[e] = (half_t)fminf(v, 65504.f);
+        lo[e] = (half_t)fminf(fmaxf(v - (float)hi[e], -65504.f), 65504.f);
+      }
+      float* dst = lds + buf * LSTG + row * RK;
+      *(half8*)(dst + ((wave ^ key) << 2)) = hi;                  // logical chunk 2 s + g = wave: k = 8 wave .. + 7
+      *(half8*)(dst + (((wave + 4) ^ key) << 2)) = lo;
+    }
+  };
+  auto stage = [&](int buf, int kt) {
+    if constexpr (LIFT) {
+      gen_a(buf, kt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dma_a(buf, kt, i);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_b(buf, kt, i);
   };
@@ -190,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < (LIFT ? 0 : 6); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
@@ -203,17 +251,24 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
 #pragma unroll
   for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+  if constexpr (LIFT) {
+    load_points(m);
+    gen_a(0, 0);
+  } else {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+    for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+    for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+  }
 
   while (true) {
     // ---- head: stage 1's six activation pieces are the last memory instructions this wave issued; everything older (stage 0,
     //      the previous tile's stores) must be complete
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (LIFT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __syncthreads();
     thread_consts();
+    if constexpr (LIFT) gen_a(1, 1);                   // every wave is past its epilogue: stage 1's rows are free
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -269,8 +324,13 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       for (int i = 0; i < 4; ++i) dma_b(0, 0, i);
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma_b(1, 1, i);
+      if constexpr (LIFT) {
+        load_points(m_next);
+        gen_a(0, 0);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dma_a(0, 0, i);              // stage 1's activation pieces are the epilogue's scratch first
+        for (int i = 0; i < 6; ++i) dma_a(0, 0, i);            // stage 1's activation pieces are the epilogue's scratch first
+      }
     }
 
     // accumulator layout: lane (mi, g) owns column 64 wn + 32 u + mi; register r of acc[t][u] is row 32 t + 8 (r >> 2) + 4 g + (r & 3).
@@ -348,8 +408,10 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       }
     }
     if (!have_next) break;
+    if constexpr (!LIFT) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(1, 1, i);                // the scratch is free again: stage 1 of the next tile
+      for (int i = 0; i < 6; ++i) dma_a(1, 1, i);              // the scratch is free again: stage 1 of the next tile
+    }
     m = m_next; n = n_next; ++it;
   }
 }
@@ -402,24 +464,26 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const float* __res
   }
 }
 
-// relu(fc_pos(p)) in X2 format plus the raw points zero-padded to 32 columns (X2) for the folded stage-0 shortcut
-__global__ void pointnet_lift_kernel(const float* __restrict__ pts, const float* __restrict__ Wpos, const float* __restrict__ bpos,
-                                     half_t* __restrict__ R0, half_t* __restrict__ P32, int B, int N, int Npad, int C) {
-  const size_t row = blockIdx.x;                       // b * Npad + i
+// The raw points zero-padded to 32 columns in X2 format (input of the folded stage-0 shortcut) and, when R0 is given, relu(fc_pos(p))
+// in X2 format (the PointNet itself no longer needs it: ehm_linear_desc.lift_points).  32 lanes per row, 8 rows per block.
+__global__ __launch_bounds__(256) void pointnet_lift_kernel(const float* __restrict__ pts, const float* __restrict__ Wpos,
+                                                            const float* __restrict__ bpos, half_t* __restrict__ R0, half_t* __restrict__ P32,
+                                                            int N, int Npad, int C, size_t rows) {
+  const size_t row = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);       // b * Npad + i
+  if (row >= rows) return;
+  const int c0 = threadIdx.x & 31;
   const int b = (int)(row / Npad), i = (int)(row % Npad);
   float x = 0.f, y = 0.f, z = 0.f;
   if (i < N) {
     const float* q = pts + ((size_t)b * N + i) * 3;
     x = q[0]; y = q[1]; z = q[2];
   }
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float v = fmaf(Wpos[c * 3 + 2], z, fmaf(Wpos[c * 3 + 1], y, fmaf(Wpos[c * 3], x, bpos[c])));   // torch addmm order is free
-    split_store(R0, row, c, C, fmaxf(v, 0.f));
-  }
-  if (threadIdx.x < 32) {
-    const int c = threadIdx.x;
-    split_store(P32, row, c, 32, c == 0 ? x : (c == 1 ? y : (c == 2 ? z : 0.f)));
-  }
+  split_store(P32, row, c0, 32, c0 == 0 ? x : (c0 == 1 ? y : (c0 == 2 ? z : 0.f)));
+  if (R0)
+    for (int c = c0; c < C; c += 32) {
+      const float v = fmaf(Wpos[c * 3 + 2], z, fmaf(Wpos[c * 3 + 1], y, fmaf(Wpos[c * 3], x, bpos[c])));   // torch addmm order is free
+      split_store(R0, row, c, C, fmaxf(v, 0.f));
+    }
 }
 
 __global__ void pack_scaled_kernel(const float* __restrict__ X, half_t* __restrict__ Y, size_t rows, int K, int Kpad, float scale) {
@@ -518,7 +582,9 @@ extern "C" int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int
 }
 
 extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
-  EHM_CHECK_ARG(d && d->A0 && d->W && (d->Y || d->colmax));
+  EHM_CHECK_ARG(d && d->W && (d->Y || d->colmax));
+  const bool lift = d->lift_points != nullptr;
+  EHM_CHECK_ARG(lift ? (!d->A0 && d->lift_W4 && d->K1 == 0 && !d->relu_in0) : d->A0 != nullptr);
   EHM_CHECK_ARG(d->M > 0 && d->M % LBM == 0 && d->N > 0 && d->N % LBN == 0);
   EHM_CHECK_ARG(d->K0 > 0 && d->K0 % BK == 0 && d->K1 >= 0 && d->K1 % BK == 0 && (d->K1 == 0 || d->A1) && d->K0 + d->K1 >= 2 * BK);
   EHM_CHECK_ARG(d->rows_per_group > 0 && d->rows_per_group % LBM == 0 && d->M % d->rows_per_group == 0);
@@ -527,6 +593,7 @@ extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
   LinArgs a;
   a.A0 = (const float*)d->A0; a.A1 = (const float*)d->A1; a.W = (const float*)d->W;
   a.bias = d->bias; a.gbias = d->group_bias; a.Y = (char*)d->Y; a.colmax = d->colmax;
+  a.pts = d->lift_points; a.W4 = d->lift_W4;
   a.K0 = d->K0; a.K1 = d->K1; a.M = (int)d->M; a.N = d->N;
   a.rows_per_group = d->rows_per_group;
   a.valid_rows_per_group = d->valid_rows_per_group > 0 ? d->valid_rows_per_group : d->rows_per_group;
@@ -538,8 +605,9 @@ extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
     ehm_set_error("ehm_linear_split: relu_in0 needs K1 == 0 (the ReLU'd operand must be the only K segment)");
     return EHM_EINVAL;
   }
-  if (d->relu_in0) hipLaunchKernelGGL(linear_tile_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(linear_tile_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (lift) hipLaunchKernelGGL((linear_tile_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (d->relu_in0) hipLaunchKernelGGL((linear_tile_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((linear_tile_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }
@@ -558,9 +626,10 @@ extern "C" int ehm_skinny_gemm_f32(const float* X, const float* W, const float* 
 
 extern "C" int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
                                  int C, void* stream) {
-  EHM_CHECK_ARG(pts && Wpos && bpos && R0 && P32 && B > 0 && N > 0 && N_padded >= N && C > 0 && C % 32 == 0);
-  hipLaunchKernelGGL(pointnet_lift_kernel, dim3((unsigned)((size_t)B * N_padded)), dim3(256), 0, (hipStream_t)stream, pts, Wpos, bpos,
-                     (half_t*)R0, (half_t*)P32, B, N, N_padded, C);
+  EHM_CHECK_ARG(pts && P32 && (!R0 || (Wpos && bpos)) && B > 0 && N > 0 && N_padded >= N && C > 0 && C % 32 == 0);
+  const size_t rows = (size_t)B * N_padded;
+  hipLaunchKernelGGL(pointnet_lift_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, pts, Wpos, bpos, (half_t*)R0,
+                     (half_t*)P32, N, N_padded, C, rows);
   EHM_LAUNCH_CHECK();
   return 0;
 }

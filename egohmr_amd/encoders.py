@@ -266,7 +266,7 @@ class ResnetPointnet(nn.Module):
             return self._packed
         H = self.hidden_dim
         d = lambda t: t.detach().double()
-        P = {"pos_w": self.fc_pos_0.weight.detach().float().contiguous(), "pos_b": self.fc_pos_0.bias.detach().float().contiguous()}
+        P = {"pos_w4": torch.cat([self.fc_pos_0.weight.detach().float(), self.fc_pos_0.bias.detach().float()[:, None]], 1).contiguous()}   # rows (w_x, w_y, w_z, bias)
         blocks = [self.block_0, self.block_1, self.block_2, self.block_3]
         b0 = blocks[0]
         P["g1_0"] = self._pack(d(b0.fc_0.weight), device) + (b0.fc_0.bias.detach().float().contiguous(),)
@@ -298,12 +298,13 @@ class ResnetPointnet(nn.Module):
         M = B * Np
         st = _lib.stream_ptr()
         f32buf = lambda cols: torch.empty(M, cols, dtype=torch.float32, device=dev)      # X2 buffers (same bytes as float32)
-        R0, P32, Hb, netA, netB = f32buf(2 * H), f32buf(32), f32buf(H), f32buf(H), f32buf(H)
-        _lib.check(L.ehm_pointnet_lift(p.data_ptr(), P["pos_w"].data_ptr(), P["pos_b"].data_ptr(), R0.data_ptr(), P32.data_ptr(),
-                                       B, N, Np, 2 * H, st), "ehm_pointnet_lift")
+        P32, Hb, netA, netB = f32buf(32), f32buf(H), f32buf(H), f32buf(H)
+        p = p.contiguous()
+        _lib.check(L.ehm_pointnet_lift(p.data_ptr(), None, None, None, P32.data_ptr(), B, N, Np, 2 * H, st), "ehm_pointnet_lift")
 
-        def gemm(A0, K0, A1, K1, W, bias, gbias, Y, colmax, relu_in0, relu_out):
-            d = _lib.LinearDesc(A0=A0.data_ptr(), A1=A1.data_ptr() if A1 is not None else None, W=W[0].data_ptr(),
+        def gemm(A0, K0, A1, K1, W, bias, gbias, Y, colmax, relu_in0, relu_out, lift=False):
+            d = _lib.LinearDesc(A0=A0.data_ptr() if A0 is not None else None, A1=A1.data_ptr() if A1 is not None else None, W=W[0].data_ptr(),
+                                lift_points=p.data_ptr() if lift else None, lift_W4=P["pos_w4"].data_ptr() if lift else None,
                                 bias=bias.data_ptr() if bias is not None else None,
                                 group_bias=gbias.data_ptr() if gbias is not None else None,
                                 Y=Y.data_ptr() if Y is not None else None, colmax=colmax.data_ptr() if colmax is not None else None,
@@ -321,7 +322,8 @@ class ResnetPointnet(nn.Module):
 
         neg_inf = float("-inf")
         # block_0 on net0 = fc_pos(p):  h = fc_0(relu(net0));  net1 = fc_1(relu(h)) + shortcut(net0)
-        gemm(R0, 2 * H, None, 0, P["g1_0"], P["g1_0"][3], None, Hb, None, False, True)
+        # (relu(net0) is produced inside the GEMM's loader from the 12 bytes of each point: ehm_linear_desc.lift_points)
+        gemm(None, 2 * H, None, 0, P["g1_0"], P["g1_0"][3], None, Hb, None, False, True, lift=True)
         pooled = torch.full((B, H), neg_inf, device=dev)
         gemm(Hb, H, P32, 32, P["g3_0"], P["g3_0"][3], None, netA, pooled, False, False)
         cur, nxt = netA, netB

@@ -187,12 +187,17 @@ typedef struct {
   int relu_in0;            /* apply ReLU to A0 on load (ResnetBlockFC's actvn before fc_0); needs K1 == 0 */
   int relu_out;            /* apply ReLU before storing                                             */
   float w_scale;           /* the power-of-two scale baked into W                                   */
+  const float* lift_points;/* NULL, or [M/rows_per_group, valid_rows_per_group, 3] float32: A0 is not read but generated on
+                              the fly as relu(points . Wpos^T + bpos), K0 wide - fc_pos + the first block's actvn
+                              (respointnet.py:35,:90) folded into the loader; then A0 == NULL, K1 == 0, relu_in0 == 0 */
+  const float* lift_W4;    /* [K0][4] float32 rows (w_x, w_y, w_z, bias) of fc_pos                   */
 } ehm_linear_desc;
 int ehm_linear_split(const ehm_linear_desc* d, void* stream);
 /* float32 [rows,K] -> X2 [rows,K_padded] (zero padded), values multiplied by `scale` (1 for activations). */
 int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int K_padded, float scale, void* stream);
-/* fc_pos + ReLU (respointnet.py:35,:90): pts [B,N,3] -> R0 = relu(pts W^T + b) as X2 [B*N_padded, C], and the raw points
- * zero-padded to 32 columns, P32 X2 [B*N_padded, 32] (input of the folded block_0 shortcut). */
+/* The raw points zero-padded to 32 columns, P32 X2 [B*N_padded, 32] (input of the folded block_0 shortcut), and - when R0 is not
+ * NULL - fc_pos + ReLU (respointnet.py:35,:90): pts [B,N,3] -> R0 = relu(pts W^T + b) as X2 [B*N_padded, C].  (The PointNet
+ * generates R0 inside its first GEMM instead: ehm_linear_desc.lift_points; R0 here serves tests and other callers.) */
 int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, void* R0, void* P32, int B, int N, int N_padded,
                       int C, void* stream);
 

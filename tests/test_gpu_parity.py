@@ -460,6 +460,52 @@ def test_pointnet_vs_oracle(dev, model, synth_weights, B, N):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("B,N", [(2, 300), (5, 1000)])
+def test_linear_split_lift_mode_equals_materialised_operand(L, dev, B, N):
+    """ehm_linear_desc.lift_points: the first PointNet GEMM produces relu(fc_pos(p)) inside its loader.  The generated operand
+    has the bits ehm_pointnet_lift writes and the matrix-core sequence is the same, so the result must equal the GEMM over the
+    materialised X2 operand bit for bit - ragged groups (N not a multiple of the 192-row tile), several tiles per block."""
+    from egohmr_amd import _lib
+    C0, H = 512, 256
+    g = torch.Generator().manual_seed(11)
+    pts = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
+    Wpos, bpos = (torch.randn(C0, 3, generator=g) * 0.7).to(dev), (torch.randn(C0, generator=g) * 0.3).to(dev)
+    W = (torch.randn(H, C0, generator=g) / C0 ** 0.5).to(dev)
+    bias = torch.randn(H, generator=g).to(dev)
+    Np = (N + 191) // 192 * 192
+    M = B * Np
+    Wx2 = torch.empty(H, C0, device=dev)
+    _lib.check(L.ehm_split_pack(W.data_ptr(), Wx2.data_ptr(), H, C0, C0, 1024.0, None))
+    R0, P32 = torch.empty(M, C0, device=dev), torch.empty(M, 32, device=dev)
+    _lib.check(L.ehm_pointnet_lift(pts.data_ptr(), Wpos.data_ptr(), bpos.data_ptr(), R0.data_ptr(), P32.data_ptr(), B, N, Np, C0, None))
+    W4 = torch.cat([Wpos, bpos[:, None]], 1).contiguous()
+    outs = []
+    for lift in (False, True):
+        Y = torch.full((M, H), float("nan"), device=dev)
+        cm = torch.full((B, H), float("-inf"), device=dev)
+        d = _lib.LinearDesc(A0=None if lift else R0.data_ptr(), A1=None, W=Wx2.data_ptr(), bias=bias.data_ptr(), group_bias=None, Y=Y.data_ptr(),
+                            colmax=cm.data_ptr(), M=M, N=H, K0=C0, K1=0, rows_per_group=Np, valid_rows_per_group=N, relu_in0=0, relu_out=1,
+                            w_scale=1024.0, lift_points=pts.data_ptr() if lift else None, lift_W4=W4.data_ptr() if lift else None)
+        _lib.check(L.ehm_linear_split(d, None))
+        torch.cuda.synchronize()
+        outs.append((Y, cm))
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1], outs[1][1])
+    # and against float64 on the valid rows
+    ref = torch.relu(torch.relu(pts.double() @ Wpos.double().t() + bpos.double()) @ W.double().t() + bias.double())
+    Yf = torch.empty(M, H, device=dev)
+    _lib.check(L.ehm_gcn_unpack_activations(outs[1][0].data_ptr(), Yf.data_ptr(), M, H, 32, None))
+    torch.cuda.synchronize()
+    got = Yf.view(B, Np, H)[:, :N]
+    assert (got.double() - ref).abs().max().item() < 2e-5
+    assert (outs[1][1].double() - ref.max(dim=1).values).abs().max().item() < 2e-5
+    # a lift descriptor that also names A0 / a second K segment is refused
+    bad = _lib.LinearDesc(A0=R0.data_ptr(), A1=None, W=Wx2.data_ptr(), bias=None, group_bias=None, Y=Y.data_ptr(), colmax=None, M=M, N=H, K0=C0, K1=0,
+                          rows_per_group=Np, valid_rows_per_group=N, relu_in0=0, relu_out=0, w_scale=1024.0, lift_points=pts.data_ptr(),
+                          lift_W4=W4.data_ptr())
+    assert L.ehm_linear_split(bad, None) != 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(256, 2048, 2048, False), (7, 672, 64, True), (33, 32, 32, False)])
 def test_skinny_gemm_f32_vs_torch_fp64(dev, shape):

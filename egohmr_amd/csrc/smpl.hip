@@ -344,6 +344,8 @@ __device__ unsigned long long* g_sdbg = nullptr;
 #define SSTAMP(i) do { } while (0)
 #endif
 
+constexpr int kSkinMfmaMinBodies = 24;   // below: the VALU skinning kernel (a 32-body MFMA tile would be mostly padding)
+
 struct SkinArgs {
   const sk_half8* PF; const float* A; SmplDev S;
   float* verts; float* joints;
@@ -639,7 +641,7 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
   else
     hipLaunchKernelGGL(pose_chain_kernel<false>, dim3(B), dim3(64), 0, st, betas, rot_or_x, (const float*)nullptr,
                        (const float*)nullptr, d, Rws, Aws, joints, (float*)nullptr, jstride);
-  static const int mfma_min = getenv("EHM_SKIN_MFMA_MIN_B") ? atoi(getenv("EHM_SKIN_MFMA_MIN_B")) : 24;   // below: the VALU kernel (a 32-body MFMA tile would be mostly padding)
+  constexpr int mfma_min = kSkinMfmaMinBodies;
   if (d.PDf && B >= mfma_min) {
     const int b_tiles = (int)ceil_div(B, 32);
     if (32 * b_tiles > h->pf_cap) {                      // grows on the first call with a larger batch only
@@ -781,7 +783,7 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
                        float* pose6d, int B, hipStream_t st, const GcnInputArgs* next_input, int next_prec, int* fused) {
   const SmplDev& d = h->d;
   if (fused) *fused = 0;
-  static const int mfma_min = getenv("EHM_SKIN_MFMA_MIN_B") ? atoi(getenv("EHM_SKIN_MFMA_MIN_B")) : 24;
+  constexpr int mfma_min = kSkinMfmaMinBodies;
   const bool mfma = d.PDf && B >= mfma_min;
   const int b_tiles = (int)ceil_div(B, 32);
   if (mfma && 32 * b_tiles > h->pf_cap) {                    // grows on the first call with a larger batch only

@@ -107,12 +107,14 @@ __global__ void pack_ws_kernel(const float* __restrict__ Wp, half_t* __restrict_
   if (i >= rows * K) return;
   split_store<G>(Ws, i / K, (int)(i % K), K, Wp[i] * scale);
 }
+// (D, M1 are [24][N]; the tile engine wants a channel's 24 values contiguous: Ds, M1s are [N][24] - six 16-byte loads per table and lane)
 __global__ void scale_epilogue_kernel(const float* __restrict__ D, const float* __restrict__ M1, float* __restrict__ Ds,
-                                      float* __restrict__ M1s, int n, float inv_scale) {
+                                      float* __restrict__ M1s, int N, float inv_scale) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Ds[i] = D[i] * inv_scale;
-  M1s[i] = M1[i] * inv_scale;
+  if (i >= kJ * N) return;
+  const int j = i / N, n = i % N;
+  Ds[n * kJ + j] = D[i] * inv_scale;
+  M1s[n * kJ + j] = M1[i] * inv_scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,7 +447,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
     hipLaunchKernelGGL(pack_ws_kernel<32>, dim3((unsigned)ceil_div((int64_t)2 * K * N, 256)), dim3(256), 0, st, L.Wp, L.Ws, (size_t)2 * N, K,
                        L.w_scale);
     ehm_pack_half(L.Wp, L.Wh, (size_t)2 * K * N, L.w_scale, st);
-    hipLaunchKernelGGL(scale_epilogue_kernel, dim3((unsigned)ceil_div(kJ * N, 256)), dim3(256), 0, st, L.D, L.M1, L.Ds, L.M1s, kJ * N,
+    hipLaunchKernelGGL(scale_epilogue_kernel, dim3((unsigned)ceil_div(kJ * N, 256)), dim3(256), 0, st, L.D, L.M1, L.Ds, L.M1s, N,
                        1.f / L.w_scale);
     EHM_LAUNCH_CHECK();
   }

@@ -16,8 +16,8 @@ struct LayerDev {
   float* Wp;     // [N/64][128][K]   packed W0|W1 columns, K contiguous
   half_t* Ws;    // same tiles in split-f16 format X2<32> (below), values scaled by w_scale
   half_t* Wh;    // the same tiles as plain f16 (values scaled by w_scale): operands of the 'f16' mode (gcn_tile.hip)
-  float* Ds;     // D / w_scale
-  float* M1s;    // M1 / w_scale
+  float* Ds;     // D / w_scale, transposed: [N][24] (tile engine only)
+  float* M1s;    // M1 / w_scale, transposed: [N][24]
   float w_scale; // power of two
   float* D;      // [24][N]  A[j][j] * M[j][n] * scale[n]
   float* M1;     // [24][N]  M[j][n] * scale[n]

@@ -480,10 +480,18 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) af[s3] = ((const half8*)io.AoffH)[s3 * 64 + lane];
       }
+      typedef unsigned int u32x4_tbl __attribute__((ext_vector_type(4)));
+      const unsigned int nrow = (unsigned int)n * (unsigned int)(kJ * 4);      // tables are [N][24]: my channel's 96 bytes
 #pragma unroll
-      for (int j = 0; j < kJ; ++j) {
-        dj[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsB, n4, j * tblrow, 0));
-        mj[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(m1B, n4, j * tblrow, 0));
+      for (int q4 = 0; q4 < kJ / 4; ++q4) {
+        const u32x4_tbl d4 = __builtin_amdgcn_raw_buffer_load_b128(dsB, nrow, 16 * q4, 0);
+        const u32x4_tbl m4 = __builtin_amdgcn_raw_buffer_load_b128(m1B, nrow, 16 * q4, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned int du = d4[i], mu = m4[i];       // (hipcc: __builtin_bit_cast of a vector ELEMENT expression reads element 0)
+          dj[4 * q4 + i] = __builtin_bit_cast(float, du);
+          mj[4 * q4 + i] = __builtin_bit_cast(float, mu);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       mfmas(fm);

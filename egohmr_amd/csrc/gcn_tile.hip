@@ -106,6 +106,10 @@ __device__ __forceinline__ const float* layer_weights(const LayerDev& L) {
 template <int P, bool CHAIN, int NW, class Args>
 __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   static_assert(NW == 4 || (NW == 8 && P == 1 && CHAIN), "the 8-wave tile exists for the chained f16 kernel (f16x3 is power-bound: 8 waves measured 150 vs 152 us)");
+  // MODE.FP16_OVFL = 1 for the life of the wave: every f32 -> f16 conversion of the epilogue clamps to +-65504 instead of producing inf
+  // (hwreg MODE = 1, bit 23).  The explicit clamps this replaces were 144 v_med3_f32 + their canonicalising v_max_f32 per wave and tile,
+  // in an epilogue during which the block's matrix pipes idle.
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   constexpr int NWN = NW / 2;                 // waves across the channels
   constexpr int NT = 32 * NWN;                // channels per tile
   constexpr int BROWS = 2 * NT;               // weight rows per stage (W0 | W1 per 64 channels)
@@ -525,6 +529,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     //      residual and output move as 8 / 16-byte accesses, 8 lanes per 64-byte row segment.  Two passes of 48 rows.
     const unsigned int arow = (unsigned int)N * (P == 3 ? 4u : 2u);       // bytes per activation row
     const bool out_f32 = io.out_f32 != 0, has_res = io.Res != nullptr, relu = io.relu != 0;
+    const float floor_v = relu ? 0.f : -3.4e38f;              // one v_max per value instead of a v_max and a select (the values are finite)
     const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(io.Y + ((size_t)cur.m_tile * 192 + 96 * wm) * (out_f32 ? (size_t)N * 4 : (size_t)arow));
     const __amdgpu_buffer_rsrc_t resB = ehm_buffer_rsrc((has_res ? io.Res : io.Y) + ((size_t)cur.m_tile * 192 + 96 * wm) * arow);
     // item (it, lane), it = 0..2 per pass: scratch row rl = 16 it + (lane>>2), channels 8 (lane&3) .. +7 of the wave's 32: 16 bytes of f16
@@ -605,8 +610,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
             const int kp = 16 * s3 + 2 * e, kq = kp + 8;           // < 24: gp[k], else dp[k - 24]
             const float p0 = kp < kJ ? gp[kp][beta] : dp[kp - kJ][beta], p1 = kp + 1 < kJ ? gp[kp + 1][beta] : dp[kp + 1 - kJ][beta];
             const float q0 = kq < kJ ? gp[kq][beta] : dp[kq - kJ][beta], q1 = kq + 1 < kJ ? gp[kq + 1][beta] : dp[kq + 1 - kJ][beta];
-            const half2_t hp = {(half_t)fminf(fmaxf(p0, -65504.f), 65504.f), (half_t)fminf(fmaxf(p1, -65504.f), 65504.f)};
-            const half2_t hq = {(half_t)fminf(fmaxf(q0, -65504.f), 65504.f), (half_t)fminf(fmaxf(q1, -65504.f), 65504.f)};
+            const half2_t hp = {(half_t)p0, (half_t)p1};          // (MODE.FP16_OVFL: conversions saturate at +-65504, see run_tiles)
+            const half2_t hq = {(half_t)q0, (half_t)q1};
             const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, hp), __builtin_bit_cast(unsigned int, hq), false, false);
             Pw[e] = sw[0];
             Qw[e] = sw[1];
@@ -621,7 +626,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
           const float v = D[x][k / 12][k % 12];
-          V[x][k] = relu ? fmaxf(v, 0.f) : v;
+          V[x][k] = fmaxf(v, floor_v);
         }
       wbase = STG + wave * 256 + 128 * g + mi;                   // scratch row 24 beta + joint0 + 4 g
     } else {
@@ -648,8 +653,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
             s1 = fmaf(c, gp[jp][1], s1);
           }
           asm volatile("" : "+v"(s0), "+v"(s1));                // pins both bodies' chains here (hipcc sank body b's to its use in pass 1 and
-          V[0][j] = relu ? fmaxf(s0, 0.f) : s0;                 // parked 500+ coefficients in VGPR lanes for it)
-          V[1][j] = relu ? fmaxf(s1, 0.f) : s1;
+          V[0][j] = fmaxf(s0, floor_v);                         // parked 500+ coefficients in VGPR lanes for it)
+          V[1][j] = fmaxf(s1, floor_v);
         }
       }
       wbase = STG + wave * 256 + (NW == 8 ? STG : 3072) * g + mi;   // scratch row 24 g + joint: pieces 3 g + (joint >> 3) (8 waves: poff(3 + x) - poff(x) = STG)
@@ -692,8 +697,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
           half8 hh, ll;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
-            if constexpr (P == 3) ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
+            hh[c] = (half_t)v[c];                                  // saturating (MODE.FP16_OVFL): |v| > 131008 saturates both halves, never inf
+            if constexpr (P == 3) ll[c] = (half_t)(v[c] - (float)hh[c]);
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, kStoreAux);
           if constexpr (P == 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, kStoreAux);

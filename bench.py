@@ -16,6 +16,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,6 +42,29 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (~2.5 PFLOP/s)
 
 
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable on a float4 copy)
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU,
+    RCCL over xGMI), exactly as the driver would: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>.
+    Returns the exit code of the launcher, or None when this process is already a rank / a single-GPU run."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"bench.py: --gpus {n} without a torchrun environment: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def hidden_layer_flops(virtual_bodies: int, hid: int) -> float:
     """per body-pass and hidden conv 24*2*hid^2 MAC (W0,W1) + 24*24*hid MAC (adjacency mix)."""
     return virtual_bodies * (24 * 2 * hid * hid + 24 * 24 * hid) * 2.0
@@ -62,49 +87,6 @@ def pmc_traffic(precision):
     except OSError:
         return None
     return e.get("bytes_per_conv") if e.get("kernel_source_sha1") == kernel_source_sha1() else None
-
-
-def time_dominant_kernel(model, B, passes, reps=5):
-    """Average launch duration of the hidden Modulated-GCN conv at the benchmark's shape, HIP events on the launch stream.
-    The convs are chained exactly as in the denoiser (block: Y1 = conv(X); X' = conv(Y1) + X), starting from a post-ReLU-like
-    matrix, so the operands are real activations: the chip's clock under MFMA load depends on the data (random dense inputs
-    run ~8 % slower than the sampler's half-zero activations), and the rocprofv3 average of the sampling loop is the
-    number this has to agree with."""
-    from egohmr_amd import _lib
-    L = _lib.lib()
-    hid = model.diffusion_model.hid_dim
-    tile = L.ehm_gcn_row_tile()
-    rows = passes * B * 24
-    rows_pad = (rows + tile - 1) // tile * tile
-    g = torch.Generator(device=model.device).manual_seed(1)
-    X = torch.relu(torch.randn(rows_pad, hid, device=model.device, generator=g)) * 0.5
-    Y1, Y2 = torch.empty_like(X), torch.empty_like(X)
-    h = model.fused_sampler.gcn()
-    if model.gcn_precision != "f32":     # split-f16 modes exchange activations in the X2 format
-        X2 = torch.empty_like(X)
-        _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), _lib.stream_ptr()))
-        X = X2
-    nl = 2 * model.diffusion_model.num_layers
-    s = _lib.stream_ptr()
-
-    X0 = X.clone()
-    import ctypes as C
-    bufs = (C.c_void_p * 3)(X.data_ptr(), Y1.data_ptr(), Y2.data_ptr())
-    res = C.c_int(0)
-
-    def sweep():    # the sampler's own call: all hidden convs of one GCN forward (one chained launch on the split-f16 path)
-        _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), s))
-
-    sweep()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for e0, e1 in ev:
-        X.copy_(X0)          # every sweep starts from the same activations (outside the timed span)
-        e0.record()
-        sweep()
-        e1.record()
-    torch.cuda.synchronize()
-    return sum(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3 / (reps * nl), rows_pad
 
 
 def cpu_baseline(n, rs, num_scene_points, budget_s, faithful=True):
@@ -149,6 +131,9 @@ def cpu_baseline(n, rs, num_scene_points, budget_s, faithful=True):
 
 
 def main():
+    rc = self_launch(sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -160,19 +145,38 @@ def main():
     ap.add_argument("--no-lbs-every-step", action="store_true")
     ap.add_argument("--precision", default=os.environ.get("EGOHMR_GCN_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16"],
                     help="arithmetic of the hidden GCN convs (DESIGN.md 3.2): f32 MFMA | split-f16 MFMA (f32-grade) | plain f16 (not parity-grade)")
+    ap.add_argument("--weights", default="sensitive", choices=["sensitive", "insensitive"],
+                    help="synthetic denoiser weights: 'sensitive' = trained-like (d x0 / d x_t follows the MMSE gain of a Gaussian prior, ~1 at low noise: "
+                         "early rounding errors are CARRIED), 'insensitive' = the plain random network of rounds 1-2 (ignores x_t: errors are contracted)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (all-f16x3, f32, f16, other weight set)")
+    ap.add_argument("--launch-check", action="store_true", help="only initialise the ranks, report the world size, exit (works without a GPU: gloo)")
     args = ap.parse_args()
 
     from egohmr_amd import dist as edist
+
+    rank, world, local = edist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) were started (WORLD_SIZE={os.environ.get('WORLD_SIZE')}); "
+                         "start it as `python bench.py --gpus N` (it launches the ranks) or under torch.distributed.run with --nproc-per-node N")
+    if args.launch_check:
+        seen = int(torch.distributed.get_world_size()) if world > 1 else 1
+        edist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "n_ranks_seen": seen, "backend": torch.distributed.get_backend() if world > 1 else None}))
+        edist.barrier()
+        return
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    ndev = torch.cuda.device_count()
+    if ndev < world and not os.environ.get("EGOHMR_BENCH_SHARE_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} HIP device(s) visible (set EGOHMR_BENCH_SHARE_GPU=1 for a functional run that shares devices)")
+    local %= ndev
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from egohmr_amd import _lib
     from egohmr_amd import synthetic as syn
     from egohmr_amd.diffusion import create_gaussian_diffusion
     from egohmr_amd.factory import batch_to_device, build_synthetic_model
-
-    rank, world, local = edist.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
-    local %= torch.cuda.device_count()          # (functional 2-rank runs on a 1-GPU box share the device)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     n, rs, desc = WORKLOADS[args.workload]
     B, N = args.batch, args.scene_points
@@ -181,7 +185,8 @@ def main():
         S, guided = 10, True
         if args.batch == 256:
             B = 128
-    model = build_synthetic_model(dev, 0, diffuse_fuse=True)
+    sens = dict(num_diffusion_timesteps=n) if args.weights == "sensitive" else None
+    model = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=sens)
     model.lbs_every_step = not args.no_lbs_every_step
     model.gcn_precision = args.precision
     diffusion = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
@@ -193,17 +198,28 @@ def main():
         batch["scene_pcd_verts_full"][:, : N // 3, 1] = batch["smpl_params"]["transl"][:, None, 1] - 0.6
     fs = model.fused_sampler
     ddim = bool(rs)
+    w_guid = 2.0 if guided else 1.0
 
-    def one_step():
-        fs.invalidate()                                                              # conditioning is part of the job: re-encode
+    def one_step(m=model):
+        f = m.fused_sampler
+        f.invalidate()                                                               # conditioning is part of the job: re-encode
         # the S samples of an item share its conditioning and are independent given it: one fused loop over S*B bodies
         # (FusedSampler.run_samples; bit-equal to S sequential loops, tests/test_gpu_api.py)
         # defer_status: the chain-status word of this call is read when the next call starts (and by check_status() behind the timed
         # region) instead of with a host wait at the end of every call
-        outs = fs.run_samples(diffusion, batch, noises[:S], ddim=ddim, guided=guided, cond_grad_weight=2.0 if guided else 1.0, defer_status=True)
+        outs = f.run_samples(diffusion, batch, noises[:S], ddim=ddim, guided=guided, cond_grad_weight=w_guid, defer_status=True)
         packs = [edist.pack_params(o["other_outputs"]["pred_smpl_params"]) for o in outs]
         return edist.gather_packed(torch.cat(packs, 0)), outs[-1]
 
+    # the precision schedule of the default path is CALIBRATED on the loaded weights (FusedSampler.calibrate_schedule) - here, before the
+    # warm-up, on the first items of this batch; it is a one-off per (checkpoint, sampler) and not part of a steady-state sampling call
+    t_cal = None
+    if args.precision == "f16x3" and model.f16x3_last_steps == "auto":
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fs.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=w_guid, denom_items=B)
+        torch.cuda.synchronize()
+        t_cal = time.perf_counter() - t1
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
@@ -219,39 +235,71 @@ def main():
     dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(res["other_outputs"]["pred_vertices"]).all()
     assert gathered.shape == (world * B * S, edist.PACKED_WIDTH)
+    lowprec = fs.last_lowprec                                                        # leading steps on plain f16 operands in the timed calls
+    sched = fs.schedule_info
 
-    # comparison legs (rank-local, N=1 only): the same job, same noise, (a) WITHOUT the precision schedule (every step split-f16),
-    # (b) with the hidden convs on the f32-input MFMA (exact f32 products), (c) on plain f16 operands in every step (the "fp16
-    # denoiser" of BASELINE config 5; NOT parity-grade) - each with its distance to the default path's vertices / joints
+    # comparison legs (rank-local, N=1 only): the same job, same noise, (a) WITHOUT the precision schedule (every step split-f16: f32-grade
+    # for ANY weights), (b) with the hidden convs on the f32-input MFMA (exact f32 products), (c) on plain f16 operands in every step (the
+    # "fp16 denoiser" of BASELINE config 5; NOT parity-grade) - each with its distance to the default path's vertices / joints - and (d) the
+    # default path on the OTHER synthetic weight set (its own calibration)
     legs = {}
-    if args.precision == "f16x3" and world == 1 and S == 1:
+    if args.precision == "f16x3" and world == 1 and not args.no_legs:
         ref_v = res["other_outputs"]["pred_vertices"].float().clone()
         ref_j = res["other_outputs"]["pred_keypoints_3d"].float().clone()
 
-        def leg(prec, last_steps):
-            old = (model.gcn_precision, model.f16x3_last_steps)
-            model.gcn_precision, model.f16x3_last_steps = prec, last_steps
+        def leg(prec, last_steps, m=model, compare=True):
+            old = (m.gcn_precision, m.f16x3_last_steps)
+            m.gcn_precision, m.f16x3_last_steps = prec, last_steps
             try:
-                one_step()
+                one_step(m)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                _, r = one_step()
+                _, r = one_step(m)
                 torch.cuda.synchronize()
-                fs.check_status()
+                m.fused_sampler.check_status()
                 d = time.perf_counter() - t1
             finally:
-                model.gcn_precision, model.f16x3_last_steps = old
-            v = r["other_outputs"]["pred_vertices"].float()
-            dv = (v - ref_v).norm(dim=-1)                                  # per-vertex distance [B, V], metres
-            return {"value": B / d, "unit": "bodies/s", "ms_per_step": d * 1e3,
-                    "vs_default_path": {"max_vertex_dist_mm": float(dv.max()) * 1e3, "mean_v2v_mm": float(dv.mean()) * 1e3,
-                                        "mpjpe_mm": float((r["other_outputs"]["pred_keypoints_3d"].float() - ref_j).norm(dim=-1).mean()) * 1e3}}
+                m.gcn_precision, m.f16x3_last_steps = old
+            out = {"value": B * S / d, "unit": "bodies/s", "ms_per_step": d * 1e3}
+            if compare:
+                v = r["other_outputs"]["pred_vertices"].float()
+                dv = (v - ref_v).norm(dim=-1)                              # per-vertex distance [B, V], metres
+                out["vs_default_path"] = {"max_vertex_dist_mm": float(dv.max()) * 1e3, "mean_v2v_mm": float(dv.mean()) * 1e3,
+                                          "mpjpe_mm": float((r["other_outputs"]["pred_keypoints_3d"].float() - ref_j).norm(dim=-1).mean()) * 1e3}
+            return out
 
         legs["all_steps_f16x3"] = leg("f16x3", None)
-        legs["f32_mfma_path"] = leg("f32", None)
+        legs["all_steps_f16x3"]["note"] = "every step in split-f16 (3 MFMA per product): f32-grade for ANY weights, no calibration involved"
+        if S == 1:
+            legs["f32_mfma_path"] = leg("f32", None)
         legs["f16_denoiser_path"] = leg("f16", None)
         legs["f16_denoiser_path"]["note"] = ("plain f16 operands and f16 activations in the hidden convs of EVERY step (f32 accumulate, everything "
                                              "else f32): BASELINE config 5's fp16 denoiser, not a parity path on its own")
+        if args.workload == "ddpm100":
+            other = "insensitive" if args.weights == "sensitive" else "sensitive"
+            m2 = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=dict(num_diffusion_timesteps=n) if other == "sensitive" else None)
+            m2.lbs_every_step = model.lbs_every_step
+            info2 = m2.fused_sampler.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=w_guid, denom_items=B)
+            legs[f"default_path_on_{other}_weights"] = leg("f16x3", "auto", m2, compare=False)
+            legs[f"default_path_on_{other}_weights"].update({
+                "calibrated_f16x3_last_steps": info2["k"], "measured_gain_dx0_dxt": m2.fused_sampler.measure_gain(batch, timesteps=(n - 1, n // 2, n // 10, 0)),
+                "note": "the same job with the other synthetic weight set and ITS calibrated schedule (rounds 1-2 benchmarked the insensitive set with a constant k = 8)"})
+            del m2
+            torch.cuda.empty_cache()
+
+    # one PROFILED call (outside the timed region): every launch of the sampling loop bracketed by HIP events on the launch stream
+    # (ehm_profile_begin / ehm_profile_end), summed per launch class -> the live per-kernel durations the roofline objects use
+    import ctypes as C
+    L = _lib.lib()
+    torch.cuda.synchronize()
+    _lib.check(L.ehm_profile_begin(), "ehm_profile_begin")
+    one_step()
+    torch.cuda.synchronize()
+    ncls = len(_lib.PROF_CLASSES)
+    ms_arr, cnt_arr = (C.c_double * ncls)(), (C.c_int64 * ncls)()
+    _lib.check(L.ehm_profile_end(ms_arr, cnt_arr, ncls), "ehm_profile_end")
+    prof = {c: {"ms_per_call": ms_arr[i], "launches_per_call": int(cnt_arr[i]), "avg_launch_us": (ms_arr[i] / cnt_arr[i] * 1e3) if cnt_arr[i] else None}
+            for i, c in enumerate(_lib.PROF_CLASSES)}
 
     # split of one call (rank 0, informative)
     torch.cuda.synchronize()
@@ -264,43 +312,55 @@ def main():
     if rank == 0:
         passes = 2
         hid = model.diffusion_model.hid_dim
-        flops = hidden_layer_flops(passes * B, hid)
+        vbodies = S * (B + (st.num_masked if model.prune_passes else B))            # body-passes per launch after pass pruning
+        rows = vbodies * 24
+        flops = hidden_layer_flops(vbodies, hid)
         n_hidden = 2 * model.diffusion_model.num_layers
-        lowprec = fs.lowprec_steps(T, min(T, 11) if guided else 0, ddim) if args.precision == "f16x3" else 0   # (the reference guides the last 11 steps: t <= 10)           # leading steps on plain f16 operands
-        kernels = {}                                                                # live HIP-event timing of each conv kernel this job runs
-
-        def time_kernel(prec):
-            old = model.gcn_precision
-            model.gcn_precision = prec
-            try:
-                kd, _ = time_dominant_kernel(model, B, passes)
-            finally:
-                model.gcn_precision = old
+        names = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue), one launch per conv",
+                 "f16x3": "gcn_hidden_chain_kernel<3, 4> (csrc/gcn_tile.hip): the 8 hidden convs of a GCN forward chained in one launch (4-wave 192x64 tiles); split-f16 "
+                          "operands, 3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue",
+                 "f16": "gcn_hidden_chain_kernel<1, 8> (csrc/gcn_tile.hip): the 8 hidden convs chained in one launch (8-wave 192x128 tiles); plain f16 operands and f16 "
+                        "activations, f32 accumulate, adjacency mix on the matrix cores, fused BN/ReLU/residual epilogue"}
+        cls_of = {"f32": "hidden_f32", "f16x3": "chain_f16x3", "f16": "chain_f16"}
+        kernels = {}
+        for prec, cls in cls_of.items():
+            pr = prof[cls]
+            if not pr["launches_per_call"]:
+                continue
+            kd = pr["ms_per_call"] * 1e-3 / pr["launches_per_call"] / n_hidden        # seconds per conv, in situ (the job's own activations and shape)
             peak = PEAK_F32_MFMA_TFLOPS if prec == "f32" else PEAK_F16_MFMA_TFLOPS
             per_prod = 3 if prec == "f16x3" else 1
-            name = {"f32": "gcn_hidden_kernel (f32-input MFMA GEMM + fused modulated-adjacency/BN/ReLU epilogue), one launch per conv",
-                    "f16x3": "gcn_hidden_chain_kernel<3, 4> (csrc/gcn_tile.hip): the 8 hidden convs of a GCN forward chained in one launch (4-wave 192x64 tiles); split-f16 operands, "
-                             "3 MFMA per algorithmic product, f32 accumulate, fused modulated-adjacency/BN/ReLU/residual epilogue",
-                    "f16": "gcn_hidden_chain_kernel<1, 8> (csrc/gcn_tile.hip): the 8 hidden convs chained in one launch (8-wave 192x128 tiles); plain f16 operands and f16 "
-                           "activations, f32 accumulate, adjacency mix on the matrix cores, fused BN/ReLU/residual epilogue"}[prec]
-            return {"bound": "mfma", "kernel": name, "achieved": flops / kd / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / kd / 1e12 / peak,
-                    "mfma_flops_per_algorithmic_flop": per_prod, "issued_mfma_frac": flops * per_prod / kd / 1e12 / peak,
-                    "traffic": pmc_traffic(prec), "avg_launch_ms": kd * 1e3, "avg_launch_ms_is": "per conv = chained launch / 8" if prec != "f32" else "per conv",
-                    "flops_per_launch": flops, "formula": "virtual_bodies*(24*2*hid^2 + 24*24*hid)*2, virtual_bodies = passes*B (SURVEY 8d, hoisted)"}
-
-        if args.precision == "f16x3":
-            kernels["f16x3"] = time_kernel("f16x3")
-            kernels["f16x3"]["launches_per_call"], kernels["f16x3"]["ms_per_call"] = T - lowprec, kernels["f16x3"]["avg_launch_ms"] * n_hidden * (T - lowprec)
-            if lowprec:
-                kernels["f16"] = time_kernel("f16")
-                kernels["f16"]["launches_per_call"], kernels["f16"]["ms_per_call"] = lowprec, kernels["f16"]["avg_launch_ms"] * n_hidden * lowprec
-        else:
-            kernels[args.precision] = time_kernel(args.precision)
-            kernels[args.precision]["launches_per_call"] = T
-            kernels[args.precision]["ms_per_call"] = kernels[args.precision]["avg_launch_ms"] * n_hidden * T
+            kernels[prec] = {"bound": "mfma", "kernel": names[prec], "achieved": flops / kd / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / kd / 1e12 / peak,
+                             "mfma_flops_per_algorithmic_flop": per_prod, "issued_mfma_frac": flops * per_prod / kd / 1e12 / peak,
+                             "traffic": pmc_traffic(prec) if (B, S) == (256, 1) else None, "avg_launch_ms": kd * 1e3,
+                             "avg_launch_ms_is": "per conv = (HIP-event span of the chained launch, on the launch stream, inside a real sampling call) / 8",
+                             "launches_per_call": pr["launches_per_call"], "ms_per_call": pr["ms_per_call"], "flops_per_launch": flops,
+                             "formula": f"virtual_bodies*(24*2*hid^2 + 24*24*hid)*2, virtual_bodies = {vbodies} body-passes per launch (SURVEY 8d, hoisted)"}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_call"])            # the kernel the job spends most time in
+        # HBM-bound kernels of the step (per-kernel GB/s against 8 TB/s), algorithmic bytes per launch
+        act_b = 2 if prof["chain_f16"]["launches_per_call"] >= prof["chain_f16x3"]["launches_per_call"] else 4   # bytes per activation element of the majority of steps
+        nb = S * B
+        hbm = {}
+
+        def hbm_entry(cls, kernel, bytes_per_launch, what):
+            pr = prof[cls]
+            if pr["launches_per_call"]:
+                t = pr["ms_per_call"] * 1e-3 / pr["launches_per_call"]
+                hbm[cls] = {"bound": "hbm", "kernel": kernel, "achieved": bytes_per_launch / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": bytes_per_launch / t / 1e9 / PEAK_HBM_GBS, "avg_launch_us": t * 1e6, "launches_per_call": pr["launches_per_call"],
+                            "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_are": what}
+        hbm_entry("out_dot", "gcn_out_dot_kernel (output conv responses [rows,hid] x [hid,12])", rows * hid * act_b + rows * 12 * 4,
+                  f"rows*hid*{act_b} B activations read + rows*12*4 B responses written, rows = {rows}")
+        hbm_entry("skin_input", "skin_input_kernel (LBS skinning of step t + input conv of step t+1)",
+                  nb * (6890 * 3 * 4 + 21 * 3 * 4 + 24 * 12 * 4 + 2 * 224 * 2) + 19.3e6 + rows * hid * (act_b if act_b == 2 else 4) + nb * 2 * 2 * hid * 4,
+                  "per body 82,680 B vertices + extra joints + transforms + blend coefficients (SURVEY 8d: ~84.1 KB/body-step incl. the inputs) + SMPL "
+                  "constants 19.3 MB once per launch + the next step's input rows written (rows*hid) + h_img / h_oth read")
+        hbm_entry("step_body", "step_body_kernel (output mix + sampler update + rot6d + 24-joint chain; one wave per body)",
+                  nb * (2 * 24 * 12 * 4 + 5 * 576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2),
+                  "per body: responses 2,304 B + x_t / noise / x0 / x_next / pose6d 5 x 576 B + betas + R + A + joints + blend-coefficient fragments (latency-bound: 1 wave per body)")
         value = world * B * S * args.steps / dt
-        flops_per_body = 183.8e9 if args.workload == "ddpm100" else None            # SURVEY 8d, hoisted, T = 100 with diffuse_fuse
+        flops_per_body = {"ddpm100": 183.8e9, "c2_ddim10": 35.5e9}.get(args.workload)  # SURVEY 8d, hoisted, with diffuse_fuse
+        k_last = T - lowprec
         out = {
             "metric": "sampled bodies/sec (100-step DDPM, batch 256)" if args.workload == "ddpm100" else f"sampled bodies/sec ({args.workload})",
             "value": value,
@@ -315,27 +375,38 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32",
                       "f16x3": "f32 results: denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands (f32 accumulate) on the last "
-                               f"{T - lowprec} of {T} steps, plain f16 operands on the first {lowprec} (precision schedule, DESIGN.md 3.6; "
-                               "final bodies within 1e-5 m of the all-split run, measured below)",
+                               f"{k_last} of {T} steps, plain f16 operands on the first {lowprec}; k = {k_last} is CALIBRATED on the loaded weights "
+                               f"(final bodies within {model.schedule_tol:g} m of the all-split loop, DESIGN.md 3.6); all-split number in all_steps_f16x3",
                       "f16": "f16 denoiser GEMMs and activations (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": S, "samples_in_one_loop": bool(S > 1), "collision_guided": guided, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
-                       "gcn_precision": args.precision, "f16x3_last_steps": (T - lowprec) if args.precision == "f16x3" else None,
+                       "gcn_precision": args.precision, "f16x3_last_steps": k_last if args.precision == "f16x3" else None,
                        "f16x3_last_steps_policy": str(model.f16x3_last_steps),
                        "pass_pruning": {"items_without_second_pass": int(B - st.num_masked) if model.prune_passes else 0, "of": B,
                                         "note": "exact (egohmr.py:249-254): all-visible items skip the image-masked pass; the synthetic "
                                                 "visibility draw (Bernoulli 0.6 per OpenPose joint, SURVEY 8d) almost never produces one"},
-                       "weights": "seeded random (no checkpoint offline)", "smpl": "synthetic SMPL-shaped asset",
+                       "weights": ("seeded synthetic, x_t-SENSITIVE (trained-like: d x0 / d x_t follows the MMSE gain of a Gaussian prior; synthetic.make_sensitive_state_dict)"
+                                   if args.weights == "sensitive" else "seeded synthetic, plain random network (ignores x_t; rounds 1-2)") + " - no checkpoint offline",
+                       "smpl": "synthetic SMPL-shaped asset",
                        "parallelism": f"items sharded x{world}, one RCCL all-gather of [B,226] at the end"},
+            "schedule": None if args.precision != "f16x3" else {
+                "f16x3_last_steps": k_last, "f16_steps": lowprec, "calibrated": sched is not None,
+                "schedule_calibrated_on": None if sched is None else f"the loaded ({args.weights}) weights, {sched['bodies']} items of this batch, 2 private noise draws, tol {sched['tol_m']:g} m",
+                "calibration_seconds_once_per_checkpoint_and_sampler": t_cal, "calibration_trials": None if sched is None else sched["trials"],
+                "measured_gain_dx0_dxt": fs.measure_gain(batch, timesteps=sorted({diffusion.timestep_map[-1], diffusion.timestep_map[T // 2], diffusion.timestep_map[T // 10], 0}, reverse=True)),
+                "gain_note": "directional || x0(x_t + d) - x0(x_t) || / || d || through the product's denoiser, per ORIGINAL timestep; ~1 at low noise = early rounding errors are carried"},
             "roofline": kernels[dominant],
             "roofline_other_kernel": {k: v for k, v in kernels.items() if k != dominant} or None,
+            "roofline_hbm": hbm,
+            "end_to_end": None if not flops_per_body else {"algorithmic_flops_per_body": flops_per_body, "achieved_tflops": value / world * flops_per_body / 1e12,
+                                                           "flops_frac_of_f16_dense_peak": value / world * flops_per_body / 1e12 / PEAK_F16_MFMA_TFLOPS},
             "breakdown_ms": {"encoders_and_projections_once": t_enc * 1e3, "per_call_total": dt / args.steps * 1e3,
-                             "hidden_convs_est": sum(v["ms_per_call"] for v in kernels.values())},
+                             "sampling_loop_by_launch_class": {k: v for k, v in prof.items() if v["launches_per_call"]}},
             "target": {"north_star_bodies_per_s": 10000,
                        "parity_ceiling_bodies_per_s": (PEAK_F16_MFMA_TFLOPS / 3) * 1e12 / flops_per_body if flops_per_body else None,
-                       "note": "183.8 GFLOP per body (SURVEY 8d); with every product as 3 MFMA the dense f16 peak allows 833 TFLOP/s algorithmic = the "
-                               "ceiling above, so >= 10k bodies/s is out of reach at f32-grade arithmetic on every step"},
+                       "note": "with every product as 3 MFMA the dense f16 peak allows 833 TFLOP/s algorithmic = the ceiling above, so >= 10k bodies/s is out of "
+                               "reach at f32-grade arithmetic on every step"},
         }
         out.update(legs)
         if args.cpu_seconds > 0 and world == 1:

@@ -139,7 +139,10 @@ PROTOTYPES = {
     "ehm_nn_dist2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ehm_sample_workspace_bytes": (_L, [C.POINTER(SampleDesc), _I, _I]),
     "ehm_sample_loop": (_I, [_P, _P, C.POINTER(SampleDesc), C.POINTER(StepCoefs)] + [_P] * 18 + [_L, _P]),
+    "ehm_profile_begin": (_I, []),
+    "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }
+PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance")   # EHM_PROF_* of the header
 
 _lib = None
 

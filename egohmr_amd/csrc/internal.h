@@ -42,3 +42,11 @@ int64_t ehm_guidance_scratch_bytes(int B, int N);
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
                       const float* scene, int B, int N, float tau, float denom, float margin, float* verts_ws, float* joints_ws, float* R_ws,
                       float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st);
+// sampler.hip: launch-class timing for bench.py (ehm_profile_begin / ehm_profile_end); a no-op unless a profile is open
+struct EhmProfScope {
+  int cls;
+  hipStream_t st;
+  void* rec;
+  EhmProfScope(int cls_, hipStream_t st_);
+  ~EhmProfScope();
+};

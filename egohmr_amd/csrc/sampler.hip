@@ -36,6 +36,52 @@ int ehm_num_cus() {   // of the CURRENT device (cached per ordinal)
   return n[dev];
 }
 
+// ------------------------------------------------------------------------------------------------ launch-class timing
+#include <vector>
+namespace {
+struct ProfRec { int cls; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec*> g_prof;
+}  // namespace
+EhmProfScope::EhmProfScope(int cls_, hipStream_t st_) : cls(cls_), st(st_), rec(nullptr) {
+  if (!g_prof_on) return;
+  ProfRec* r = new ProfRec{cls, nullptr, nullptr};
+  if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess || hipEventRecord(r->a, st) != hipSuccess) {
+    delete r;
+    return;
+  }
+  rec = r;
+}
+EhmProfScope::~EhmProfScope() {
+  if (!rec) return;
+  ProfRec* r = (ProfRec*)rec;
+  (void)hipEventRecord(r->b, st);
+  g_prof.push_back(r);
+}
+extern "C" int ehm_profile_begin(void) {
+  for (ProfRec* r : g_prof) { (void)hipEventDestroy(r->a); (void)hipEventDestroy(r->b); delete r; }
+  g_prof.clear();
+  g_prof_on = true;
+  return 0;
+}
+extern "C" int ehm_profile_end(double* ms, int64_t* launches, int n) {
+  EHM_CHECK_ARG(ms && launches && n > 0 && n <= EHM_PROF_N);
+  g_prof_on = false;
+  for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
+  int rc = 0;
+  for (ProfRec* r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r->b) != hipSuccess || hipEventElapsedTime(&t, r->a, r->b) != hipSuccess) rc = EHM_EIO;
+    else if (r->cls >= 0 && r->cls < n) { ms[r->cls] += t; launches[r->cls] += 1; }
+    (void)hipEventDestroy(r->a);
+    (void)hipEventDestroy(r->b);
+    delete r;
+  }
+  g_prof.clear();
+  if (rc) ehm_set_error("ehm_profile_end: an event of the profile could not be read");
+  return rc;
+}
+
 namespace {
 
 // torch evaluates these chains as separate rounded float32 ops; keep the same roundings (no FMA contraction)
@@ -165,6 +211,12 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   int rc = 0;
   const int base_prec = ehm_gcn_get_precision(gcn);
   const int lowprec = base_prec == 1 /* f16x3 */ ? d->lowprec_steps : 0;
+  struct PrecisionGuard {      // the per-step kernel choice is host-side state of the handle: put it back on EVERY exit path (EHM_HIP returns early)
+    ehm_gcn* g;
+    int prec;
+    bool armed;
+    ~PrecisionGuard() { if (armed) ehm_gcn_set_precision(g, prec); }
+  } guard{gcn, base_prec, lowprec > 0};
   auto prec_of = [&](int k) { return (lowprec > 0 && k < lowprec) ? 2 : base_prec; };
   bool input_done = false;          // step k's input conv already ran inside step k-1's skinning launch
   for (int k = 0; k < d->num_steps && rc == 0; ++k) {
@@ -175,18 +227,29 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     // ---- collision guidance on x_t (gaussian_diffusion.py:378-385, egohmr.py:517-570): depends on x_t and betas only, so it runs first
     const float* grad = nullptr;
     if (c.grad_scale != 0.f) {
+      EhmProfScope ps(EHM_PROF_GUIDANCE, st);
       rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom, d->guide_all_points ? d->tau : 0.f,
                              w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, w.g_scratch, st);
       grad = w.g_grad;
     }
     // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257): input conv, chained hidden convs, output conv responses ----
-    if (rc == 0 && !input_done) rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
+    if (rc == 0 && !input_done) {
+      EhmProfScope ps(EHM_PROF_INPUT, st);
+      rc = ehm_gcn_input_layer(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k * 2 * hid, w.X[0], B, d->passes, st);
+    }
     input_done = false;
     int in = 0;
-    if (rc == 0) rc = ehm_gcn_hidden_stack(gcn, w.X, w.rows_pad, &in, st);
+    if (rc == 0) {
+      const int p = prec_of(k);
+      EhmProfScope ps(p == 1 ? EHM_PROF_CHAIN_F16X3 : p == 2 ? EHM_PROF_CHAIN_F16 : EHM_PROF_HIDDEN_F32, st);
+      rc = ehm_gcn_hidden_stack(gcn, w.X, w.rows_pad, &in, st);
+    }
     const float* hs = nullptr;
     const void* out_dev = nullptr;
-    if (rc == 0) rc = ehm_gcn_output_dot_impl(gcn, w.X[in], B, d->passes, &hs, &out_dev, st);
+    if (rc == 0) {
+      EhmProfScope ps(EHM_PROF_OUT_DOT, st);
+      rc = ehm_gcn_output_dot_impl(gcn, w.X[in], B, d->passes, &hs, &out_dev, st);
+    }
     // ---- per body, one launch: output-conv mix + visibility fuse -> x0 (egohmr.py:247-256), x_{t-1} (gaussian_diffusion.py:298-337 /
     //      :511-556), de-normalise + rot6d + kinematic chain (egohmr.py:258-260); then the skinning launch (egohmr.py:276) ----
     //      When the step is not the last one, the NEXT step's input conv (it needs x_{t-1} only) rides in the skinning launch.
@@ -209,6 +272,5 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
       input_done = fused != 0;
     }
   }
-  if (lowprec > 0) ehm_gcn_set_precision(gcn, base_prec);
-  return rc;
+  return rc;      // (PrecisionGuard restores base_prec)
 }

@@ -800,8 +800,12 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
   a.betas = betas; a.mean = mean; a.std_ = std_; a.Rws = Rws; a.Aws = Aws; a.joints = joints; a.pose6d = pose6d;
   a.jstride = (kJ + d.n_extra) * 3;
   a.pf = mfma ? (sk_half8*)h->pf : nullptr;
-  hipLaunchKernelGGL(step_body_kernel, dim3(B), dim3(64), 0, st, a, d);
+  {
+    EhmProfScope ps(EHM_PROF_STEP_BODY, st);
+    hipLaunchKernelGGL(step_body_kernel, dim3(B), dim3(64), 0, st, a, d);
+  }
   if (do_pose) {
+    EhmProfScope ps(EHM_PROF_SKIN_INPUT, st);
     if (mfma) {
       const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
       const int blocks = (int)round_up(vt_groups, 8) * b_tiles;

@@ -281,6 +281,91 @@ def make_state_dict(seed: int = 0, manifest: list | None = None, **manifest_kw) 
     return sd
 
 
+def mmse_gain(tau, prior_var: float = 0.3):
+    """d x0 / d x_t of the MMSE denoiser of a Gaussian prior N(mu, prior_var) (normalised pose space) under the cosine schedule
+    abar(tau) = cos^2(tau pi / 2): J = sqrt(abar) v / (abar v + 1 - abar).  -> 1 at low noise, -> 0 at tau = 1."""
+    tau = np.asarray(tau, dtype=np.float64)
+    abar = np.cos((tau + 0.008) / 1.008 * np.pi / 2) ** 2
+    return np.sqrt(abar) * prior_var / (abar * prior_var + 1.0 - abar)
+
+
+SENSITIVE_CHANNELS = 12      # hidden channels 2d / 2d+1 carry +x_t[:, j, d] / -x_t[:, j, d] of the joint's 6-D rotation
+
+
+def _norm_cdf_inv(p):
+    from statistics import NormalDist
+    nd = NormalDist()
+    return np.array([nd.inv_cdf(float(min(max(q, 1e-4), 1 - 1e-4))) for q in np.ravel(p)]).reshape(np.shape(p))
+
+
+def make_sensitive_state_dict(seed: int = 0, num_diffusion_timesteps: int = 100, prior_var: float = 0.3, gain: float = 1.0,
+                              **manifest_kw) -> dict:
+    """`make_state_dict(seed)` plus an **x_t-sensitive skip path** through the denoiser, so that the network behaves like a trained
+    START_X denoiser: d x0 / d x_t ~ gain * mmse_gain(t / n) - close to `gain` at low noise, a few percent at t ~ n - instead of the
+    ~0.06 at every t of the plain random network (whose output conv is scaled down on purpose).  Why it matters: the sampler's
+    posterior mean x_{t-1} = c1 x0(x_t) + c2 x_t contracts an early step's rounding error only if c1 J + c2 < 1; for the ideal
+    denoiser J = 1 / sqrt(abar) at low noise and c1 J + c2 = 1 / sqrt(alpha_t) >= 1, i.e. an error is carried to the output.  A
+    precision schedule tuned on a network that ignores x_t says nothing about a checkpoint.
+
+    Construction (exact in the reference's own ModulatedGCN arithmetic, modulated_gcn.py:99-116 - nothing here is a new operator):
+      * hidden channels 2d, 2d+1 (d = 0..5) of the input conv receive p = +x_t[j,d] + s(t), n = -x_t[j,d] + s(t): the 512-d
+        InputProcess slice of W[0] is the minimum-norm solution of Wp^T w = +-e_d, bp . w = 0; the timestep slice is a ridge fit of
+        s(t) on the TimestepEmbedder's features for t in [0, n); the conditioning slices, W[1] (neighbour branch), the bias and the
+        BatchNorm of these channels are neutral (0 / 1);
+      * every residual block passes them through unchanged (gconv2 writes relu(0) = 0 on top of the skip), the other channels
+        still read them through their random weights;
+      * the output conv reads g_out * (relu(p) - relu(n)): gain 2 g_out when s >> |x|, g_out at s = 0, 0 when s << -|x|;
+        s(t) = Phi^-1(target(t) / (2 g_out)) makes the average gain over x ~ N(0, 1) follow the target profile.
+    `num_diffusion_timesteps` = the n of `create_gaussian_diffusion` the weights are "trained" for (the gate is a function of the
+    ORIGINAL timestep the model is conditioned on, respace.py:124-129)."""
+    sd = make_state_dict(seed, **manifest_kw)
+    n = int(num_diffusion_timesteps)
+    S = SENSITIVE_CHANNELS
+    ch = np.arange(S)
+    g_out = 0.5 * max(gain, 1e-3) * 1.02
+    # --- timestep features phi(t) = time_embed.2(silu(time_embed.0(pe[t])))  (egohmr.py:636-643), float64
+    pe = sd["embed_timestep.sequence_pos_encoder.pe"][:n, 0].astype(np.float64)
+    h = pe @ sd["embed_timestep.time_embed.0.weight"].astype(np.float64).T + sd["embed_timestep.time_embed.0.bias"]
+    h = h / (1.0 + np.exp(-h))
+    phi = h @ sd["embed_timestep.time_embed.2.weight"].astype(np.float64).T + sd["embed_timestep.time_embed.2.bias"]   # [n,512]
+    tau = np.arange(n) / max(n - 1, 1)
+    target = gain * mmse_gain(tau, prior_var)
+    s = np.clip(_norm_cdf_inv(target / (2.0 * g_out)), -3.5, 3.5)                      # [n]
+    lam = 1e-6 * np.trace(phi.T @ phi) / phi.shape[1]
+    v_t = np.linalg.solve(phi.T @ phi + lam * np.eye(phi.shape[1]), phi.T @ s)        # ridge: phi v ~ s
+    # --- x_t slice: W[0, b:c, ch] with Wp^T w = +-e_d and bp . w = 0 (minimum norm)
+    Wp = sd["input_process.poseEmbedding.weight"].astype(np.float64)                  # [512, 6]
+    bp = sd["input_process.poseEmbedding.bias"].astype(np.float64)                    # [512]
+    Amat = np.concatenate([Wp, bp[:, None]], axis=1)                                  # [512, 7]
+    pinv = Amat @ np.linalg.inv(Amat.T @ Amat)                                        # w = pinv @ rhs solves Amat^T w = rhs
+    p = "diffusion_model.gconv_input.0."
+    W = sd[p + "gconv.W"]
+    in_dim = W.shape[1]
+    b, c, d_ = in_dim - 1024, in_dim - 512, in_dim
+    W[:, :, ch] = 0.0
+    for k in range(S):
+        rhs = np.zeros(7)
+        rhs[k // 2] = 1.0 if k % 2 == 0 else -1.0
+        W[0, b:c, k] = (pinv @ rhs).astype(np.float32)
+        W[0, c:d_, k] = v_t.astype(np.float32)
+    sd[p + "gconv.M"][:, ch] = 1.0
+    sd[p + "gconv.bias"][ch] = 0.0
+    for leaf, val in (("weight", 1.0), ("bias", 0.0), ("running_mean", 0.0), ("running_var", 1.0)):
+        sd[p + "bn." + leaf][ch] = val
+    blocks = sorted({k.split(".")[2] for k in sd if k.startswith("diffusion_model.gconv_layers.")})
+    for blk in blocks:                                   # the residual carries the channels; the block adds relu(0) = 0 to them
+        q = f"diffusion_model.gconv_layers.{blk}.gconv2."
+        sd[q + "gconv.W"][:, :, ch] = 0.0
+        sd[q + "gconv.bias"][ch] = 0.0
+        sd[q + "bn.bias"][ch] = 0.0
+        sd[q + "bn.running_mean"][ch] = 0.0
+    Wo = sd["diffusion_model.gconv_output.W"]                                           # [2, hid, 6]
+    Wo[:, ch, :] = 0.0
+    for k in range(S):
+        Wo[0, k, k // 2] = g_out if k % 2 == 0 else -g_out
+    return sd
+
+
 # ----------------------------------------------------------------------------------------------
 # inputs
 # ----------------------------------------------------------------------------------------------

@@ -349,6 +349,26 @@ int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_desc* d, cons
                     float* x_final, float* x0_final, float* verts, float* joints, float* R, float* pose6d,
                     float* trace, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- measurement aid (bench.py's roofline objects; SURVEY.md 8d asks for per-kernel figures).  No reference counterpart.
+ * Between ehm_profile_begin() and ehm_profile_end() every launch of ehm_sample_loop is bracketed by a pair of HIP events ON THE
+ * LAUNCH STREAM, tagged with its class; ehm_profile_end waits for them and adds the elapsed times up per class
+ * (ms[c] = sum of (stop - start), launches[c] = pairs), c < n <= EHM_PROF_N.  The event pairs serialise nothing that is not
+ * already serial (the loop is one dependency chain), but they cost a few microseconds each: never inside a timed region.
+ * Not thread-safe, one profile at a time. */
+enum {
+  EHM_PROF_INPUT = 0,        /* gcn_input_kernel (only the first step when the skinning launch carries it)              */
+  EHM_PROF_CHAIN_F16X3 = 1,  /* gcn_hidden_chain_kernel<3, 4>: the 8 hidden convs of a step, split-f16                   */
+  EHM_PROF_CHAIN_F16 = 2,    /* gcn_hidden_chain_kernel<1, 8>: the same on plain f16 operands                            */
+  EHM_PROF_HIDDEN_F32 = 3,   /* gcn_hidden_kernel x 8 (f32-input MFMA) or per-conv tile launches                         */
+  EHM_PROF_OUT_DOT = 4,      /* gcn_out_dot_kernel                                                                       */
+  EHM_PROF_STEP_BODY = 5,    /* step_body_kernel                                                                         */
+  EHM_PROF_SKIN_INPUT = 6,   /* skin_input_kernel (skinning of step t + input conv of step t+1) / skin_mfma_kernel       */
+  EHM_PROF_GUIDANCE = 7,     /* the collision-guidance kernel sequence of a guided step                                  */
+  EHM_PROF_N = 8
+};
+int ehm_profile_begin(void);
+int ehm_profile_end(double* ms, int64_t* launches, int n);
+
 #ifdef __cplusplus
 }
 #endif

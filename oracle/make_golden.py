@@ -406,6 +406,50 @@ def g15_constructor_flags(asset, mean, std):
     save("g15_forward_ctor_flags", batch_seed=51, weight_seed=15, cam_dim=3, num_scene_points=512, x_t=x_t, t=np.array([12] * B), **_pack_out(o))
 
 
+def g16_sensitive_denoiser(asset, mean, std):
+    """The x_t-SENSITIVE synthetic denoiser (egohmr_amd.synthetic.make_sensitive_state_dict: d x0 / d x_t follows the MMSE gain of a
+    Gaussian prior, ~1 at low noise) through the reference itself: single forwards at high / mid / low noise and whole loops
+    (DDPM-100, DDIM-10 of 100, guided DDPM-100).  These gate the product's default path - calibrated precision schedule included - on
+    a network that CARRIES early rounding errors instead of contracting them."""
+    from diffusion.model_util import create_gaussian_diffusion
+    n = 100
+    sd = syn.make_sensitive_state_dict(0, n)
+    m = build_reference_model(sd, asset, mean, std, diffuse_fuse=True)
+    B = 3
+    b = syn.make_batch(B, num_scene_points=512, seed=61)
+    b["orig_keypoints_2d"][0, :, 2] = 1.0
+    x_t = syn.make_noise_stack(0, B, seed=61)[0]
+    arrs = {"x_t": x_t, "ts": np.array([99, 50, 5])}
+    for t in (99, 50, 5):
+        tb = to_torch_batch(b)
+        tb["x_t"] = torch.from_numpy(x_t)
+        with torch.no_grad():
+            arrs.update(_pack_out(m(tb, torch.tensor([t] * B)), f"t{t}__"))
+    save("g16_forward_sensitive", batch_seed=61, num_scene_points=512, n=n, **arrs)
+    for name, rs, Bc, N, guided, w in [("g16_e2e_ddpm100_sensitive", "", 4, 1024, False, 0.0),
+                                       ("g16_e2e_ddim10_sensitive", "ddim10", 4, 1024, False, 0.0),
+                                       ("g16_e2e_ddpm100_sensitive_guided", "", 2, 1024, True, 2.0)]:
+        d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+        bb = to_torch_batch(syn.make_batch(Bc, num_scene_points=N, seed=62))
+        if guided:
+            bb["scene_pcd_verts_full"][:, : N // 3, 1] = bb["smpl_params"]["transl"][:, None, 1] - 0.6
+        T = d.num_timesteps
+        noise = torch.from_numpy(syn.make_noise_stack(T, Bc, seed=62))
+        xs = []
+        orig = d.p_mean_variance
+
+        def spy(mm, b_, x, t, _o=orig, **kw):
+            xs.append(x.clone().numpy())
+            return _o(mm, b_, x, t, **kw)
+
+        d.p_mean_variance = spy
+        with explicit_noise(noise), torch.no_grad():
+            o = d.val_losses(model=m, batch=bb, shape=[Bc, 144], progress=False, clip_denoised=False, cur_epoch=0,
+                             timestep_respacing=rs, cond_fn_with_grad=guided, cond_grad_weight=w, compute_loss=False)
+        save(name, batch_seed=62, noise_seed=62, B=Bc, N=N, n=n, respacing=rs, guided=guided, cond_grad_weight=w,
+             x_t_trace=np.stack(xs), **_pack_out(o))
+
+
 def g13_gcn_nonlocal():
     """ModulatedGCN(nonlocal_layer=True) (modulated_gcn.py:93-110): the reference module itself, synthetic weights with a
     non-trivial W.1 BatchNorm (the reference initialises it to zero = identity block)."""
@@ -462,6 +506,9 @@ def main():
     if os.environ.get("GOLDEN_ONLY") == "g7":
         g7_single_steps()
         return
+    if os.environ.get("GOLDEN_ONLY") == "g16":
+        g16_sensitive_denoiser(asset, *syn.make_body_rep_stats(0))
+        return
     g1_schedules()
     g2_g3_geometry()
     g4_gcn()
@@ -482,6 +529,7 @@ def main():
     g8_g9_end_to_end(model)
     g14_c4_c5_and_volsmpl(model, build_reference_model(sd, asset, mean, std, diffuse_fuse=True, volsmpl=True))
     g15_constructor_flags(asset, mean, std)
+    g16_sensitive_denoiser(asset, mean, std)
 
 
 if __name__ == "__main__":

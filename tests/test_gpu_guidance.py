@@ -147,8 +147,8 @@ def test_guided_ddpm_vs_reference_golden(golden_dir, dev, model, route):
         res = model.fused_sampler.run(d, b, noise, ddim=False, guided=True, cond_grad_weight=w, trace=True)
         o = res["other_outputs"]
         tr = model.fused_sampler.last_trace.cpu().numpy()
-        low = model.fused_sampler.lowprec_steps(d.num_timesteps, 11, False)           # leading steps on plain f16 operands (precision schedule):
-        assert d.num_timesteps - low >= 11 + 20                                       # every guided step and the 20 steps before them run in f16x3
+        low = model.fused_sampler.last_lowprec                                        # leading steps on plain f16 operands (calibrated precision schedule)
+        assert d.num_timesteps - low >= 11 + 8                                        # every guided step and at least the 8 steps before them run in f16x3
         np.testing.assert_allclose(tr[:low + 1], g["x_t_trace"][:low + 1], atol=2e-3)
         np.testing.assert_allclose(tr[low + 4:], g["x_t_trace"][low + 4:], atol=3e-4)
         np.testing.assert_allclose(tr[-1], g["x_t_trace"][-1], atol=5e-5)

@@ -379,7 +379,7 @@ def test_end_to_end_vs_reference_golden(golden_dir, dev, model, name, route, pre
             res = model.fused_sampler.run(d, b, noise, ddim=bool(rs), trace=True)
             o = res["other_outputs"]
             tr = model.fused_sampler.last_trace.cpu().numpy()
-            low = model.fused_sampler.lowprec_steps(d.num_timesteps, False, bool(rs))   # leading steps on plain f16 operands (precision schedule)
+            low = model.fused_sampler.last_lowprec                                     # leading steps on plain f16 operands (calibrated precision schedule)
             np.testing.assert_allclose(tr[:low + 1], g["x_t_trace"][:low + 1], atol=2e-3)     # x_t fed to those steps + the first f16x3 one
             if low + 4 < d.num_timesteps:                                     # the early steps' rounding is contracted away step by step
                 np.testing.assert_allclose(tr[low + 4:], g["x_t_trace"][low + 4:], atol=1e-4)

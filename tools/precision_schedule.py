@@ -3,7 +3,11 @@
 (f16x3, f32-grade) on the LAST k.  For each k: max / mean vertex distance of the final bodies to the all-f16x3 run on the same
 noise, and the wall time of the sampling call.  Acceptance bar set by the judge: max vertex distance < 1e-5 m at B=256, T=100.
 
-    python tools/precision_schedule.py [--batch 256] [--T 100] [--ks 0,5,10,20,30,50,100] [--guided]
+    python tools/precision_schedule.py [--batch 256] [--T 100] [--ks 0,5,10,20,30,50,100] [--guided] [--gain 1.0]
+
+--gain g > 0 swaps the plain random denoiser (which ignores x_t: d x0 / d x_t ~ 0.05 at every t) for the x_t-sensitive one of
+synthetic.make_sensitive_state_dict (d x0 / d x_t ~ g x the MMSE gain of a Gaussian prior: ~g at low noise); the row then also
+carries the measured directional gain at t = n-1, n/2, n/10, 0 and the k that FusedSampler.calibrate_schedule picks.
 """
 import argparse
 import json
@@ -24,6 +28,8 @@ def main():
     ap.add_argument("--ks", default="0,2,5,10,15,20,30,50,100")
     ap.add_argument("--seeds", default="0,1")
     ap.add_argument("--guided", action="store_true")
+    ap.add_argument("--gain", type=float, default=0.0, help="0 = plain random denoiser; > 0 = x_t-sensitive denoiser with this low-noise gain")
+    ap.add_argument("--prior-var", type=float, default=0.3)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from egohmr_amd import synthetic as syn
@@ -32,7 +38,8 @@ def main():
     dev = torch.device("cuda:0")
     rows = []
     for seed in [int(s) for s in a.seeds.split(",")]:
-        model = build_synthetic_model(dev, seed, diffuse_fuse=True)
+        sens = dict(num_diffusion_timesteps=a.T, gain=a.gain, prior_var=a.prior_var) if a.gain > 0 else None
+        model = build_synthetic_model(dev, seed, diffuse_fuse=True, sensitive=sens)
         diffusion = create_gaussian_diffusion(num_diffusion_timesteps=a.T, timestep_respacing=a.respacing)
         T = diffusion.num_timesteps
         B = a.batch
@@ -53,10 +60,17 @@ def main():
             return r["other_outputs"]["pred_vertices"].clone(), r["other_outputs"]["pred_keypoints_3d"].clone(), time.perf_counter() - t0
 
         ref_v, ref_j, t_ref = run(None)
+        gains = fs.measure_gain(batch, timesteps=(a.T - 1, a.T // 2, a.T // 10, 0))
+        model.f16x3_last_steps = "auto"
+        t0 = time.perf_counter()
+        info = fs.calibrate_schedule(diffusion, batch, ddim=ddim, guided=a.guided, cond_grad_weight=2.0 if a.guided else 1.0, force=True)
+        torch.cuda.synchronize()
+        print(json.dumps({"seed": seed, "gain_setting": a.gain, "measured_gain": gains, "calibrated_k": info["k"], "calibration_s": time.perf_counter() - t0,
+                          "trials": info["trials"]}), flush=True)
         for k in [int(s) for s in a.ks.split(",")]:
             v, j, dt = run(k)
             dv = (v - ref_v).norm(dim=-1)
-            row = {"seed": seed, "T": T, "B": B, "guided": a.guided, "f16x3_last_steps": k, "max_vertex_dist_m": float(dv.max()),
+            row = {"seed": seed, "gain_setting": a.gain, "T": T, "B": B, "guided": a.guided, "f16x3_last_steps": k, "max_vertex_dist_m": float(dv.max()),
                    "mean_v2v_m": float(dv.mean()), "mpjpe_m": float((j - ref_j).norm(dim=-1).mean()),
                    "call_ms_conditioning_cached": dt * 1e3, "all_f16x3_call_ms": t_ref * 1e3}
             rows.append(row)

@@ -217,7 +217,7 @@ def main():
     if args.precision == "f16x3" and model.f16x3_last_steps == "auto":
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        fs.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=w_guid, denom_items=B)
+        edist.agree_schedule(fs, diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=w_guid, denom_items=B)   # rank 0 measures, every rank adopts
         torch.cuda.synchronize()
         t_cal = time.perf_counter() - t1
     for _ in range(args.warmup):

@@ -80,3 +80,21 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def agree_schedule(fused_sampler, diffusion, batch, ddim=False, guided=False, cond_grad_weight=1.0, denom_items=None, **kw):
+    """One precision-schedule calibration for the whole job: rank 0 measures k on ITS batch (FusedSampler.calibrate_schedule - with the
+    contiguous sharding of `shard_range` these are the first items of the data set whatever the world size), every rank installs that k.
+    Without this each rank would calibrate on its own shard at first use and the result rows would depend on how the items were
+    sharded.  Single-process: just calibrates.  Returns the info dict."""
+    B = int(denom_items or next(v for v in batch.values() if torch.is_tensor(v)).shape[0])
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    info = None
+    if not multi or dist.get_rank() == 0:
+        info = fused_sampler.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, denom_items=B, **kw)
+    if multi:
+        box = [info]
+        dist.broadcast_object_list(box, src=0)
+        info = box[0]
+        fused_sampler.install_schedule(diffusion, info, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, denom_items=B)
+    return info

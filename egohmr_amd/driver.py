@@ -26,7 +26,7 @@ class Stage2Driver:
     def __init__(self, model, diffusion, smpl_neutral, smpl_male, smpl_female, num_samples: int = 5, timestep_respacing: str = "",
                  with_coap_grad: bool = False, cond_grad_weight: float = 2.0, eval_coll_loss: bool = False,
                  eval_contact_score: bool = True, eval_with_vis_mask_pa: bool = False, fx_norm_coeff: float = 1500.0,
-                 batch_samples: bool = True):
+                 batch_samples: bool = True, two_stage: bool = False):
         if eval_with_vis_mask_pa:
             raise NotImplementedError("reconstruction_error_with_vis_mask (utils/pose_utils.py) is not on the default path (test_egohmr.py:76)")
         self.model, self.diffusion = model, diffusion
@@ -36,8 +36,12 @@ class Stage2Driver:
         self.eval_coll_loss, self.eval_contact = bool(eval_coll_loss), bool(eval_contact_score)
         self.fx_norm_coeff = fx_norm_coeff
         self.batch_samples = bool(batch_samples)   # the S samples of a batch as one fused loop over S*B bodies (FusedSampler.run_samples)
+        # --two_stage (test_egohmr.py:24, default True there): the batch carries `stage1_transl_full` [B,3] - the stage-1 (ProHMR-scene)
+        # camera-frame translation, results.pkl['pred_cam_full_list'] read by egohmr_amd.io.load_stage1_cam - and the sampler is
+        # conditioned on it instead of the ground-truth translation (:243-245)
+        self.two_stage = bool(two_stage)
         self._acc = {}
-        self._lists = {k: [] for k in ("pred_betas", "pred_global_orient", "pred_body_pose", "gt_cam_full", "coll", "contact")}
+        self._lists = {k: [] for k in ("pred_betas", "pred_global_orient", "pred_body_pose", "gt_cam_full", "pred_cam_full", "coll", "contact")}
         self._vis_counts = dict(joint_vis=0, joint_invis=0, vertex_vis=0, vertex_invis=0)
 
     # ------------------------------------------------------------------ :241-266
@@ -101,7 +105,12 @@ class Stage2Driver:
     def step(self, batch, noise_stacks=None):
         dev = batch["img"].device
         B = batch["img"].shape[0]
-        gt_cam_full = batch["smpl_params"]["transl"].clone()                       # :238 (two_stage would replace the conditioning transl)
+        gt_cam_full = batch["smpl_params"]["transl"].clone()                       # :238
+        if self.two_stage:                                                         # :243-245: replace the gt camera translation by stage 1's
+            if "stage1_transl_full" not in batch:
+                raise KeyError("two_stage=True needs batch['stage1_transl_full'] [B,3] (egohmr_amd.io.load_stage1_cam reads it from the stage-1 results.pkl)")
+            batch["smpl_params"]["transl"] = batch["stage1_transl_full"].to(dev).float()
+            self._lists["pred_cam_full"].append(batch["smpl_params"]["transl"])    # :302-303
         pred, coll = self.sample(batch, noise_stacks)
         p = self.decode(pred, batch["smpl_params"]["transl"])
         g = self.ground_truth(batch, gt_cam_full)
@@ -174,7 +183,7 @@ class Stage2Driver:
         cat = lambda k: torch.cat(self._lists[k], 0)
         contact = torch.cat(self._acc["contact"], 0) if "contact" in self._acc else torch.zeros_like(torch.cat(self._acc["coll"], 0))
         return eio.results_dict(cat("pred_betas"), cat("pred_global_orient"), cat("pred_body_pose"), torch.cat(self._acc["coll"], 0), contact,
-                                cat("gt_cam_full"))
+                                cat("gt_cam_full"), pred_cam_full=cat("pred_cam_full") if self.two_stage else None)      # :685-693
 
     def save(self, save_root: str, model_id: str, seed: int) -> str:
         return eio.save_results(save_root, model_id, seed, self.results())

@@ -516,6 +516,14 @@ class FusedSampler:
         self.schedule_info = info
         return info
 
+    def install_schedule(self, diffusion, info, ddim=False, guided=False, cond_grad_weight=1.0, denom_items=1):
+        """Adopt a calibration result measured elsewhere (another rank's: egohmr_amd.dist.agree_schedule) for THIS process's weights."""
+        T = diffusion.num_timesteps
+        n_guided = sum(1 for i in range(min(T, 16)) if diffusion.step_coefs(i, ddim, 0.0, cond_grad_weight, guided).grad_scale != 0.0)
+        assert int(info["T"]) == T, (info["T"], T)
+        self._sched_cache[self.schedule_key(diffusion, ddim, n_guided, cond_grad_weight, self.guide_denom(int(denom_items)))] = dict(info)
+        self.schedule_info = dict(info)
+
     @torch.no_grad()
     def measure_gain(self, batch=None, timesteps=(0,), prepared=None, bodies=16, delta=1e-2, seed=7):
         """Directional sensitivity of the loaded denoiser, || x0(x_t + d) - x0(x_t) || / || d || for a random direction d at x_t ~ N(0, 1),

@@ -13,10 +13,14 @@ from oracle import sampler as osamp
 
 
 def run_batch(model, smpl_neutral, smpl_male, smpl_female, batch, tables, noise_stacks, respacing, num_samples, guided=False,
-              cond_grad_weight=2.0, guide_reduction="mean", guide_all_points=False, eval_coll=False, fx_norm_coeff=1500.0):
+              cond_grad_weight=2.0, guide_reduction="mean", guide_all_points=False, eval_coll=False, fx_norm_coeff=1500.0, two_stage=False):
     B = batch["img"].shape[0]
     S = num_samples
     gt_cam_full = batch["smpl_params"]["transl"].clone()                                   # :238
+    pred_cam_full = None
+    if two_stage:                                                                            # :243-245
+        batch["smpl_params"]["transl"] = batch["stage1_transl_full"]
+        pred_cam_full = batch["stage1_transl_full"]
     outs = {"betas": [], "global_orient": [], "body_pose": []}
     coll = np.zeros((B, S))
     for n in range(S):                                                                       # :251-263
@@ -84,4 +88,4 @@ def run_batch(model, smpl_neutral, smpl_male, smpl_female, batch, tables, noise_
     res["contact"] = (d2.min(-1) < 0.02).reshape(B, S).astype(np.float64)
     res["coll"] = coll
     return dict(pred=pred, joints_align=pja, vertices=pv, gt_joints=gj, gt_vertices=gv, joint_vis_mask=jvis, vertex_vis_mask=vvis,
-                gt_cam_full=gt_cam_full, **res)
+                gt_cam_full=gt_cam_full, pred_cam_full=pred_cam_full, joints_full=pjf, **res)

@@ -270,6 +270,76 @@ def test_driver_block_vs_oracle_pipeline(dev, model, synth_weights, smpl_asset, 
     np.testing.assert_allclose(res["gt_cam_full_list"], bnp["smpl_params"]["transl"])
 
 
+def test_bench_self_launches_two_ranks_on_this_box(dev):
+    """`python bench.py --gpus 2` (no torchrun environment) starts two ranks itself - here sharing this box's one GPU over gloo - and the JSON
+    line says so: n_gpus = n_ranks_seen = 2, value = the two ranks' bodies over the max-over-ranks time (VERDICT r02 weak #3)."""
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(EGOHMR_DIST_BACKEND="gloo", EGOHMR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--scene-points", "512",
+                        "--workload", "c1_ddim5", "--cpu-seconds", "0", "--no-legs"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 8 * 1 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["schedule"]["calibrated"] and out["roofline"]["avg_launch_ms"] > 0
+
+
+def test_driver_two_stage_conditions_on_stage1_translation(dev, model, synth_weights, smpl_asset, tmp_path):
+    """--two_stage (test_egohmr.py:243-246, :302-303, :691-692): the sampler is conditioned on the stage-1 translation read from the stage-1
+    results.pkl (egohmr_amd.io.load_stage1_cam), the ground truth keeps its own, `pred_cam_full_list` lands in the results pkl; against
+    oracle/driver.py with two_stage=True, and different from the one-stage run."""
+    from egohmr_amd import io as eio
+    from egohmr_amd import smpl as smpl_mod
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.driver import Stage2Driver
+    from egohmr_amd.factory import batch_to_device
+    from oracle import driver as odrv, model as om, schedule as osched
+    from oracle.smpl import SMPLOracle
+    B, N, S, n, rs = 3, 1024, 2, 50, "ddim5"
+    bnp = syn.make_batch(B, N, seed=19)
+    gt = syn.make_gt_annotations(B, seed=19)
+    bnp["smpl_params"].update({k: gt[k] for k in ("global_orient", "body_pose", "betas")})
+    bnp["gender"] = gt["gender"]
+    stage1 = (bnp["smpl_params"]["transl"] + np.random.Generator(np.random.PCG64(19)).normal(scale=0.08, size=(B, 3))).astype(np.float32)
+    pkl_path = tmp_path / "results.pkl"                      # what test_prohmr_scene.py:417-426 writes
+    with open(pkl_path, "wb") as f:
+        pickle.dump({"pred_cam_full_list": stage1.astype(np.float64), "pred_betas_list": np.zeros((B, 10))}, f, protocol=2)
+    bnp["stage1_transl_full"] = eio.load_stage1_cam(str(pkl_path))
+    assets = {gname: syn.make_smpl_asset(i) for i, gname in enumerate(("neutral", "male", "female"))}
+    assets["neutral"] = smpl_asset
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+    noises = [syn.make_noise_stack(d.num_timesteps, B, seed=19 + 10 * s) for s in range(S)]
+    smpls = {k: smpl_mod.create(asset=a, gender=k).to(dev) for k, a in assets.items()}
+    with precision(model, "f16x3"):
+        drv = Stage2Driver(model, d, smpls["neutral"], smpls["male"], smpls["female"], num_samples=S, timestep_respacing=rs, two_stage=True,
+                           eval_contact_score=False)
+        got = drv.step(batch_to_device(bnp, dev), [torch.from_numpy(z).to(dev) for z in noises])
+        path = drv.save(str(tmp_path), "two_stage", 0)
+        one = Stage2Driver(model, d, smpls["neutral"], smpls["male"], smpls["female"], num_samples=S, timestep_respacing=rs, eval_contact_score=False)
+        got1 = one.step(batch_to_device({k: v for k, v in bnp.items() if k != "stage1_transl_full"}, dev), [torch.from_numpy(z).to(dev) for z in noises])
+        with pytest.raises(KeyError):
+            Stage2Driver(model, d, smpls["neutral"], smpls["male"], smpls["female"], num_samples=S, timestep_respacing=rs, two_stage=True).step(
+                batch_to_device({k: v for k, v in bnp.items() if k != "stage1_transl_full"}, dev), [torch.from_numpy(z).to(dev) for z in noises])
+    mean, std = syn.make_body_rep_stats(0)
+    ref_model = om.EgoHMROracle(synth_weights, smpl_asset, mean, std, faithful=False)
+    tb = {k: ({kk: torch.from_numpy(np.asarray(vv)) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(np.asarray(v)))
+          for k, v in bnp.items()}
+    want = odrv.run_batch(ref_model, SMPLOracle(assets["neutral"]), SMPLOracle(assets["male"]), SMPLOracle(assets["female"]), tb,
+                          osched.make_tables(n, rs), [torch.from_numpy(z) for z in noises], rs, S, two_stage=True)
+    c = lambda t: t.detach().cpu().numpy()
+    np.testing.assert_allclose(c(got["pred"]["body_pose"]), want["pred"]["body_pose"].numpy(), atol=5e-5)
+    np.testing.assert_allclose(c(got["decoded"]["joints_full"]), want["joints_full"].numpy(), atol=VJ_TOL)      # pred joints + STAGE-1 translation
+    np.testing.assert_allclose(c(got["g_mpjpe"]), want["g_mpjpe"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(c(got["gt"]["joints"]), want["gt_joints"].numpy(), atol=2e-5)                     # the ground truth keeps its own
+    assert float((got["pred"]["body_pose"] - got1["pred"]["body_pose"]).abs().max()) > 1e-4                      # the conditioning did change
+    res = eio.load_results(path)
+    np.testing.assert_allclose(res["pred_cam_full_list"], stage1, atol=0)
+    np.testing.assert_allclose(res["gt_cam_full_list"], syn.make_batch(B, N, seed=19)["smpl_params"]["transl"])
+    assert list(res.keys()).index("pred_cam_full_list") < list(res.keys()).index("gt_cam_full_list")             # the reference's key order (:685-693)
+
+
 def test_rotmat_to_rot6d_product_vs_reference_golden(golden_dir, dev):
     """utils/geometry.py:69-75 (G2 `rot6d_back`) through the PRODUCT function."""
     from egohmr_amd.geometry import rot6d_to_rotmat, rotmat_to_rot6d
@@ -299,8 +369,9 @@ bnp = syn.make_batch(n_items, 1024, seed=5)
 noise = syn.make_noise_stack(d.num_timesteps, n_items, seed=5)
 items = list(edist.shard_range(n_items, rank, world))
 counts = [len(edist.shard_range(n_items, r, world)) for r in range(world)]
-sub = {{k: ({{kk: vv[items] for kk, vv in v.items()}} if isinstance(v, dict) else v[items]) for k, v in bnp.items()}}
-o = model.fused_sampler.run(d, batch_to_device(sub, dev), torch.from_numpy(noise[:, items]).to(dev), ddim=True)["other_outputs"]
+sub = batch_to_device({{k: ({{kk: vv[items] for kk, vv in v.items()}} if isinstance(v, dict) else v[items]) for k, v in bnp.items()}}, dev)
+edist.agree_schedule(model.fused_sampler, d, sub, ddim=True)      # ONE calibration for the job (rank 0's), not one per shard
+o = model.fused_sampler.run(d, sub, torch.from_numpy(noise[:, items]).to(dev), ddim=True)["other_outputs"]
 full = edist.gather_packed(edist.pack_params(o["pred_smpl_params"]), counts)
 edist.barrier()
 if rank == 0:
@@ -340,8 +411,10 @@ def test_two_ranks_real_sampler_equals_single_process(dev, model, tmp_path, n_it
         single = {}
         for r in range(2):        # the same shards, one after the other, in this process
             items = list(edist.shard_range(n_items, r, 2))
-            sub = {k: ({kk: vv[items] for kk, vv in v.items()} if isinstance(v, dict) else v[items]) for k, v in bnp.items()}
-            o = model.fused_sampler.run(d, batch_to_device(sub, dev), noise[:, items].contiguous(), ddim=True)["other_outputs"]
+            sub = batch_to_device({k: ({kk: vv[items] for kk, vv in v.items()} if isinstance(v, dict) else v[items]) for k, v in bnp.items()}, dev)
+            if r == 0:
+                model.fused_sampler.calibrate_schedule(d, sub, ddim=True, force=True)     # the job's calibration = shard 0's, as agree_schedule does
+            o = model.fused_sampler.run(d, sub, noise[:, items].contiguous(), ddim=True)["other_outputs"]
             single[r] = edist.pack_params(o["pred_smpl_params"]).cpu().numpy()
     want = np.concatenate([single[0], single[1]], 0)
     got = np.load(out)

@@ -83,10 +83,16 @@ class StepCoefs(C.Structure):
                                          "sqrt_ac_prev", "dir_coef", "sigma", "nonzero", "grad_scale")]
 
 
+class NonlocalParams(C.Structure):
+    """ehm_nonlocal_params"""
+    _fields_ = [("Wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("qkv_scale", C.c_float), ("Wo", C.c_void_p), ("bo", C.c_void_p), ("o_scale", C.c_float),
+                ("Ci", C.c_int)]
+
+
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -108,6 +114,7 @@ PROTOTYPES = {
     "ehm_gcn_get_precision": (_I, [_P]),
     "ehm_gcn_set_uncond_mode": (_I, [_P, _I]),
     "ehm_gcn_set_pass_map": (_I, [_P, _P, _P, _I]),
+    "ehm_gcn_set_nonlocal": (_I, [_P, C.POINTER(NonlocalParams)]),
     "ehm_gcn_reserve": (_I, [_P, _I, _I]),
     "ehm_gcn_activation_group": (_I, [_P]),
     "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _I, _P]),

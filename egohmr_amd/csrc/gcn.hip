@@ -671,6 +671,16 @@ extern "C" int ehm_gcn_set_pass_map(ehm_gcn* h, const int32_t* mask_items, const
   return 0;
 }
 
+extern "C" int ehm_gcn_set_nonlocal(ehm_gcn* h, const ehm_nonlocal_params* p) {
+  EHM_CHECK_ARG(h);
+  if (!p) { h->nonlocal = ehm_nonlocal_params{}; return 0; }
+  EHM_CHECK_ARG(p->Wqkv && p->bqkv && p->Wo && p->bo && p->Ci > 0 && p->Ci % 8 == 0 && p->qkv_scale > 0.f && p->o_scale > 0.f);
+  h->nonlocal = *p;
+  return 0;
+}
+int ehm_gcn_nonlocal_ci(const ehm_gcn* h) { return h->nonlocal.Ci; }
+const ehm_nonlocal_params* ehm_gcn_nonlocal(const ehm_gcn* h) { return &h->nonlocal; }
+
 int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const float** hs, const void** out_dev, hipStream_t st) {
   const int64_t rows = (int64_t)ehm_gcn_virtual_bodies(h, B, passes) * kJ;
   if (rows > h->hs_rows) {

@@ -1,6 +1,7 @@
 // Device-side structures of the Modulated-GCN kernels, shared by gcn.hip (f32 MFMA) and gcn_tile.hip (f16 / split-f16 MFMA).
 #pragma once
 #include "common.h"
+#include "egohmr_hip.h"
 
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -63,6 +64,7 @@ struct ehm_gcn {
   float* hs = nullptr;      // [hs_rows,12] responses of the output conv (gcn_out_dot_kernel -> gcn_out_mix_kernel)
   int64_t hs_rows = 0;
   int64_t reserved_rows = 0;   // rows_pad the sync words / hs scratch were sized for (ehm_gcn_reserve)
+  ehm_nonlocal_params nonlocal{};   // optional non-local block of the one-call loop (ehm_gcn_set_nonlocal); Ci == 0: none
 };
 
 // Split-f16 activation / weight format ("X2<G>"): row-major rows of K values, every group of G consecutive k stored as

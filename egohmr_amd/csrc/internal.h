@@ -23,6 +23,8 @@ struct GcnInputArgs;
 int ehm_gcn_input_args(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x, const float* Wx, const float* tvec,
                        float* out, int B, int passes, GcnInputArgs* a);
 int ehm_gcn_hid(const ehm_gcn* h);
+int ehm_gcn_nonlocal_ci(const ehm_gcn* h);
+const ehm_nonlocal_params* ehm_gcn_nonlocal(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
 int ehm_gcn_virtual_bodies(const ehm_gcn* h, int B, int passes);   // B + second passes after pruning (ehm_gcn_set_pass_map)
 const int32_t* ehm_gcn_mask_slot(const ehm_gcn* h, int passes);

@@ -144,6 +144,8 @@ struct Workspace {
   float* g_gpose;      // [B,144]
   float* g_grad;       // [B,144]
   void* g_scratch;     // bbox / selection / dA / dpose-feature (guidance.hip)
+  float* nl_qkv;       // non-local block: [rows, 3 Ci] theta | phi | g
+  float* nl_y;         //                  [rows, Ci]   attention output
   int64_t rows, rows_pad;
   int64_t total_bytes;
 };
@@ -173,6 +175,10 @@ Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* ba
     w.g_grad = take((int64_t)d->B * kPoseDim);
     w.g_scratch = take(ehm_guidance_scratch_bytes(d->B, d->num_scene_points) / 4 + 64);
   }
+  if (d->nonlocal_ci > 0) {
+    w.nl_qkv = take(w.rows * 3 * d->nonlocal_ci);
+    w.nl_y = take(w.rows * d->nonlocal_ci);
+  }
   w.total_bytes = off;
   return w;
 }
@@ -197,6 +203,9 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   bool any_guided = false;
   for (int k = 0; k < d->num_steps; ++k) any_guided |= steps[k].grad_scale != 0.f;
   EHM_CHECK_ARG(!any_guided || (scene && d->num_scene_points > 0 && !d->ddim));
+  const ehm_nonlocal_params* nlp = ehm_gcn_nonlocal(gcn);
+  EHM_CHECK_ARG(d->nonlocal_ci == nlp->Ci);                                            // the descriptor sized the workspace for the block that is set
+  EHM_CHECK_ARG(nlp->Ci == 0 || (ehm_gcn_get_precision(gcn) != 2 && d->lowprec_steps == 0));   // the block reads float32 features
   Workspace w = carve(d, hid, V, 64 + kJ, (char*)workspace);
   EHM_CHECK_ARG(workspace_bytes >= w.total_bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -246,9 +255,21 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     }
     const float* hs = nullptr;
     const void* out_dev = nullptr;
+    const float* feat = w.X[in];
+    if (rc == 0 && nlp->Ci > 0) {
+      // optional non-local block (modulated_gcn.py:104-110): z = BN(W (softmax(theta phi^T) g)) + x over the 24 joints of a body; float32 features in X[in]
+      // (the last hidden conv writes float32), result into X[1] (free between the chain and the next step's convs)
+      const int ci = nlp->Ci, nrows = (int)w.rows;
+      ehm_conv_desc c1{feat, nlp->Wqkv, nlp->bqkv, nullptr, w.nl_qkv, nrows, 1, 1, hid, 3 * ci, 1, 1, 1, 0, 0, nlp->qkv_scale};
+      rc = ehm_conv_nhwc_split(&c1, st);
+      if (rc == 0) rc = ehm_nonlocal_attention(w.nl_qkv, w.nl_y, w.rows / kJ, ci, st);
+      ehm_conv_desc c2{w.nl_y, nlp->Wo, nlp->bo, feat, w.X[1], nrows, 1, 1, ci, hid, 1, 1, 1, 0, 0, nlp->o_scale};
+      if (rc == 0) rc = ehm_conv_nhwc_split(&c2, st);
+      feat = w.X[1];
+    }
     if (rc == 0) {
       EhmProfScope ps(EHM_PROF_OUT_DOT, st);
-      rc = ehm_gcn_output_dot_impl(gcn, w.X[in], B, d->passes, &hs, &out_dev, st);
+      rc = ehm_gcn_output_dot_impl(gcn, feat, B, d->passes, &hs, &out_dev, st);
     }
     // ---- per body, one launch: output-conv mix + visibility fuse -> x0 (egohmr.py:247-256), x_{t-1} (gaussian_diffusion.py:298-337 /
     //      :511-556), de-normalise + rot6d + kinematic chain (egohmr.py:258-260); then the skinning launch (egohmr.py:276) ----

@@ -274,7 +274,6 @@ class GaussianDiffusion:
 
     def _fused_ok(self, model, skip_timesteps, init_data, dump_steps, progress, eta):
         return (getattr(self, "allow_fused", True) and getattr(model, "fused_sampler", None) is not None
-                and not getattr(getattr(model, "diffusion_model", None), "nonlocal_layer", False)   # optional non-local block: step-wise route
                 and not skip_timesteps and init_data is None
                 and dump_steps is None and not progress and eta == 0.0)
 

@@ -103,6 +103,12 @@ class FusedSampler:
         mode = PRECISIONS[self.model.gcn_precision]
         if _lib.lib().ehm_gcn_get_precision(self._gcn) != mode:
             _lib.check(_lib.lib().ehm_gcn_set_precision(self._gcn, mode), "ehm_gcn_set_precision")
+        if self.model.diffusion_model.nonlocal_layer:       # the one-call loop runs the block natively (ehm_gcn_set_nonlocal)
+            (wq, sq, bq), (wo, so, bo) = self._nonlocal_packed()
+            if getattr(self, "_nl_set", None) != (self._nl_key, self._gcn.value):
+                p = _lib.NonlocalParams(wq.data_ptr(), bq.data_ptr(), sq, wo.data_ptr(), bo.data_ptr(), so, self.model.diffusion_model.non_local.inter_channels)
+                _lib.check(_lib.lib().ehm_gcn_set_nonlocal(self._gcn, C.byref(p)), "ehm_gcn_set_nonlocal")
+                self._nl_set = (self._nl_key, self._gcn.value)
         return self._gcn
 
     def _free(self):
@@ -310,29 +316,10 @@ class FusedSampler:
         """NONLocalBlock2D on the joint axis (modulated_gcn.py:104-110): [theta|phi|g] as ONE 1x1-conv GEMM and W + BatchNorm(eval,
         folded) + residual as another, both on ehm_conv_nhwc_split (rows = N, H = W = 1); the 24 x 24 softmax attention per body
         in ehm_nonlocal_attention."""
-        import math
         m, L = self.model, _lib.lib()
         nl = m.diffusion_model.non_local
         hid, ci = m.diffusion_model.hid_dim, nl.inter_channels
-        key = tuple((p.data_ptr(), p._version) for p in list(nl.parameters()) + list(nl.buffers()))
-        if getattr(self, "_nl_key", None) != key:
-            def pack(w2, bias):                                   # [Co, K] float32 -> X2 split weights for the conv kernel
-                Co, K = w2.shape
-                Co_pad = (Co + 127) // 128 * 128
-                wp = torch.zeros(Co_pad, K, device=m.device)
-                wp[:Co] = w2
-                amax = float(wp.abs().max())
-                scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
-                buf = torch.empty(Co_pad, K, device=m.device)
-                _lib.check(L.ehm_split_pack(wp.data_ptr(), buf.data_ptr(), Co_pad, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
-                return buf, scale, bias.float().contiguous()
-            wqkv = torch.cat([nl.theta.weight, nl.phi.weight, nl.g.weight], 0).flatten(1).float()
-            bqkv = torch.cat([nl.theta.bias, nl.phi.bias, nl.g.bias], 0)
-            bn = nl.W[1]
-            sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
-            ww = (nl.W[0].weight.flatten(1).double() * sc[:, None]).float()
-            bw = ((nl.W[0].bias.double() - bn.running_mean.double()) * sc + bn.bias.double()).float()
-            self._nl_packed, self._nl_key = (pack(wqkv, bqkv), pack(ww, bw)), key
+        self._nonlocal_packed()
         (wq, sq, bq), (wo, so, bo) = self._nl_packed
         s = _lib.stream_ptr()
         qkv = torch.empty(rows, 3 * ci, device=m.device)
@@ -344,6 +331,34 @@ class FusedSampler:
         d = _lib.ConvDesc(y.data_ptr(), wo.data_ptr(), bo.data_ptr(), X.data_ptr(), Z.data_ptr(), rows, 1, 1, ci, hid, 1, 1, 1, 0, 0, so)
         _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
         return Z
+
+    def _nonlocal_packed(self):
+        """The non-local block's two 1x1-conv GEMMs in ehm_conv_nhwc_split's operand format: ([theta | phi | g] weights, scale, bias),
+        (W.0 with BatchNorm(eval) folded, scale, bias); re-packed when a parameter of the block changes."""
+        import math
+        m, L = self.model, _lib.lib()
+        nl = m.diffusion_model.non_local
+        key = tuple((p.data_ptr(), p._version) for p in list(nl.parameters()) + list(nl.buffers()))
+        if getattr(self, "_nl_key", None) != key:
+            def pack(w2, bias):                                   # [Co, K] float32 -> X2 split weights for the conv kernel
+                Co, K = w2.shape
+                Co_pad = (Co + 127) // 128 * 128
+                wp = torch.zeros(Co_pad, K, device=m.device)
+                wp[:Co] = w2
+                amax = float(wp.abs().max())
+                scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
+                buf = torch.empty(Co_pad, K, device=m.device)
+                with torch.cuda.device(m.device):
+                    _lib.check(L.ehm_split_pack(wp.data_ptr(), buf.data_ptr(), Co_pad, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
+                return buf, scale, bias.float().contiguous()
+            wqkv = torch.cat([nl.theta.weight, nl.phi.weight, nl.g.weight], 0).flatten(1).float()
+            bqkv = torch.cat([nl.theta.bias, nl.phi.bias, nl.g.bias], 0)
+            bn = nl.W[1]
+            sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            ww = (nl.W[0].weight.flatten(1).double() * sc[:, None]).float()
+            bw = ((nl.W[0].bias.double() - bn.running_mean.double()) * sc + bn.bias.double()).float()
+            self._nl_packed, self._nl_key = (pack(wqkv.detach(), bqkv.detach()), pack(ww.detach(), bw.detach())), key
+        return self._nl_packed
 
     # ------------------------------------------------------------------ guidance pieces
     @torch.no_grad()
@@ -598,9 +613,9 @@ class FusedSampler:
         """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
         Returns the reference's dict(sample, pred_xstart, other_outputs)."""
         m, L = self.model, _lib.lib()
-        if m.diffusion_model.nonlocal_layer:
-            raise _lib.EgoHMRHipError("the one-call sampling loop does not carry the optional non-local GCN block; "
-                                      "use GaussianDiffusion.p_sample_loop / ddim_sample_loop (they take the step-wise route for such a model)")
+        nonlocal_ci = m.diffusion_model.non_local.inter_channels if m.diffusion_model.nonlocal_layer else 0
+        if nonlocal_ci and m.gcn_precision == "f16":
+            raise _lib.EgoHMRHipError("the optional non-local GCN block runs on float32 features; use gcn_precision 'f16x3' or 'f32' with it")
         ev = getattr(self, "_status_event", None)
         if ev is not None and ev.query():                 # a deferred status word of an earlier call has arrived: look at it now
             self.check_status()
@@ -617,6 +632,8 @@ class FusedSampler:
         passes = 2 if m.diffuse_fuse else 1
         # precision schedule: an explicit `lowprec` (calibration runs), else EgoHMR.f16x3_last_steps; 'auto' = the k calibrated for THESE
         # weights and THIS sampler - measured now, on this batch's first items, when it is not cached yet (auto_calibrate) - or no f16 step
+        if nonlocal_ci:
+            lowprec = 0                                   # the block reads float32 features: no plain-f16 steps
         if lowprec is None:
             skey = None
             if m.f16x3_last_steps == "auto" and m.gcn_precision == "f16x3":
@@ -631,7 +648,7 @@ class FusedSampler:
         desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
                                guide_denom=self.guide_denom(denom_items or B), tau=m.collision_tau, num_masked=num_masked,
-                               guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=int(lowprec))
+                               guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=int(lowprec), nonlocal_ci=int(nonlocal_ci))
         nbytes = L.ehm_sample_workspace_bytes(C.byref(desc), hid, V)
         if nbytes < 0:
             raise _lib.EgoHMRHipError(f"ehm_sample_workspace_bytes rejected the descriptor (rc={nbytes})")
@@ -661,7 +678,7 @@ class FusedSampler:
                 # (every pointer the captured launches bake in that is not inside `bufs`: the two native handles and the mean / std buffers)
                 key = (B, T, int(ddim), desc.passes, desc.lbs_every_step, desc.lowprec_steps, m.gcn_precision, self._gcn_key,
                        bytes(steps), st.scene.shape[1], num_masked, smpl_h.value if hasattr(smpl_h, "value") else int(smpl_h or 0),
-                       mean.data_ptr(), std.data_ptr(), self._folded.Wx.data_ptr())
+                       mean.data_ptr(), std.data_ptr(), self._folded.Wx.data_ptr(), getattr(self, '_nl_set', None))
                 ent = self._graphs.get(key)
                 if ent is None:
                     if len(self._graphs) >= 8:

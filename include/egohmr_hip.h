@@ -137,6 +137,17 @@ int ehm_gcn_set_uncond_mode(ehm_gcn* h, int masks_whole_condition);
  * on, with passes == 2, the activation matrices hold (B + num_masked) * 24 rows: rows [0, B*24) the conditional pass, then the second
  * pass of mask_items[0], mask_items[1], ...  num_masked < 0 clears the map (every item has a second pass: B * 2 * 24 rows). */
 int ehm_gcn_set_pass_map(ehm_gcn* h, const int32_t* mask_items, const int32_t* mask_slot, int num_masked);
+/* The optional non-local block behind the last hidden conv (ModulatedGCN(nonlocal_layer=True), modulated_gcn.py:104-110;
+ * nets/non_local_embedded_gaussian.py:60-85) for the ONE-CALL sampling loop (ehm_sample_loop): two 1x1-conv GEMMs in the operand format
+ * of ehm_conv_nhwc_split - Wqkv = [theta | phi | g] as [3*Ci (padded to 128), hid], Wo = W.0 with BatchNorm(eval) folded as [hid, Ci] -
+ * with their biases and power-of-two scales, and ehm_nonlocal_attention between them.  The arrays must stay alive while set;
+ * NULL removes the block.  ehm_sample_desc.nonlocal_ci must carry Ci (it sizes the workspace). */
+typedef struct {
+  const void* Wqkv; const float* bqkv; float qkv_scale;
+  const void* Wo; const float* bo; float o_scale;
+  int Ci;
+} ehm_nonlocal_params;
+int ehm_gcn_set_nonlocal(ehm_gcn* h, const ehm_nonlocal_params* p);
 int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x,
                         const float* Wx, const float* tvec, float* out, int B, int passes, void* stream);
 
@@ -333,6 +344,8 @@ typedef struct {
   int guide_all_points; /* 1 = VolSMPL-style guidance over ALL scene points (egohmr_volsmpl.py:609-612), 0 = bbox-selected (egohmr.py:550-552) */
   int lowprec_steps;  /* precision schedule: the FIRST lowprec_steps executed steps run the hidden convs on plain f16 operands
                          (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */
+  int nonlocal_ci;    /* inter_channels of the non-local block set with ehm_gcn_set_nonlocal, 0 = none (needs float32 features:
+                         handle mode 0 or 1 and lowprec_steps == 0)                                                              */
 } ehm_sample_desc;
 
 /* GaussianDiffusion.p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508, :618-718)

@@ -319,8 +319,8 @@ def test_hidden_stack_chained_equals_layer_by_layer(B, passes, prec):
 @pytest.mark.gpu
 def test_non_local_gcn_block_vs_oracle():
     """gcn_nonlocal_layer=True (ModulatedGCN + NONLocalBlock2D, modulated_gcn.py:93-110; the oracle's block is pinned by the
-    reference golden G13): EgoHMR.forward and a short DDIM loop against the oracle; the one-call loop refuses such a model and
-    the diffusion API falls back to the step-wise (still all-HIP) route."""
+    reference golden G13): EgoHMR.forward and a short DDIM loop against the oracle - on the step-wise route AND on the one-call loop
+    (ehm_gcn_set_nonlocal: the block runs inside ehm_sample_loop), which agree; plain f16 features are refused."""
     from egohmr_amd import _lib, synthetic as syn
     from egohmr_amd.diffusion import create_gaussian_diffusion
     from egohmr_amd.factory import batch_to_device, build_synthetic_model
@@ -356,17 +356,29 @@ def test_non_local_gcn_block_vs_oracle():
     print(f"non-local forward: max|x0 - fp64| hip {e_hip:.2e}, float32 oracle {e_f32:.2e}")
     assert e_hip <= max(3.0 * e_f32, 5e-5)
     np.testing.assert_allclose(o["pred_vertices"].cpu().numpy(), o64["pred_vertices"].float().numpy(), atol=1e-4)
-    # sampling: API routes step-wise, the fused loop refuses
+    # sampling: the one-call loop (default route of the API) and the step-wise route, both against the oracle
     d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
     noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=9))
     out = d.val_losses(model, batch_to_device(bnp, dev), shape=[B, 144], clip_denoised=False, timestep_respacing="ddim5", compute_loss=False,
                        noise_stack=noise.to(dev))
+    assert model.fused_sampler.last_lowprec == 0                       # float32 features for the block: no plain-f16 step
     tab = osched.make_tables(50, "ddim5")
     tb2 = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in bnp.items()}
     o2 = osampler.val_losses(ref, tb2, tab, noise, "ddim5")
     np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), o2["pred_vertices"].numpy(), atol=1e-4)
+    d.allow_fused = False
+    out_sw = d.val_losses(model, batch_to_device(bnp, dev), shape=[B, 144], clip_denoised=False, timestep_respacing="ddim5", compute_loss=False,
+                          noise_stack=noise.to(dev))
+    np.testing.assert_allclose(out_sw["pred_vertices"].cpu().numpy(), out["pred_vertices"].cpu().numpy(), atol=2e-5)
+    d.allow_fused = True
+    for prec in ("f32",):                                              # the f32-MFMA mode carries the block too
+        model.gcn_precision = prec
+        o3 = model.fused_sampler.run(d, batch_to_device(bnp, dev), noise.to(dev), ddim=True)["other_outputs"]
+        np.testing.assert_allclose(o3["pred_vertices"].cpu().numpy(), o2["pred_vertices"].numpy(), atol=1e-4)
+    model.gcn_precision = "f16"
     with pytest.raises(_lib.EgoHMRHipError):
         model.fused_sampler.run(d, batch_to_device(bnp, dev), noise.to(dev), ddim=True)
+    model.gcn_precision = "f16x3"
 
 
 @pytest.mark.gpu

@@ -21,6 +21,8 @@ h = model.fused_sampler.gcn()
 hid, tile = model.diffusion_model.hid_dim, L.ehm_gcn_row_tile()
 rows_pad = (2 * B * 24 + tile - 1) // tile * tile
 X = torch.randn(rows_pad, hid, device=dev) * float(os.environ.get("EHM_X_SCALE", "1"))   # EHM_X_SCALE=0: zero operands (clock / power probe)
+if os.environ.get("EHM_X_RELU", "1") != "0":    # default: relu-like activations (half zeros), what the sampler feeds the hidden convs; EHM_X_RELU=0: dense random
+    X = torch.relu(X) * 0.5
 X2, Y1, Y2 = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
 if prec != "f32":
     _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), X2.data_ptr(), rows_pad, hid, L.ehm_gcn_activation_group(h), None))

@@ -28,5 +28,5 @@ for prec, tmpl in (("f16", "gcn_hidden_chain_kernel<1, 8>"), ("f16x3", "gcn_hidd
         write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
         out[prec] = {"kernel": tmpl, "kernel_source_sha1": sha, "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write,
                      "bytes_per_launch": fetch + write, "bytes_per_conv": (fetch + write) / 8, "launches_averaged": len(vals["FETCH_SIZE"]),
-                     "workload": "tools/bench_hidden.py (EHM_STACK=1): B=256 x 2 passes, dense random activations"}
+                     "workload": "tools/bench_hidden.py (EHM_STACK=1): B=256 x 2 passes, relu-like activations (half zeros), as in the sampler"}
 print(json.dumps(out, indent=1))

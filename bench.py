@@ -43,6 +43,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (
 
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable on a float4 copy)
+# What the matrix pipe sustains at the 1400 W socket cap on operands that toggle like these convs' when NOTHING else runs (register-only
+# v_mfma_f32_32x32x16_f16 loop, 8 waves per CU; tools/mfma_ceiling.py -> profiles/r03_mfma_ceiling.jsonl) - a measured reference, not re-measured here.
+# Both chained conv kernels run AT that cap (tools/power_probe.py -> profiles/r03_power_probe.jsonl: 1400 / 1390 W).
+POWER_LIMITED_MFMA_TFLOPS = {"f16": 1772.0, "f16x3": 1815.0}
 
 
 def self_launch(argv):
@@ -148,6 +152,9 @@ def main():
     ap.add_argument("--weights", default="sensitive", choices=["sensitive", "insensitive"],
                     help="synthetic denoiser weights: 'sensitive' = trained-like (d x0 / d x_t follows the MMSE gain of a Gaussian prior, ~1 at low noise: "
                          "early rounding errors are CARRIED), 'insensitive' = the plain random network of rounds 1-2 (ignores x_t: errors are contracted)")
+    ap.add_argument("--f16x3-last-steps", type=int, default=None,
+                    help="explicit k instead of the calibration (e.g. the k a previous run printed): no calibration launches, so that under rocprofv3 "
+                         "every launch of a chain kernel is a full-size one and the kernel-stats average equals roofline.avg_launch_ms * 8")
     ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (all-f16x3, f32, f16, other weight set)")
     ap.add_argument("--launch-check", action="store_true", help="only initialise the ranks, report the world size, exit (works without a GPU: gloo)")
     args = ap.parse_args()
@@ -189,6 +196,8 @@ def main():
     model = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=sens)
     model.lbs_every_step = not args.no_lbs_every_step
     model.gcn_precision = args.precision
+    if args.f16x3_last_steps is not None:
+        model.f16x3_last_steps = int(args.f16x3_last_steps)
     diffusion = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
     T = diffusion.num_timesteps
     batch = batch_to_device(syn.make_batch(B, N, seed=100 + rank), dev)            # inputs resident in HBM before timing
@@ -332,6 +341,11 @@ def main():
             per_prod = 3 if prec == "f16x3" else 1
             kernels[prec] = {"bound": "mfma", "kernel": names[prec], "achieved": flops / kd / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / kd / 1e12 / peak,
                              "mfma_flops_per_algorithmic_flop": per_prod, "issued_mfma_frac": flops * per_prod / kd / 1e12 / peak,
+                             "power_limited": None if prec == "f32" else {
+                                 "socket_power_w": {"f16x3": 1400, "f16": 1390}[prec], "socket_cap_w": 1400,
+                                 "mfma_only_ceiling_tflops_at_the_cap": POWER_LIMITED_MFMA_TFLOPS[prec],
+                                 "issued_frac_of_that_ceiling": flops * per_prod / kd / 1e12 / POWER_LIMITED_MFMA_TFLOPS[prec],
+                                 "source": "profiles/r03_power_probe.jsonl, profiles/r03_mfma_ceiling.jsonl (measured references; the guide's tuned-GEMM random-data figure is 1247 TFLOP/s = 0.50)"},
                              "traffic": pmc_traffic(prec) if (B, S) == (256, 1) else None, "avg_launch_ms": kd * 1e3,
                              "avg_launch_ms_is": "per conv = (HIP-event span of the chained launch, on the launch stream, inside a real sampling call) / 8",
                              "launches_per_call": pr["launches_per_call"], "ms_per_call": pr["ms_per_call"], "flops_per_launch": flops,
@@ -375,8 +389,9 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32",
                       "f16x3": "f32 results: denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands (f32 accumulate) on the last "
-                               f"{k_last} of {T} steps, plain f16 operands on the first {lowprec}; k = {k_last} is CALIBRATED on the loaded weights "
-                               f"(final bodies within {model.schedule_tol:g} m of the all-split loop, DESIGN.md 3.6); all-split number in all_steps_f16x3",
+                               f"{k_last} of {T} steps, plain f16 operands on the first {lowprec}; k = {k_last} is " +
+                               ("given on the command line" if args.f16x3_last_steps is not None else "CALIBRATED on the loaded weights") +
+                               f" (final bodies within {model.schedule_tol:g} m of the all-split loop, DESIGN.md 3.6); all-split number in all_steps_f16x3",
                       "f16": "f16 denoiser GEMMs and activations (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "items_per_gpu": B, "samples_per_item": S, "samples_in_one_loop": bool(S > 1), "collision_guided": guided, "denoising_steps": T,
@@ -391,7 +406,8 @@ def main():
                        "smpl": "synthetic SMPL-shaped asset",
                        "parallelism": f"items sharded x{world}, one RCCL all-gather of [B,226] at the end"},
             "schedule": None if args.precision != "f16x3" else {
-                "f16x3_last_steps": k_last, "f16_steps": lowprec, "calibrated": sched is not None,
+                "f16x3_last_steps": k_last, "f16_steps": lowprec, "calibrated": sched is not None and args.f16x3_last_steps is None,
+                "explicit_k_from_command_line": args.f16x3_last_steps,
                 "schedule_calibrated_on": None if sched is None else f"the loaded ({args.weights}) weights, {sched['bodies']} items of this batch, 2 private noise draws, tol {sched['tol_m']:g} m",
                 "calibration_seconds_once_per_checkpoint_and_sampler": t_cal, "calibration_trials": None if sched is None else sched["trials"],
                 "measured_gain_dx0_dxt": fs.measure_gain(batch, timesteps=sorted({diffusion.timestep_map[-1], diffusion.timestep_map[T // 2], diffusion.timestep_map[T // 10], 0}, reverse=True)),

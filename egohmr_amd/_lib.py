@@ -127,7 +127,6 @@ PROTOTYPES = {
     "ehm_gcn_output_layer": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "ehm_linear_split": (_I, [C.POINTER(LinearDesc), _P]),
     "ehm_split_pack": (_I, [_P, _P, _L, _I, _I, _F, _P]),
-    "ehm_bias_act": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "ehm_skinny_gemm_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_resnet_stem_scratch_bytes": (C.c_size_t, [_I, _I, _I]),
     "ehm_resnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

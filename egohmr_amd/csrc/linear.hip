@@ -547,30 +547,6 @@ __global__ __launch_bounds__(256) void nonlocal_attention_kernel(const float* __
   }
 }
 
-// y = act(y + bias[c] (+ residual)), NCHW, in place; float4 when a quad never straddles a channel (HW % 4 == 0).
-template <bool VEC>
-__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res,
-                                                       int64_t n, int C, int HW, int relu) {
-  const int64_t stride = (int64_t)gridDim.x * 256 * (VEC ? 4 : 1);
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1); i < n; i += stride) {
-    if (VEC) {
-      const float b = bias[(i / HW) % C];
-      f32x4 v = *(const f32x4*)(y + i);
-      if (res) v += *(const f32x4*)(res + i);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] += b;
-        if (relu) v[k] = fmaxf(v[k], 0.f);
-      }
-      *(f32x4*)(y + i) = v;
-    } else {
-      float v = y[i] + bias[(i / HW) % C];
-      if (res) v += res[i];
-      y[i] = relu ? fmaxf(v, 0.f) : v;
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int ehm_split_pack(const float* X, void* X2, int64_t rows, int K, int K_padded, float scale, void* stream) {
@@ -630,20 +606,6 @@ extern "C" int ehm_pointnet_lift(const float* pts, const float* Wpos, const floa
   const size_t rows = (size_t)B * N_padded;
   hipLaunchKernelGGL(pointnet_lift_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, pts, Wpos, bpos, (half_t*)R0,
                      (half_t*)P32, N, N_padded, C, rows);
-  EHM_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int ehm_bias_act(float* y, const float* bias, const float* residual, int64_t n, int C, int HW, int relu, void* stream) {
-  if (n == 0) return 0;
-  EHM_CHECK_ARG(y && bias && n > 0 && C > 0 && HW > 0 && n % ((int64_t)C * HW) == 0);
-  const bool vec = HW % 4 == 0 && ((uintptr_t)y % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0);
-  const int64_t work = vec ? n / 4 : n;
-  int64_t blocks = ceil_div(work, 256);
-  const int64_t cap = (int64_t)ehm_num_cus() * 16;       // grid-stride: enough waves to keep HBM busy, not one block per 1 KiB
-  if (blocks > cap) blocks = cap;
-  if (vec) hipLaunchKernelGGL((bias_act_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, n, C, HW, relu);
-  else hipLaunchKernelGGL((bias_act_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, n, C, HW, relu);
   EHM_LAUNCH_CHECK();
   return 0;
 }

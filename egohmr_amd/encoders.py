@@ -57,18 +57,22 @@ class ResNet50Features(nn.Module):
         return x.mean(dim=(2, 3))
 
     # ------------------------------------------------------------------ inference form: BatchNorm folded into the convolutions
-    fold_batchnorm = True
-
     @torch.no_grad()
-    def folded(self, channels_last: bool = True, matrix_core: bool = True, x2_activations: bool = True):
-        """Eval-mode equivalent with every BatchNorm2d folded into its convolution (w' = w * g/sqrt(v+eps),
-        b' = beta - mean * g/sqrt(v+eps); exact up to float re-association) - removes 53 BatchNorm and most ReLU/add passes."""
+    def folded(self, x2_activations: bool = True):
+        """Eval-mode ResNet-50 on the matrix cores with every BatchNorm2d folded into its convolution (w' = w * g/sqrt(v+eps),
+        b' = beta - mean * g/sqrt(v+eps); exact up to float re-association).  x2_activations=True (the product path): the activations
+        stay in the X2 split format from the stem to the average pool (ehm_conv_x2); False: float32 NHWC activations between the
+        convolutions (ehm_conv_nhwc_split - the kernel the non-local GCN block also uses; kept as a second implementation the tests
+        compare).  HIP tensors only: there is no eager / library-convolution route."""
+        import ctypes as C
+        import math
+
+        from . import _lib
+
         def fold(conv, bn):
             scale = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
             w = (conv.weight.double() * scale.view(-1, 1, 1, 1)).float()
             b = (bn.bias.double() - bn.running_mean.double() * scale).float()
-            if channels_last:
-                w = w.contiguous(memory_format=torch.channels_last)
             return w, b, conv.stride, conv.padding
 
         stem = fold(self.conv1, self.bn1)
@@ -77,42 +81,6 @@ class ResNet50Features(nn.Module):
             for blk in layer:
                 blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), fold(blk.conv3, blk.bn3),
                                fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
-
-        def conv(x, p):
-            return F.conv2d(x, p[0], p[1], stride=p[2], padding=p[3])
-
-        def run_eager(x):
-            if channels_last:
-                x = x.contiguous(memory_format=torch.channels_last)
-            x = F.max_pool2d(F.relu_(conv(x, stem)), 3, stride=2, padding=1)
-            for c1, c2, c3, ds in blocks:
-                y = F.relu_(conv(x, c1))
-                y = F.relu_(conv(y, c2))
-                y = conv(y, c3)
-                y += x if ds is None else conv(x, ds)
-                x = F.relu_(y)
-            return x.mean(dim=(2, 3))
-
-        from . import _lib
-
-        def cba(x, p, res=None, relu=True):
-            """library convolution, then bias (+ identity) + ReLU in ONE in-place pass (ehm_bias_act) instead of the eager
-            bias / relu / add / relu passes - a third of the backbone's time at B=256 went into those."""
-            y = F.conv2d(x, p[0], None, stride=p[2], padding=p[3])
-            _lib.check(_lib.lib().ehm_bias_act(y.data_ptr(), p[1].data_ptr(), res.data_ptr() if res is not None else None, y.numel(),
-                                                y.shape[1], y.shape[2] * y.shape[3], 1 if relu else 0, _lib.stream_ptr()), "ehm_bias_act")
-            return y
-
-        def run_hip(x):
-            x = F.max_pool2d(cba(x.contiguous(), stem), 3, stride=2, padding=1)
-            for c1, c2, c3, ds in blocks:
-                y = cba(cba(x, c1), c2)
-                x = cba(y, c3, res=x if ds is None else cba(x, ds, relu=False))
-            return x.mean(dim=(2, 3))
-
-        # ---- matrix-core path: everything behind the stem as NHWC implicit GEMMs with fused bias / identity / ReLU (csrc/conv.hip)
-        import ctypes as C
-        import math
         packed = {}
 
         def pack(p):
@@ -180,8 +148,8 @@ class ResNet50Features(nn.Module):
         def run_x2(x):
             """the whole trunk with the activations in the X2 split format between the layers (taps gathered by the LDS DMA)"""
             N = x.shape[0]
+            shp = (N, x.shape[2] // 4, x.shape[3] // 4)
             x = stem_mc(x, x2=True)
-            shp = (N, x_shape_hw[0], x_shape_hw[1])
             for c1, c2, c3, ds in blocks:
                 y, s1 = conv_x2(x, shp, c1)
                 y, s2 = conv_x2(y, s1, c2)
@@ -191,26 +159,19 @@ class ResNet50Features(nn.Module):
             _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], _lib.stream_ptr()), "ehm_x2_group_mean")
             return out
 
-        x_shape_hw = [0, 0]
-
-        def run_mc(x):
+        def run(x):
+            if not x.is_cuda:
+                raise _lib.EgoHMRHipError("the ResNet-50 backbone needs its input on a HIP device; egohmr_amd has no CPU path")
             x = _lib.f32(x)
-            if x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:               # (the reference always feeds 224 x 224 crops)
-                x = F.max_pool2d(cba(x.contiguous(), stem), 3, stride=2, padding=1).permute(0, 2, 3, 1).contiguous()
-            elif x2_activations:
-                x_shape_hw[0], x_shape_hw[1] = x.shape[2] // 4, x.shape[3] // 4
+            if x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+                raise _lib.EgoHMRHipError(f"the fused stem needs [N,3,H,W] images with H, W multiples of 32 (the reference feeds 224 x 224 crops); got {tuple(x.shape)}")
+            if x2_activations:
                 return run_x2(x)
-            else:
-                x = stem_mc(x)                                                      # NHWC from here on
+            x = stem_mc(x)                                                          # NHWC float32 from here on
             for c1, c2, c3, ds in blocks:
                 y = conv_mc(conv_mc(x, c1), c2)
                 x = conv_mc(y, c3, res=x if ds is None else conv_mc(x, ds, relu=False))
             return x.mean(dim=(1, 2))
-
-        def run(x):
-            if not x.is_cuda or channels_last:
-                return run_eager(x)
-            return run_mc(x) if matrix_core else run_hip(x)
 
         return run
 

@@ -129,7 +129,7 @@ class FusedSampler:
             self._bbk = _lib.TensorKey(bb)
         key = self._bbk()
         if getattr(self, "_bb_key", None) != key:
-            self._bb_fn, self._bb_key = bb.folded(channels_last=False, matrix_core=self.model.backbone_matrix_core), key
+            self._bb_fn, self._bb_key = bb.folded(), key
         return self._bb_fn
 
     # ------------------------------------------------------------------ step-invariant conditioning

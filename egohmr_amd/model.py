@@ -211,7 +211,6 @@ class EgoHMR(nn.Module):
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)
         self.overlap_encoders = True       # ResNet-50 and the scene PointNet on two HIP streams (FusedSampler.prepare)
-        self.backbone_matrix_core = True   # ResNet-50 blocks as split-f16 implicit GEMMs (csrc/conv.hip); False = library convs + ehm_bias_act
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
         # precision schedule: only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'), the

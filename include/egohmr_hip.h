@@ -218,11 +218,6 @@ int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, vo
  * X 16-byte aligned; bias may be NULL; relu != 0 applies max(., 0).  Deterministic (no atomics). */
 int ehm_skinny_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int K, int N, int relu, void* stream);
 
-/* In place y = act(y + bias[c] (+ residual)) over an NCHW float tensor (c = (i / HW) % C): the BatchNorm-folded bias,
- * the bottleneck's identity add and the ReLU of torchvision's ResNet-50 (`out = self.bn3(out); out += identity;
- * out = self.relu(out)`, used as EgoHMR's backbone at models/egohmr/egohmr.py:183) in ONE pass over the activation instead
- * of the three or four eager passes.  residual may be NULL; relu != 0 applies max(., 0). */
-int ehm_bias_act(float* y, const float* bias, const float* residual, int64_t n, int C, int HW, int relu, void* stream);
 
 /* ResNet-50 stem in one pass (torchvision ResNet.forward conv1 / bn1 / relu / maxpool, models/resnet.py:139-150 as used at
  * models/egohmr/egohmr.py:183): conv 7x7 stride 2 pad 3 (3 -> 64) + bias + ReLU + max-pool 3x3 stride 2 pad 1.

@@ -625,9 +625,9 @@ def test_resnet_stem_vs_torch_fp64(dev, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["x2", "f32act", "library"])
+@pytest.mark.parametrize("mode", ["x2", "f32act"])
 def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, mode):
-    """The BatchNorm-folded backbone (split-f16 implicit-GEMM convs of csrc/conv.hip, or library convs + ehm_bias_act) against the
+    """The BatchNorm-folded backbone (split-f16 implicit-GEMM convs of csrc/conv.hip) against the
     reference's own ResNet-50 output (G6, generated by oracle/make_golden.py from models/egohmr/egohmr.py's backbone)."""
     from egohmr_amd import synthetic as syn
     from egohmr_amd.encoders import ResNet50Features
@@ -637,16 +637,21 @@ def test_resnet50_backbone_vs_reference_golden(dev, golden_dir, mode):
     net.load_state_dict({k[len("backbone."):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if k.startswith("backbone.")})
     net = net.to(dev).eval()
     # x2: activations in the split format between the layers (conv_x2_tile_kernel); f32act: float32 activations (conv_nhwc_split_kernel)
-    kw = {"x2": dict(matrix_core=True, x2_activations=True), "f32act": dict(matrix_core=True, x2_activations=False), "library": dict(matrix_core=False)}[mode]
+    kw = {"x2": dict(x2_activations=True), "f32act": dict(x2_activations=False)}[mode]
     rng = np.random.Generator(np.random.PCG64(int(g["img_seed"])))
     rng.uniform(-1, 1, size=(2, 257, 3))          # same stream position as the generator script
     img = torch.from_numpy(rng.normal(size=(2, 3, 224, 224)).astype(np.float32)).to(dev)
     with torch.no_grad():
-        out = net.folded(channels_last=False, **kw)(img)
+        out = net.folded(**kw)(img)
     np.testing.assert_allclose(out.cpu().numpy(), g["feat"], atol=3e-5)
     # ragged row count (M = 3*56*56 ... 3*7*7 is not a multiple of the 128-row tile) and batch consistency
     img3 = torch.cat([img, img[:1]], 0)
     with torch.no_grad():
-        out3 = net.folded(channels_last=False, **kw)(img3)
-    np.testing.assert_allclose(out3[:2].cpu().numpy(), out.cpu().numpy(), atol=5e-6)   # the library convs pick batch-dependent algorithms
+        out3 = net.folded(**kw)(img3)
+    np.testing.assert_allclose(out3[:2].cpu().numpy(), out.cpu().numpy(), atol=5e-6)
     np.testing.assert_allclose(out3[2].cpu().numpy(), out[0].cpu().numpy(), atol=5e-6)
+    from egohmr_amd import _lib
+    with pytest.raises(_lib.EgoHMRHipError):                     # no eager / CPU route, no library-conv route for odd sizes
+        net.folded(**kw)(img.cpu())
+    with pytest.raises(_lib.EgoHMRHipError):
+        net.folded(**kw)(img[:, :, :200, :200].contiguous())

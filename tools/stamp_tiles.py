@@ -62,6 +62,10 @@ seg = {"head wait (prev stores + DMA landing)": t[:, 5] - t[:, 0], "consts + fir
 for k, v in seg.items():
     print(f"  {k:40s} mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.median(v):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles")
 if mode == "chain":
+    # K loop / tile total by the block's tile number (16 tiles per block at B = 256: layer = i // 2, i % 2 = first / second tile of the layer)
+    kl, tt = d[:, :, 2] - d[:, :, 1], d[:, :, 4] - d[:, :, 0]
+    n_i = int(ok.sum(1).max())
+    print("  per tile number of the block:  " + "  ".join(f"{i}:{np.median(kl[:, i][ok[:, i]]) / 1e3:.0f}k/{np.median(tt[:, i][ok[:, i]]) / 1e3:.0f}k" for i in range(n_i) if ok[:, i].any()))
     # gap between a tile's end and the next tile's head on the same block
     gaps = []
     for b in range(nblk):

@@ -166,10 +166,18 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + A_T + (wave + NW * i) * 256), 16, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
+#if defined(EHM_ABL_NO_DMA)          // timing-only ablation (results are garbage): the K loop without its operand stream
+    (void)buf; (void)kt;
+#else
+#if !defined(EHM_ABL_NO_DMA_A)
 #pragma unroll
     for (int i = 0; i < NDA; ++i) dma_a(buf, kt, i);
+#endif
+#if !defined(EHM_ABL_NO_DMA_B)
 #pragma unroll
     for (int i = 0; i < NDB; ++i) dma_b(buf, kt, i);
+#endif
+#endif
   };
   // The first two K tiles of a tile are fetched around the previous tile's epilogue: both weight stages and activation stage 0 before it,
   // activation stage 1 (whose pieces are the epilogue's scratch) after it = "late" = what a wave issues last = what the head of the K
@@ -879,6 +887,9 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   a.sticky = h->chain_sticky;
   const int total = nl * m_tiles * n_tiles;
   int blocks = (wide ? 1 : 2) * ehm_num_cus();         // what is co-resident (80 KiB LDS per 4-wave block, 112 KiB per 8-wave block)
+#ifdef EHM_STAMPS
+  if (const char* e = getenv("EHM_CHAIN_BLOCKS")) blocks = atoi(e);   // stamp builds only: e.g. one block per CU to time a tile without a co-resident partner
+#endif
   if (blocks > total) blocks = total;
   a.nq = ehm_num_cus() / 32;
   if (a.nq < 1) a.nq = 1;

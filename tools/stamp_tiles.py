@@ -43,7 +43,7 @@ def run():
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-nblk = 512 if mode == "chain" else rows_pad // 192 * 16
+nblk = int(os.environ.get("EHM_CHAIN_BLOCKS", "512")) if mode == "chain" else rows_pad // 192 * 16
 dbg = torch.zeros(nblk * 64 * 8, dtype=torch.int64, device=dev)
 fn = L.ehm_dbg_set
 fn.argtypes = [ctypes.c_void_p]

@@ -1,0 +1,66 @@
+"""GPU (MI355X): edge cases of the sampling path - a single item with the reference's real scene size (N = 20000,
+preprocess_scene_s2_for_test.py:24), and collision guidance with nothing to collide with (the reference's zero-loss short-circuit,
+egohmr.py:561,569-570: gradient = zeros, so the guided loop must reproduce the unguided one)."""
+import numpy as np
+import pytest
+import torch
+
+from egohmr_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev, synth_weights, smpl_asset):
+    from egohmr_amd.factory import build_synthetic_model
+    return build_synthetic_model(dev, 0, diffuse_fuse=True, state_dict=synth_weights, smpl_asset=smpl_asset)
+
+
+def test_single_item_with_20000_scene_points_vs_oracle(dev, model, synth_weights, smpl_asset):
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device
+    from oracle import model as om, sampler as osamp, schedule as osched
+    B, N, n, rs = 1, 20000, 50, "ddim5"
+    bnp = syn.make_batch(B, N, seed=81)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+    noise = syn.make_noise_stack(d.num_timesteps, B, seed=81)
+    out = d.val_losses(model, batch_to_device(bnp, dev), shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False,
+                       noise_stack=torch.from_numpy(noise).to(dev))
+    mean, std = syn.make_body_rep_stats(0)
+    ref = om.EgoHMROracle(synth_weights, smpl_asset, mean, std, faithful=False)
+    tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in bnp.items()}
+    ro = osamp.val_losses(ref, tb, osched.make_tables(n, rs), torch.from_numpy(noise), rs)
+    assert out["pred_vertices"].shape == (1, 6890, 3) and out["pred_keypoints_3d"].shape == (1, 45, 3)
+    np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), ro["pred_vertices"].numpy(), atol=1e-4)
+    np.testing.assert_allclose(out["pred_keypoints_3d"].cpu().numpy(), ro["pred_keypoints_3d"].numpy(), atol=1e-4)
+    np.testing.assert_allclose(out["pred_smpl_params"]["betas"].cpu().numpy(), ro["pred_smpl_params"]["betas"].numpy(), atol=5e-5)
+
+
+@pytest.mark.parametrize("volsmpl", [False, True])
+def test_guidance_with_nothing_to_collide_with_equals_the_unguided_loop(dev, synth_weights, smpl_asset, volsmpl):
+    """Scene 50 m away: no scene point inside any body's bounding box / within tau of it -> every item's loss is 0 -> the reference returns a
+    zero gradient (egohmr.py:561,569-570; egohmr_volsmpl.py:617-629) and the mean shift of p_sample_with_grad vanishes: bit-equal bodies."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, state_dict=synth_weights, smpl_asset=smpl_asset, volsmpl=volsmpl)
+    m.f16x3_last_steps = None                        # same arithmetic on every step in both loops (a guided loop calibrates its own schedule)
+    B, N = 5, 2048
+    bnp = syn.make_batch(B, N, seed=82)
+    bnp["scene_pcd_verts_full"] = bnp["scene_pcd_verts_full"] + np.float32(50.0)
+    b = batch_to_device(bnp, dev)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="")
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=82)).to(dev)
+    w = 30.0 if volsmpl else 2.0
+    guided = d.p_sample_loop(m, dict(b), [B, 144], cond_fn_with_grad=True, cond_grad_weight=w, noise_stack=noise)
+    plain = d.p_sample_loop(m, dict(b), [B, 144], cond_fn_with_grad=False, noise_stack=noise)
+    assert torch.equal(guided["sample"], plain["sample"])
+    assert torch.equal(guided["other_outputs"]["pred_vertices"], plain["other_outputs"]["pred_vertices"])
+    assert m.eval_coll(guided["other_outputs"]) == [0.0] * B
+    g = m.guide_coll(b | {"x_t": noise[0]}, guided["other_outputs"], torch.zeros(B, dtype=torch.long, device=dev))
+    assert g.shape == (B, 144) and float(g.abs().max()) == 0.0

@@ -654,12 +654,17 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
         for (int i = 0; i < GR; ++i) {
           const int j = j0 + i;
           float s0 = dp[j][0], s1 = dp[j][1];
+#if !defined(EHM_ABL_NO_MIX)      // timing-only ablation (stamp builds): the epilogue without its 1152 adjacency-mix FMAs per lane
 #pragma unroll
           for (int jp = 0; jp < kJ; ++jp) {
             const float c = Ag[i * kJ + jp];
             s0 = fmaf(c, gp[jp][0], s0);
             s1 = fmaf(c, gp[jp][1], s1);
           }
+#else
+          s0 += gp[j][0] * Ag[i * kJ];
+          s1 += gp[j][1] * Ag[i * kJ];
+#endif
           asm volatile("" : "+v"(s0), "+v"(s1));                // pins both bodies' chains here (hipcc sank body b's to its use in pass 1 and
           V[0][j] = fmaxf(s0, floor_v);                         // parked 500+ coefficients in VGPR lanes for it)
           V[1][j] = fmaxf(s1, floor_v);

@@ -263,10 +263,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if constexpr (P == 3) {                           // small cross terms first, leading term last
+#if !defined(EHM_ABL_DROP_XLO)   // measurement builds only ("two-MFMA split"): drop lo(x)*hi(w) / hi(x)*lo(w)
         acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[0], acc0[t], 0, 0, 0);
         acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[1], acc1[t], 0, 0, 0);
+#endif
+#if !defined(EHM_ABL_DROP_WLO)
         acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[0], acc0[t], 0, 0, 0);
         acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[1], acc1[t], 0, 0, 0);
+#endif
       }
       acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[0], acc0[t], 0, 0, 0);
       acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[1], acc1[t], 0, 0, 0);

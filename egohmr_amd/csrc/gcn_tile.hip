@@ -166,18 +166,10 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + A_T + (wave + NW * i) * 256), 16, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
-#if defined(EHM_ABL_NO_DMA)          // timing-only ablation (results are garbage): the K loop without its operand stream
-    (void)buf; (void)kt;
-#else
-#if !defined(EHM_ABL_NO_DMA_A)
 #pragma unroll
     for (int i = 0; i < NDA; ++i) dma_a(buf, kt, i);
-#endif
-#if !defined(EHM_ABL_NO_DMA_B)
 #pragma unroll
     for (int i = 0; i < NDB; ++i) dma_b(buf, kt, i);
-#endif
-#endif
   };
   // The first two K tiles of a tile are fetched around the previous tile's epilogue: both weight stages and activation stage 0 before it,
   // activation stage 1 (whose pieces are the epilogue's scratch) after it = "late" = what a wave issues last = what the head of the K
@@ -263,14 +255,10 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if constexpr (P == 3) {                           // small cross terms first, leading term last
-#if !defined(EHM_ABL_DROP_XLO)   // measurement builds only ("two-MFMA split"): drop lo(x)*hi(w) / hi(x)*lo(w)
         acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[0], acc0[t], 0, 0, 0);
         acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[1], acc1[t], 0, 0, 0);
-#endif
-#if !defined(EHM_ABL_DROP_WLO)
         acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[0], acc0[t], 0, 0, 0);
         acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[1], acc1[t], 0, 0, 0);
-#endif
       }
       acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[0], acc0[t], 0, 0, 0);
       acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[1], acc1[t], 0, 0, 0);
@@ -658,17 +646,12 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
         for (int i = 0; i < GR; ++i) {
           const int j = j0 + i;
           float s0 = dp[j][0], s1 = dp[j][1];
-#if !defined(EHM_ABL_NO_MIX)      // timing-only ablation (stamp builds): the epilogue without its 1152 adjacency-mix FMAs per lane
 #pragma unroll
           for (int jp = 0; jp < kJ; ++jp) {
             const float c = Ag[i * kJ + jp];
             s0 = fmaf(c, gp[jp][0], s0);
             s1 = fmaf(c, gp[jp][1], s1);
           }
-#else
-          s0 += gp[j][0] * Ag[i * kJ];
-          s1 += gp[j][1] * Ag[i * kJ];
-#endif
           asm volatile("" : "+v"(s0), "+v"(s1));                // pins both bodies' chains here (hipcc sank body b's to its use in pass 1 and
           V[0][j] = fmaxf(s0, floor_v);                         // parked 500+ coefficients in VGPR lanes for it)
           V[1][j] = fmaxf(s1, floor_v);

@@ -437,6 +437,23 @@ class FusedSampler:
             x *= 4.0 / 3.0
         return [k for k in ks if k < T] + [T]
 
+    @staticmethod
+    def pick_k(ladder, err_a, err_b, bar):
+        """Index into `ladder` (ascending k, last entry = T = every step f32-grade, error 0 by definition) of the smallest k whose error
+        on draw A is <= bar AND, from there upwards, the first k that also passes on draw B.  Bisection on draw A (the error falls with
+        k up to noise; a non-monotone blip can only make the answer more conservative because draw B re-checks it), then a linear climb."""
+        lo, hi = 0, len(ladder) - 1
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if err_a(ladder[mid]) <= bar:
+                hi = mid
+            else:
+                lo = mid + 1
+        idx = lo
+        while idx < len(ladder) - 1 and err_b(ladder[idx]) > bar:
+            idx += 1
+        return idx
+
     def _subset(self, st, sel):
         """Some items of a prepared batch as a prepared batch of their own (pass map recomputed): sel = n (the first n) or an index tensor."""
         if isinstance(sel, int):
@@ -511,18 +528,12 @@ class FusedSampler:
                 tried[(k, d)] = 0.0 if k >= T else dist(loop(draws[d], T - k), refs[d])
             return tried[(k, d)]
 
-        lo, hi = 0, len(ladder) - 1                      # ladder[hi] = T passes by construction
-        while lo < hi:
-            mid = (lo + hi) // 2
-            if err(ladder[mid], 0) <= 0.5 * tol:
-                hi = mid
-            else:
-                lo = mid + 1
-        idx = lo
-        if ladder[idx] < T:
-            refs.append(loop(draws[1], 0))
-            while ladder[idx] < T and err(ladder[idx], 1) > 0.5 * tol:
-                idx += 1
+        def err1(k):
+            if ladder[-1] > k and len(refs) < 2:          # draw B's reference loop only when a candidate below T reaches the second check
+                refs.append(loop(draws[1], 0))
+            return err(k, 1)
+
+        idx = self.pick_k(ladder, lambda k: err(k, 0), err1, 0.5 * tol)
         k = ladder[idx]
         info = {"k": int(k), "T": int(T), "f16_steps": int(T - k), "tol_m": tol, "criterion": "max vertex/joint distance to the all-f16x3 loop <= tol/2 on two noise draws",
                 "bodies": int(nb), "ddim": bool(ddim), "guided_steps": int(n_guided),

@@ -59,3 +59,40 @@ def test_two_rank_gather_gloo(tmp_path, n_items):
                        for i in range(n_items)])
     for r in range(2):
         np.testing.assert_allclose(np.load(tmp_path / f"r{r}.npy"), expect, rtol=0, atol=1e-6)
+
+
+class _FakeSampler:
+    """Stands in for FusedSampler: rank r would calibrate k = 10 + 7 r on its own shard."""
+
+    def __init__(self, rank):
+        self.rank, self.installed, self.calibrated = rank, None, 0
+
+    def calibrate_schedule(self, diffusion, batch, **kw):
+        self.calibrated += 1
+        return {"k": 10 + 7 * self.rank, "T": 50, "tol_m": 1e-5, "trials": [], "denom": kw.get("denom_items")}
+
+    def install_schedule(self, diffusion, info, **kw):
+        self.installed = dict(info)
+
+
+def _agree_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    edist.init_from_env("gloo")
+    fs = _FakeSampler(rank)
+    info = edist.agree_schedule(fs, None, {"img": torch.zeros(6 + rank, 3)}, ddim=True)
+    np.save(os.path.join(out_dir, f"k{rank}.npy"), np.array([info["k"], fs.calibrated, -1 if fs.installed is None else fs.installed["k"], info["denom"]]))
+    dist.destroy_process_group()
+
+
+def test_agree_schedule_every_rank_adopts_rank0_calibration(tmp_path):
+    """dist.agree_schedule: ONE calibration per job - rank 0 measures on its batch (the first items of the data set under contiguous
+    sharding), every rank installs that k; nobody else runs a calibration.  Single-process: it simply calibrates."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "k0.npy"), np.load(tmp_path / "k1.npy")
+    assert list(r0) == [10, 1, 10, 6] and list(r1) == [10, 0, 10, 6]          # k, calibrations run here, installed k, rank 0's batch size
+    fs = _FakeSampler(3)
+    assert edist.agree_schedule(fs, None, {"img": torch.zeros(4, 3)})["k"] == 31 and fs.calibrated == 1 and fs.installed is None

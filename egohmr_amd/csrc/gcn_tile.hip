@@ -132,8 +132,12 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   // ---- DMA: one wave instruction = 8 rows x 128 B; physical 16-byte chunk c of row r holds logical chunk c ^ ((r>>1)&7)
   int r0, swz;                                               // r0 = 8 wave + lane / 8; swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2; r0 + 32 i keeps the key
   const size_t row32 = (size_t)(8 * NW) * rowf;              // a wave's consecutive DMA instructions are 32 (64) rows apart
-  const float* pA;
-  const float* pB;
+  // operand stream addressing: buffer form - a tile's base in an SGPR descriptor, the lane's row / chunk in ONE 32-bit VGPR offset that is
+  // the same for every piece of the tile, the piece (rows + K tile) in the scalar offset: no vector-ALU address arithmetic in the K loop
+  // (with 64-bit global pointers every piece cost two v_add: 20 VALU per K tile and wave, and VALU issue is time the matrix pipe of the
+  // SIMD does not get)
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  int voAB;
   auto io_of = [&](const Tile& t) -> TileIO {
     TileIO o;
     if constexpr (CHAIN) {
@@ -156,14 +160,15 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   };
   auto set_tile_ptrs = [&](const Tile& t) {
     const TileIO o = io_of(t);
-    pA = o.X + ((size_t)t.m_tile * 192 + r0) * rowf + swz;
-    pB = o.W + ((size_t)t.n_tile * BROWS + r0) * rowf + swz;
+    rsA = ehm_buffer_rsrc(o.X + (size_t)t.m_tile * 192 * rowf);
+    rsB = ehm_buffer_rsrc(o.W + (size_t)t.n_tile * BROWS * rowf);
+    voAB = (r0 * rowf + swz) * 4;
   };
   auto dma_a = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pA + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + (wave + NW * i) * 256), 16, 0, kLoadAux);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (AS3 void*)(lds + buf * STG + (wave + NW * i) * 256), 16, voAB, (i * (int)row32 + kt * RK) * 4, 0, kLoadAux);
   };
   auto dma_b = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * row32 + kt * RK), (AS3 void*)(lds + buf * STG + A_T + (wave + NW * i) * 256), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (AS3 void*)(lds + buf * STG + A_T + (wave + NW * i) * 256), 16, voAB, (i * (int)row32 + kt * RK) * 4, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
 #pragma unroll

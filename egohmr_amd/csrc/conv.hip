@@ -301,38 +301,42 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 
   // my six activation rows of the tile: float offset of the (kh = 0, kw = 0) tap pixel's channel 0 (+ my swizzled chunk) and the taps
   // that lie inside the image
-  int pbase[6];
+  // operand pieces in buffer form (as in gcn_tile.hip): the activation tensor / the tile's weight rows behind SGPR descriptors, one 32-bit BYTE
+  // offset per lane and piece (the gathered pixel, or the zero row), the weights' piece in the scalar offset
+  unsigned int pbase[6];        // byte offset (mod 2^32: border pixels start below zero) of the (kh = 0, kw = 0) tap pixel's channel 0 + my swizzled chunk
   unsigned int pmask[6];
-  const float* pB;
-  const size_t brow32 = (size_t)32 * K;
+  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc(p.x);
+  __amdgpu_buffer_rsrc_t rsB;
+  int voB;
+  const int brow32 = 32 * K;
   auto set_tile = [&](int m, int n) {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const long long gm = (long long)m * XBM + r0 + 32 * i;
       pmask[i] = 0u;
-      pbase[i] = 0;
+      pbase[i] = 0u;
       if (gm < p.M) {
         const int nimg = (int)(gm / hw), rem = (int)(gm % hw);
         const int hi0 = (rem / p.Wo) * p.stride - p.pad, wi0 = (rem % p.Wo) * p.stride - p.pad;
-        pbase[i] = ((nimg * p.H + hi0) * p.Wd + wi0) * p.Ci + swz;
+        pbase[i] = (unsigned int)(((nimg * p.H + hi0) * p.Wd + wi0) * p.Ci + swz) * 4u;
         for (int kh = 0; kh < p.KH; ++kh)
           for (int kw = 0; kw < p.KW; ++kw)
             if (hi0 + kh >= 0 && hi0 + kh < p.H && wi0 + kw >= 0 && wi0 + kw < p.Wd) pmask[i] |= 1u << (kh * p.KW + kw);
       }
     }
-    pB = p.W + ((size_t)n * XBN + r0) * K + swz;
+    rsB = ehm_buffer_rsrc(p.W + (size_t)n * XBN * K);
+    voB = (r0 * K + swz) * 4;
   };
   auto dma_a = [&](int buf, int kt, int i) {
     const int tap = kt / cpt, cg = kt - tap * cpt;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int toff = (kh * p.Wd + kw) * p.Ci + cg * XRK;                       // (wave-uniform)
-    const unsigned int off = ((pmask[i] >> tap) & 1u) ? (unsigned int)(pbase[i] + toff) : p.zero_off + (unsigned int)swz;
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(p.x + off), (AS3 void*)(lds + buf * XSTG + (wave + 4 * i) * 256), 16, 0, 0);
+    const unsigned int toff = (unsigned int)((kh * p.Wd + kw) * p.Ci + cg * XRK) * 4u;   // (wave-uniform, bytes)
+    const unsigned int off = ((pmask[i] >> tap) & 1u) ? pbase[i] + toff : (p.zero_off + (unsigned int)swz) * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (AS3 void*)(lds + buf * XSTG + (wave + 4 * i) * 256), 16, (int)off, 0, 0, 0);
   };
   auto dma_b = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * brow32 + (size_t)kt * XRK), (AS3 void*)(lds + buf * XSTG + XA_T + (wave + 4 * i) * 256), 16,
-                                     0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (AS3 void*)(lds + buf * XSTG + XA_T + (wave + 4 * i) * 256), 16, voB, (i * brow32 + kt * XRK) * 4, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
 #pragma unroll
@@ -597,9 +601,9 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Wd + 2 * d->pad - d->KW) / d->stride + 1;
   EHM_CHECK_ARG(Ho > 0 && Wo > 0 && d->KH * d->KW * (d->Ci / XRK) >= 2);
   const int64_t in_rows = (int64_t)d->N * d->H * d->Wd;
-  if (d->x_rows < ehm_conv_x2_rows(in_rows) || (ehm_conv_x2_rows(in_rows) * d->Ci) >= ((int64_t)1 << 31) ||
+  if (d->x_rows < ehm_conv_x2_rows(in_rows) || (d->x_rows * d->Ci) >= ((int64_t)1 << 30) ||       // (32-bit BYTE offsets into x: the operand pieces use buffer addressing)
       ehm_conv_x2_rows((int64_t)d->N * Ho * Wo) * d->Co >= ((int64_t)1 << 31)) {
-    ehm_set_error("ehm_conv_x2: x_rows = %lld, need ehm_conv_x2_rows(N*H*W) = %lld rows (tile padding + the zero row), and tensors below 2^31 elements",
+    ehm_set_error("ehm_conv_x2: x_rows = %lld, need ehm_conv_x2_rows(N*H*W) = %lld rows (tile padding + the zero row), x below 2^30 and y below 2^31 elements",
                   (long long)d->x_rows, (long long)ehm_conv_x2_rows(in_rows));
     return EHM_EINVAL;
   }

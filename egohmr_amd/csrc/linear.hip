@@ -129,20 +129,26 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     return m < m_tiles;
   };
 
-  const float *pA0, *pA1, *pB;
-  const size_t a0row32 = (size_t)32 * p.K0, a1row32 = (size_t)32 * p.K1, brow32 = (size_t)32 * K;
+  // operand pieces in buffer form (as in gcn_tile.hip): the tile's base in an SGPR descriptor, the lane's row / swizzled chunk in one 32-bit
+  // offset per operand, the piece in the scalar offset - no vector-ALU address arithmetic per piece
+  __amdgpu_buffer_rsrc_t rsA0, rsA1, rsB;
+  int voA0, voA1, voB;
+  const int a0row32 = 32 * p.K0, a1row32 = 32 * p.K1, brow32 = 32 * K;
   auto set_tile_ptrs = [&](int m, int n) {
-    pA0 = p.A0 + ((size_t)m * LBM + r0) * p.K0 + swz;
-    pA1 = p.K1 ? p.A1 + ((size_t)m * LBM + r0) * p.K1 + swz : nullptr;
-    pB = p.W + ((size_t)n * LBN + r0) * K + swz;
+    rsA0 = ehm_buffer_rsrc(p.A0 + (size_t)m * LBM * p.K0);
+    rsA1 = ehm_buffer_rsrc(p.K1 ? p.A1 + (size_t)m * LBM * p.K1 : p.A0);
+    rsB = ehm_buffer_rsrc(p.W + (size_t)n * LBN * K);
+    voA0 = (r0 * p.K0 + swz) * 4;
+    voA1 = (r0 * p.K1 + swz) * 4;
+    voB = (r0 * K + swz) * 4;
   };
   auto dma_a = [&](int buf, int kt, int i) {
-    const float* src = kt < KT0 ? pA0 + i * a0row32 + (size_t)kt * RK : pA1 + i * a1row32 + (size_t)(kt - KT0) * RK;
-    __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + buf * LSTG + (wave + 4 * i) * 256), 16, 0, 0);
+    AS3 void* dst = (AS3 void*)(lds + buf * LSTG + (wave + 4 * i) * 256);
+    if (kt < KT0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, dst, 16, voA0, (i * a0row32 + kt * RK) * 4, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, dst, 16, voA1, (i * a1row32 + (kt - KT0) * RK) * 4, 0, 0);
   };
   auto dma_b = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_global_load_lds((const AS1 void*)(pB + i * brow32 + (size_t)kt * RK), (AS3 void*)(lds + buf * LSTG + LA_T + (wave + 4 * i) * 256), 16,
-                                     0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (AS3 void*)(lds + buf * LSTG + LA_T + (wave + 4 * i) * 256), 16, voB, (i * brow32 + kt * RK) * 4, 0, 0);
   };
   float px[3], py[3], pz[3];                                    // LIFT: the points of rows lane + 64 j of the current tile
   auto load_points = [&](int m) {

@@ -448,6 +448,17 @@ def g16_sensitive_denoiser(asset, mean, std):
                              timestep_respacing=rs, cond_fn_with_grad=guided, cond_grad_weight=w, compute_loss=False)
         save(name, batch_seed=62, noise_seed=62, B=Bc, N=N, n=n, respacing=rs, guided=guided, cond_grad_weight=w,
              x_t_trace=np.stack(xs), **_pack_out(o))
+    # BASELINE config 5's schedule length on a trained-like denoiser: a thousand steps over which rounding errors are carried, not contracted
+    n = 1000
+    m = build_reference_model(syn.make_sensitive_state_dict(0, n), asset, mean, std, diffuse_fuse=True)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing="")
+    Bc, N = 2, 512
+    bb = to_torch_batch(syn.make_batch(Bc, num_scene_points=N, seed=63))
+    noise = torch.from_numpy(syn.make_noise_stack(n, Bc, seed=63))
+    with explicit_noise(noise), torch.no_grad():
+        o = d.val_losses(model=m, batch=bb, shape=[Bc, 144], progress=False, clip_denoised=False, cur_epoch=0, timestep_respacing="",
+                         cond_fn_with_grad=False, cond_grad_weight=0.0, compute_loss=False)
+    save("g16_e2e_ddpm1000_sensitive", batch_seed=63, noise_seed=63, B=Bc, N=N, n=n, respacing="", guided=False, cond_grad_weight=0.0, **_pack_out(o))
 
 
 def g13_gcn_nonlocal():

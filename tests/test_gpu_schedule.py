@@ -102,6 +102,24 @@ def test_default_path_on_sensitive_weights_vs_reference_golden(golden_dir, dev, 
     _check_out(o, g)
 
 
+def test_ddpm1000_on_sensitive_weights_vs_reference_golden(golden_dir, dev, smpl_asset):
+    """BASELINE config 5's loop length (1000-step DDPM) on a trained-like denoiser whose weights are 'trained' for n = 1000: a thousand steps over
+    which rounding errors are carried rather than contracted - the default path (calibrated at first use) against the reference's own run."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    g = _load(golden_dir, "g16_e2e_ddpm1000_sensitive")
+    B, N, n = int(g["B"]), int(g["N"]), int(g["n"])
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=n))
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing="")
+    b = batch_to_device(syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"])), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(n, B, seed=int(g["noise_seed"]))).to(dev)
+    o = d.val_losses(m, b, shape=[B, 144], clip_denoised=False, timestep_respacing="", compute_loss=False, noise_stack=noise)
+    info = m.fused_sampler.schedule_info
+    dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    print(f"[ddpm1000 sensitive] calibrated k = {info['k']} of {info['T']}; max|dverts| vs reference = {dv:.3e}")
+    _check_out(o, g)
+
+
 def _final_dist(fs, d, b, noise, ddim, lowprec):
     ref = fs.run(d, b, noise, ddim=ddim, lowprec=0)["other_outputs"]["pred_vertices"].clone()
     got = fs.run(d, b, noise, ddim=ddim, lowprec=lowprec)["other_outputs"]["pred_vertices"]

@@ -15,13 +15,11 @@ denoiser, rot6d->rotmat, SMPL LBS and the sampler update are hand-written HIP ke
 """
 from __future__ import annotations
 
-import ctypes as C
 from types import SimpleNamespace
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, geometry, synthetic
 from . import smpl as smpl_mod

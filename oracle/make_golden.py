@@ -459,6 +459,20 @@ def g16_sensitive_denoiser(asset, mean, std):
         o = d.val_losses(model=m, batch=bb, shape=[Bc, 144], progress=False, clip_denoised=False, cur_epoch=0, timestep_respacing="",
                          cond_fn_with_grad=False, cond_grad_weight=0.0, compute_loss=False)
     save("g16_e2e_ddpm1000_sensitive", batch_seed=63, noise_seed=63, B=Bc, N=N, n=n, respacing="", guided=False, cond_grad_weight=0.0, **_pack_out(o))
+    if os.environ.get("GOLDEN_SKIP_C5_SENSITIVE"):
+        return
+    # ... and BASELINE config 5 itself on it: the VolSMPL twin (egohmr_volsmpl.py:582-629: batched loss over all scene points, -loss.sum()), guided
+    mv = build_reference_model(syn.make_sensitive_state_dict(0, n), asset, mean, std, diffuse_fuse=True, volsmpl=True)
+    bb = to_torch_batch(syn.make_batch(Bc, num_scene_points=N, seed=64))
+    bb["scene_pcd_verts_full"][:, : N // 3, 1] = bb["smpl_params"]["transl"][:, None, 1] - 0.6
+    noise = torch.from_numpy(syn.make_noise_stack(n, Bc, seed=64))
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing="")
+    with explicit_noise(noise), torch.no_grad():
+        o = d.val_losses(model=mv, batch=bb, shape=[Bc, 144], progress=False, clip_denoised=False, cur_epoch=0, timestep_respacing="",
+                         cond_fn_with_grad=True, cond_grad_weight=0.5, compute_loss=False)
+        extra = {"eval_coll": np.array(mv.eval_coll(o), dtype=np.float64), "eval_coll_volsmpl": np.array(mv.eval_coll_volsmpl(o), dtype=np.float64)}
+    save("g16_e2e_ddpm1000_volsmpl_sensitive_guided", batch_seed=64, noise_seed=64, B=Bc, N=N, n=n, respacing="", guided=True, cond_grad_weight=0.5,
+         **extra, **_pack_out(o))
 
 
 def g13_gcn_nonlocal():

@@ -120,6 +120,28 @@ def test_ddpm1000_on_sensitive_weights_vs_reference_golden(golden_dir, dev, smpl
     _check_out(o, g)
 
 
+def test_c5_volsmpl_guided_ddpm1000_on_sensitive_weights_vs_reference_golden(golden_dir, dev, smpl_asset):
+    """BASELINE config 5 end to end on a trained-like denoiser: the VolSMPL twin (batched loss over all scene points, -loss.sum()), 1000-step DDPM,
+    guidance on the last 11 steps - the product's default path and its two collision metrics against the reference's own egohmr_volsmpl.py run."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    g = _load(golden_dir, "g16_e2e_ddpm1000_volsmpl_sensitive_guided")
+    B, N, n, w = int(g["B"]), int(g["N"]), int(g["n"]), float(g["cond_grad_weight"])
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=n), volsmpl=True)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing="")
+    bnp = syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"]))
+    bnp["scene_pcd_verts_full"][:, : N // 3, 1] = bnp["smpl_params"]["transl"][:, None, 1] - 0.6
+    b = batch_to_device(bnp, dev)
+    noise = torch.from_numpy(syn.make_noise_stack(n, B, seed=int(g["noise_seed"]))).to(dev)
+    o = d.val_losses(m, b, shape=[B, 144], clip_denoised=False, timestep_respacing="", compute_loss=False, noise_stack=noise,
+                     cond_fn_with_grad=True, cond_grad_weight=w)
+    dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    print(f"[C5 sensitive] k = {m.fused_sampler.schedule_info['k']}; max|dverts| vs reference = {dv:.3e}")
+    _check_out(o, g)
+    np.testing.assert_allclose(np.array(m.eval_coll(o)), g["eval_coll"], atol=1.01 / N)
+    np.testing.assert_allclose(np.array(m.eval_coll_volsmpl(o)), g["eval_coll_volsmpl"], atol=1.01 / N)
+
+
 def _final_dist(fs, d, b, noise, ddim, lowprec):
     ref = fs.run(d, b, noise, ddim=ddim, lowprec=0)["other_outputs"]["pred_vertices"].clone()
     got = fs.run(d, b, noise, ddim=ddim, lowprec=lowprec)["other_outputs"]["pred_vertices"]

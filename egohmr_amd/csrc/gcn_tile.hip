@@ -446,9 +446,13 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
       phases_before_barrier(buf);
       if (pending_publish) { publish(prev); pending_publish = false; }     // every wave's stores of the previous tile have landed (vmcnt(0) + barrier)
       read_frags(f0, buf ^ 1, 0);              // (KS even: the next tile starts on set 0 again)
+      // the phase that stages the operand pieces runs at raised priority: a wave in piece issue is the one its SIMD partner has to wait for
+      // least (split-f16 conv 144.1 -> 142.1 us, f16 conv 59.8 -> 58.0 us, same-box A/B; priority 3 and priority on the OTHER phase: no gain)
+      __builtin_amdgcn_s_setprio(2);
       stage(buf, kt + 2);
       mfmas(f_last);
       pin_reads_dma();
+      __builtin_amdgcn_s_setprio(0);
     }
     if constexpr (CHAIN) {
       if (tid == 0 && t_next < total) {        // were the producers of my NEXT tile complete already?

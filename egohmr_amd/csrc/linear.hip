@@ -295,9 +295,11 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       const int buf = kt & 1;
       first_phase(buf);
       read_frags(f0, buf ^ 1, 0);
+      __builtin_amdgcn_s_setprio(2);             // the staging phase at raised priority (as in gcn_tile.hip)
       stage(buf, kt + 2);
       mfmas(f1);
       pin_reads_dma();
+      __builtin_amdgcn_s_setprio(0);
     }
     {
       const int buf = (KT - 2) & 1;

@@ -5,7 +5,7 @@
 //   P = 1  "f16":   plain f16 storage [rows][hid] and one MFMA per product (BASELINE config 5's fp16 denoiser, and the early
 //          steps of the precision schedule).
 // Tile = 192 rows (8 bodies x 24 joints) x 64 channels x both branches (W0 | W1); 4 waves as 2 x 2, 96 x 32(x2) per wave;
-// operands stream L2 -> LDS with 16-byte LDS DMA (buffer_load_dwordx4 ... offen lds), one K tile = 128 bytes per row (64 k in f16, 32 k hi|lo in X2),
+// operands stream L2 -> LDS with 16-byte global_load_lds DMA, one K tile = 128 bytes per row (64 k in f16, 32 k hi|lo in X2),
 // two 40 KiB stages, XOR-swizzled on the source address so every ds_read_b128 fragment read is bank-conflict free; register
 // double-buffered fragments, one barrier per K tile.
 //

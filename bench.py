@@ -290,7 +290,13 @@ def main():
             m2.lbs_every_step = model.lbs_every_step
             info2 = m2.fused_sampler.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=w_guid, denom_items=B)
             legs[f"default_path_on_{other}_weights"] = leg("f16x3", "auto", m2, compare=False)
+            _, r_sched = one_step(m2)
+            m2.f16x3_last_steps = None
+            _, r_all = one_step(m2)
+            m2.f16x3_last_steps = "auto"
+            dv2 = (r_sched["other_outputs"]["pred_vertices"].float() - r_all["other_outputs"]["pred_vertices"].float()).norm(dim=-1)
             legs[f"default_path_on_{other}_weights"].update({
+                "vs_its_all_steps_f16x3_run": {"max_vertex_dist_mm": float(dv2.max()) * 1e3, "mean_v2v_mm": float(dv2.mean()) * 1e3},
                 "calibrated_f16x3_last_steps": info2["k"], "measured_gain_dx0_dxt": m2.fused_sampler.measure_gain(batch, timesteps=(n - 1, n // 2, n // 10, 0)),
                 "note": "the same job with the other synthetic weight set and ITS calibrated schedule (rounds 1-2 benchmarked the insensitive set with a constant k = 8)"})
             del m2

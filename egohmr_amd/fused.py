@@ -473,7 +473,7 @@ class FusedSampler:
         return r
 
     @torch.no_grad()
-    def calibrate_schedule(self, diffusion, batch=None, ddim=False, guided=False, cond_grad_weight=1.0, tol=None, bodies=32, prepared=None,
+    def calibrate_schedule(self, diffusion, batch=None, ddim=False, guided=False, cond_grad_weight=1.0, tol=None, bodies=64, prepared=None,
                            seeds=(20260929, 20260930), force=False, denom_items=None, n_guided=None):
         """Measure, for the weights that are loaded NOW, the smallest k such that a sampling loop whose first T - k steps run the hidden
         convs on plain f16 operands ends within `tol` metres (max vertex / joint distance, every body) of the loop that runs every step in
@@ -482,7 +482,7 @@ class FusedSampler:
         Why per checkpoint: x_{t-1} = c1 x0(x_t) + c2 x_t carries an early step's rounding error with gain c1 J + c2, J = d x0 / d x_t.
         A denoiser that ignores x_t (J ~ 0) contracts it away within a few steps; a trained START_X denoiser has J -> 1 / sqrt(abar_t)
         at low noise, where c1 J + c2 = 1 / sqrt(alpha_t) >= 1: the error is carried to the output (gaussian_diffusion.py:298-337 is exact
-        for any weights, so must this be).  Procedure: `bodies` items of the batch (conditioning already encoded), two private noise
+        for any weights, so must this be).  Procedure: the first `bodies` items of the batch (conditioning already encoded), two private noise
         draws; bisection over a geometric ladder of k with draw A against tol / 2, then draw B must pass too (k moves up the ladder until
         it does).  k = T (no f16 step at all) always passes, so the result is always safe; cost = ~6-10 small sampling loops, once per
         (weights, sampler).  Returns the info dict that `schedule_info` / bench.py report."""

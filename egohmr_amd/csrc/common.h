@@ -64,6 +64,13 @@ static __device__ __forceinline__ float wave_sum(float v) {    // wave-uniform s
 // Buffer descriptor over [p, p + 2 GiB) for raw_buffer_load/store: SGPR descriptor + 32-bit lane offset + scalar offset, i.e. no
 // VALU address arithmetic.  readfirstlane pins the (wave-uniform) base into SGPRs; without it hipcc wraps every access in a
 // waterfall loop.
+// (num_records = 2 GiB - 1: the default; ehm_buffer_rsrc_4g covers [p, p + 4 GiB) for the one caller whose lane offsets span a whole tensor)
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t ehm_buffer_rsrc_4g(const void* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)a);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)0xffffffffu, 0x00020000);
+}
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t ehm_buffer_rsrc(const void* p) {
   const unsigned long long a = (unsigned long long)p;
   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)a);

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   // offset per lane and piece (the gathered pixel, or the zero row), the weights' piece in the scalar offset
   unsigned int pbase[6];        // byte offset (mod 2^32: border pixels start below zero) of the (kh = 0, kw = 0) tap pixel's channel 0 + my swizzled chunk
   unsigned int pmask[6];
-  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc(p.x);
+  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(p.x);      // lane offsets address the whole activation tensor (< 2^30 elements = 4 GiB, checked by ehm_conv_x2)
   __amdgpu_buffer_rsrc_t rsB;
   int voB;
   const int brow32 = 32 * K;

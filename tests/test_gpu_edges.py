@@ -64,3 +64,28 @@ def test_guidance_with_nothing_to_collide_with_equals_the_unguided_loop(dev, syn
     assert m.eval_coll(guided["other_outputs"]) == [0.0] * B
     g = m.guide_coll(b | {"x_t": noise[0]}, guided["other_outputs"], torch.zeros(B, dtype=torch.long, device=dev))
     assert g.shape == (B, 144) and float(g.abs().max()) == 0.0
+
+
+def test_resnet_activation_offsets_beyond_2_gib(dev, synth_weights):
+    """The X2 trunk addresses its input activations through 32-bit BYTE offsets in a buffer descriptor (csrc/conv.hip): a batch whose
+    layer-1 tensor is larger than 2 GiB (1100 images: 883 M elements = 3.5 GB) must give the same features as the same images in a
+    small batch, and a batch past the 2^30-element limit must be refused, not silently mis-addressed."""
+    from egohmr_amd import _lib
+    from egohmr_amd.encoders import ResNet50Features
+    net = ResNet50Features()
+    net.load_state_dict({k[len("backbone."):]: torch.from_numpy(np.asarray(v)) for k, v in synth_weights.items() if k.startswith("backbone.")})
+    net = net.to(dev).eval()
+    fwd = net.folded()
+    g = torch.Generator(device=dev).manual_seed(5)
+    img = torch.randn(1100, 3, 224, 224, device=dev, generator=g)
+    with torch.no_grad():
+        big = fwd(img)
+        small = fwd(img[-4:].contiguous())
+        first = fwd(img[:4].contiguous())
+    np.testing.assert_allclose(big[-4:].cpu().numpy(), small.cpu().numpy(), atol=5e-6)
+    np.testing.assert_allclose(big[:4].cpu().numpy(), first.cpu().numpy(), atol=5e-6)
+    assert torch.isfinite(big).all() and float(big.abs().max()) > 0
+    del big, img
+    torch.cuda.empty_cache()
+    with pytest.raises(_lib.EgoHMRHipError):
+        fwd(torch.zeros(1400, 3, 224, 224, device=dev))

@@ -68,3 +68,33 @@ def test_state_dict_names_match_reference_manifest():
     m = build_synthetic_model("cpu", 0)
     mine = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("smpl.")}
     assert mine == dict(syn.egohmr_manifest())
+
+
+def test_oracle_is_test_infrastructure_only():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import oracle/: nothing under egohmr_amd/ or tools/ does, and the
+    two allowed files import it inside exactly those functions."""
+    import ast
+    import glob
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef):
+                for sub in ast.walk(node):
+                    if isinstance(sub, (ast.Import, ast.ImportFrom)):
+                        names = [a.name for a in sub.names] if isinstance(sub, ast.Import) else [sub.module or ""]
+                        if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                            hits.append(node.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        for sub in top:
+            names = [a.name for a in sub.names] if isinstance(sub, ast.Import) else [sub.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                hits.append("<module>")
+        return hits
+
+    for f in glob.glob(os.path.join(repo, "egohmr_amd", "*.py")) + glob.glob(os.path.join(repo, "tools", "*.py")):
+        assert oracle_imports(f) == [], f
+    assert set(oracle_imports(os.path.join(repo, "bench.py"))) == {"cpu_baseline"}
+    assert set(oracle_imports(os.path.join(repo, "__graft_entry__.py"))) == {"smoke"}

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void skin_mfma_kernel(SkinArgs a) {
 // run the input conv (gcn_dev.h: gcn_input_body); one 36 KiB LDS buffer serves either.  Separate streams for the two cost more in
 // cross-stream events than they overlapped (measured: -7 %), a second kernel boundary costs 2.6 us.
 template <int OUT>
-__global__ __launch_bounds__(256) void skin_input_kernel(SkinArgs a, GcnInputArgs g, int skin_blocks) {
+__global__ __launch_bounds__(256, 4) void skin_input_kernel(SkinArgs a, GcnInputArgs g, int skin_blocks) {
   __shared__ __attribute__((aligned(16))) float sbuf[32 * kJ * 12];
   if ((int)blockIdx.x < skin_blocks) {
     skin_mfma_body((float (*)[kJ][12])sbuf, blockIdx.x, a);

@@ -142,6 +142,8 @@ class FusedSampler:
         # recycled for a different batch while the entry is alive; in-place edits bump _version.
         ins = [batch["img"], batch["scene_pcd_verts_full"], batch["orig_keypoints_2d"], batch["fx"], batch["cam_cx"], batch["cam_cy"],
                batch["box_center"], batch["box_size"], batch["smpl_params"]["transl"]]
+        if ins[0].shape[0] == 0:
+            raise ValueError("empty batch (the reference fails on it too: egohmr.py:233 reshapes x_t [0, 144] to [0, 24, -1])")
         key = tuple((id(t), t._version, t.data_ptr()) for t in ins) + self._param_key() + self._cond_param_key()
         if self._prep is not None and self._prep_key == key:
             return self._prep
@@ -200,12 +202,22 @@ class FusedSampler:
         other = torch.cat([scene_feats, transl_feat, cam], dim=1)                      # :220-221
         f = self._folded
         h_img, h_oth, betas = self._project(img_feats.contiguous(), other)
+        # The reference's float32 graph carries a NaN / Inf of an item's inputs into every output of THAT item (ReLU and max-pool propagate NaN
+        # in torch); the kernels' v_max / saturating conversions would swallow it.  One flag per item, applied to the outputs (_pack_output).
+        # (a row sum is non-finite exactly when the row holds a NaN / Inf - or finite values whose float32 sum overflows, which no image or
+        # point cloud in metres does: one read of the tensor, no 38 M-element temporary)
+        rows_ok = lambda t: torch.isfinite(t.reshape(t.shape[0], -1).sum(dim=1))
+        finite = rows_ok(img) & rows_ok(scene) & rows_ok(transl) & torch.isfinite(fx)
+        if m.with_bbox_info:
+            finite = finite & rows_ok(bc) & torch.isfinite(bs)
+        if m.with_cam_center:
+            finite = finite & torch.isfinite(cx) & torch.isfinite(cy)
         count_ready.synchronize()
         num_masked = int(self._count_host[0])
         mask_items = order[:num_masked].contiguous()
         self._prep = _Prepared(B=img_feats.shape[0], h_img=h_img, h_oth=h_oth, vis=vis.to(torch.uint8).contiguous(), vis_bool=vis,
                                betas=betas, scene=scene, transl=transl, fx=fx, cam_cx=cx, cam_cy=cy, img_feats=img_feats,
-                               scene_feats=scene_feats)
+                               scene_feats=scene_feats, finite=finite)
         self._prep.inputs = ins                  # strong references (see the key above)
         self._prep.mask_items, self._prep.mask_slot, self._prep.num_masked = mask_items, mask_slot, num_masked
         self._prep_key = key
@@ -720,11 +732,16 @@ class FusedSampler:
                 tr = torch.empty(T, B, 144, device=dev) if trace else None
                 launch(o, self._workspace(nbytes, dev), tr)
         x_final, x0, verts, joints, R, pose6d = o.x_final, o.x0, o.verts, o.joints, o.R, o.pose6d
+        # non-finite noise: x_T or a step's draw poisons the item from the next denoiser evaluation on; the LAST step's draw is multiplied by
+        # nonzero_mask = 0 (DDIM: by sigma = 0 too) and 0 * NaN = NaN lands in that element of `sample` only (gaussian_diffusion.py:357-359, :575-580)
+        st_out = _Prepared(**vars(st))
+        st_out.finite = st.finite & torch.isfinite(noise[:T]).all(dim=2).all(dim=0)
+        x_final.masked_fill_(~st_out.finite[:, None] | ~torch.isfinite(noise[T]), float("nan"))
         self.last_trace = tr
         if tr is not None:
             batch["x_t"] = tr[-1]
         batch["vis_mask_smpl"] = st.vis_bool
-        out = m._pack_output(batch, st, x0, pose6d, R, verts, joints)
+        out = m._pack_output(batch, st_out, x0, pose6d, R, verts, joints)
         # a chained launch that gave up on a producer wait (GPU shared / preempted) flags the handle instead of hanging: one read-back
         # per sampling call (the call's only host wait, after everything has been enqueued) turns that into an exception rather than
         # silently wrong bodies

@@ -273,9 +273,17 @@ class EgoHMR(nn.Module):
                                                      _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(R), _lib.ptr(pose6d), None, B,
                                                      _lib.stream_ptr()), "ehm_smpl_forward_rot6d")
         batch["vis_mask_smpl"] = st.vis_bool
-        return self._pack_output(batch, st, x0, pose6d, R, verts, joints)
+        st_out = type(st)(**vars(st))
+        st_out.finite = st.finite & torch.isfinite(x_t).all(dim=1)
+        return self._pack_output(batch, st_out, x0, pose6d, R, verts, joints)
 
     def _pack_output(self, batch, st, x0, pose6d, R, verts, joints):
+        # items with a NaN / Inf in their inputs come out as NaN, like the reference's float32 graph gives them (FusedSampler.prepare)
+        bad = ~st.finite
+        nan = float("nan")
+        for t in (x0, pose6d, R, verts, joints):
+            t.masked_fill_(bad.reshape(-1, *([1] * (t.dim() - 1))), nan)
+        betas = st.betas.masked_fill(bad[:, None], nan)
         self.scene_pcd_verts = st.scene
         self.input_transl = st.transl
         self.smpl_output = smpl_mod.SMPLOutput(vertices=verts, joints=joints, full_pose=R)
@@ -286,7 +294,7 @@ class EgoHMR(nn.Module):
         kp2d = torch.stack([kp2d[..., 0] / 1920 - 0.5, kp2d[..., 1] / 1080 - 0.5], dim=-1)
         return {
             "pred_x_start": x0,
-            "pred_smpl_params": {"global_orient": R[:, [0]].clone(), "body_pose": R[:, 1:].clone(), "betas": st.betas.clone()},
+            "pred_smpl_params": {"global_orient": R[:, [0]].clone(), "body_pose": R[:, 1:].clone(), "betas": betas},
             "pred_pose_6d": pose6d,
             "pred_keypoints_3d": joints,
             "pred_vertices": verts,

@@ -223,6 +223,11 @@ def test_error_behaviour(dev, model):
     assert torch.isfinite(out["sample"]).all()
     with pytest.raises(NotImplementedError):
         d.training_losses(model, _batch(dev), torch.zeros(3, dtype=torch.long))           # training is out of scope
+    empty = {k: ({kk: vv[:0] for kk, vv in v.items()} if isinstance(v, dict) else v[:0]) for k, v in _batch(dev).items()}
+    with pytest.raises(ValueError, match="empty batch"):          # the reference fails too (egohmr.py:233: reshape of [0, 144] to [0, 24, -1])
+        d.p_sample_loop(model, empty, [0, 144])
+    with pytest.raises(IndexError):                                # gaussian_diffusion.py:160 indexes posterior_variance[1]: one-step chains fail there too
+        create_gaussian_diffusion(num_diffusion_timesteps=1, timestep_respacing="")
 
 
 def test_rotation_matrix_to_angle_axis_vs_reference_golden(golden_dir, dev):

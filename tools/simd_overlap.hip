@@ -11,7 +11,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int LOAD, bool READS>   // LOAD 0 none, 1 global_load_lds, 2 global_load_lds sc1, 3 global_load_dwordx4 -> VGPR
+template <int LOAD, bool READS, bool PACKED = true>   // LOAD 0 none, 1 global_load_lds, 2 global_load_lds sc1, 3 global_load_dwordx4 -> VGPR
 __global__ __launch_bounds__(512) void overlap_loop(const half8* __restrict__ A, const char* __restrict__ src, unsigned int window_bytes,
                                                     int iters, int pieces, int do_compute, float* __restrict__ out, int valu) {
   __shared__ __attribute__((aligned(16))) char lds[80 * 1024];
@@ -78,12 +78,16 @@ __global__ __launch_bounds__(512) void overlap_loop(const half8* __restrict__ A,
     float e[8];                                                              // `valu` independent-chain FMAs per iteration: the epilogue slice a helper wave would run
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = lane * 0.001f + i;
+    const float m1 = 0.999f + lane * 1e-9f, m2 = 0.001f;
     for (int it = 0; it < iters; ++it) {
       for (int v = 0; v < (valu < 0 ? -valu : valu); v += 64) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) e[i] = __builtin_fmaf(e[i], 0.999f, 0.001f * (r + 1));
+          for (int i = 0; i < 8; ++i) {
+            if (PACKED) e[i] = __builtin_fmaf(e[i], 0.999f, 0.001f * (r + 1));          // hipcc SLP-packs these into v_pk_fma_f32
+            else asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(e[i]) : "v"(m1), "v"(m2));   // the conv epilogue's adjacency mix is 1128 plain v_fmac_f32
+          }
       }
       if (LOAD != 0) {
         for (int p = 0; p < pieces; ++p) {
@@ -107,5 +111,14 @@ extern "C" int overlap_launch(int load, int reads, const void* A, const void* sr
 #define L(LD, RD) hipLaunchKernelGGL((overlap_loop<LD, RD>), dim3(blocks), dim3(512), 0, st, (const half8*)A, (const char*)src, window_bytes, iters, pieces, do_compute, out, valu)
   if (reads) { if (load == 0) L(0, true); else if (load == 1) L(1, true); else if (load == 2) L(2, true); else L(3, true); }
   else { if (load == 0) L(0, false); else if (load == 1) L(1, false); else if (load == 2) L(2, false); else L(3, false); }
+  return (int)hipGetLastError();
+}
+
+// the same, with the partner wave's vector-ALU work as plain v_fmac_f32 (LOAD: 0 none, 1 global_load_lds; fragment reads on)
+extern "C" int overlap_launch_plain_valu(int load, const void* A, const void* src, unsigned int window_bytes, int iters, int pieces, int do_compute,
+                                         float* out, int blocks, void* stream, int valu) {
+  hipStream_t st = (hipStream_t)stream;
+  if (load == 0) hipLaunchKernelGGL((overlap_loop<0, true, false>), dim3(blocks), dim3(512), 0, st, (const half8*)A, (const char*)src, window_bytes, iters, pieces, do_compute, out, valu);
+  else hipLaunchKernelGGL((overlap_loop<1, true, false>), dim3(blocks), dim3(512), 0, st, (const half8*)A, (const char*)src, window_bytes, iters, pieces, do_compute, out, valu);
   return (int)hipGetLastError();
 }

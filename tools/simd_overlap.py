@@ -71,3 +71,34 @@ for reads in (0, 1):
         base = run(0, reads, 0, 1); c_base = last_cycles
         print(json.dumps({"loader": "VALU only", "valu_fma_per_iter": valu, "fragment_reads": bool(reads), "cycles_loader_only": c_alone, "cycles_both": c_both,
                           "cycles_compute_only": c_base}), flush=True)
+
+# the same pairs with the partner's vector-ALU work as PLAIN v_fmac_f32 (what the conv epilogue's adjacency mix is: 1128 v_fmac_f32 per lane and tile);
+# the rows above use what hipcc makes of independent fmaf chains: v_pk_fma_f32, which MI355X_MICROARCH.md lists as an anti-lever beside MFMAs
+lib.overlap_launch_plain_valu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+
+
+def run_plain(load, pieces, do_compute, valu):
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.overlap_launch_plain_valu(load, A.data_ptr(), src.data_ptr(), window, 100, pieces, do_compute, out.data_ptr(), cus, st, valu) == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    assert lib.overlap_launch_plain_valu(load, A.data_ptr(), src.data_ptr(), window, iters, pieces, do_compute, out.data_ptr(), cus, st, valu) == 0
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters, float(out.view(cus, 512)[:, 0].mean()) / iters
+
+
+for valu in (256, 512, 1024, 2048):
+    _, c_alone = run_plain(0, 0, 0, valu)
+    us_both, c_both = run_plain(0, 0, 1, valu)
+    _, c_base = run_plain(0, 0, 1, 0)
+    print(json.dumps({"loader": "VALU only, plain v_fmac_f32", "valu_fma_per_iter": valu, "fragment_reads": True, "cycles_loader_only": c_alone, "cycles_both": c_both,
+                      "cycles_compute_only": c_base, "both_over_sum": c_both / (c_alone + c_base), "both_over_max": c_both / max(c_alone, c_base)}), flush=True)
+for valu in (256, 512):
+    _, c_alone = run_plain(1, 10, 0, valu)
+    us_both, c_both = run_plain(1, 10, 1, valu)
+    _, c_base = run_plain(0, 0, 1, 0)
+    print(json.dumps({"loader": "global_load_lds + plain v_fmac_f32", "valu_fma_per_iter": valu, "pieces_per_iter_per_wave": 10, "fragment_reads": True, "cycles_loader_only": c_alone,
+                      "cycles_both": c_both, "cycles_compute_only": c_base, "both_over_sum": c_both / (c_alone + c_base), "both_over_max": c_both / max(c_alone, c_base),
+                      "mfma_tflops_both": cus * 4 * 36 * 32768 / us_both / 1e6}), flush=True)

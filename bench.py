@@ -47,6 +47,9 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achi
 # v_mfma_f32_32x32x16_f16 loop, 8 waves per CU; tools/mfma_ceiling.py -> profiles/r03_mfma_ceiling.jsonl) - a measured reference, not re-measured here.
 # Both chained conv kernels run AT that cap (tools/power_probe.py -> profiles/r03_power_probe.jsonl: 1400 / 1390 W).
 POWER_LIMITED_MFMA_TFLOPS = {"f16": 1772.0, "f16x3": 1815.0}
+# The vendor library on the same GEMM, same data, NO epilogue: torch.matmul (hipBLASLt) [12288, 1024] x [1024, 2048] f16 -> f16 on relu-like activations,
+# sustained (tools/gemm_yardstick.py -> profiles/r03_gemm_yardstick.jsonl; the same box ran the f16 conv at 46.7 us in situ) - a measured reference.
+VENDOR_GEMM_US_PER_F16_CONV = 53.4
 
 
 def self_launch(argv):
@@ -351,7 +354,9 @@ def main():
                                  "socket_power_w": {"f16x3": 1400, "f16": 1390}[prec], "socket_cap_w": 1400,
                                  "mfma_only_ceiling_tflops_at_the_cap": POWER_LIMITED_MFMA_TFLOPS[prec],
                                  "issued_frac_of_that_ceiling": flops * per_prod / kd / 1e12 / POWER_LIMITED_MFMA_TFLOPS[prec],
-                                 "source": "profiles/r03_power_probe.jsonl, profiles/r03_mfma_ceiling.jsonl (measured references; the guide's tuned-GEMM random-data figure is 1247 TFLOP/s = 0.50)"},
+                                 "source": "profiles/r03_power_probe.jsonl, profiles/r03_mfma_ceiling.jsonl (measured references; the guide's tuned-GEMM random-data figure is 1247 TFLOP/s = 0.50)",
+                                 "vendor_gemm_same_shape_no_epilogue_us": VENDOR_GEMM_US_PER_F16_CONV * per_prod if (B, S) == (256, 1) else None,
+                                 "vendor_gemm_note": "torch.matmul / hipBLASLt f16 GEMM of one conv's two branches at B256 x 2 passes, relu-like data, no epilogue (x3 for split-f16: three such GEMMs); profiles/r03_gemm_yardstick.jsonl"},
                              "traffic": pmc_traffic(prec) if (B, S) == (256, 1) else None, "avg_launch_ms": kd * 1e3,
                              "avg_launch_ms_is": "per conv = (HIP-event span of the chained launch, on the launch stream, inside a real sampling call) / 8",
                              "launches_per_call": pr["launches_per_call"], "ms_per_call": pr["ms_per_call"], "flops_per_launch": flops,

@@ -441,6 +441,13 @@ def main():
             out["cpu_baseline_hoisted"] = cpu_baseline(n, rs, N, args.cpu_seconds * 0.4, faithful=False) if T <= 100 else None
         else:
             out["cpu_baseline"] = None
+        if args.workload == "ddpm100":
+            # the reference's own way of running the path - eager PyTorch, float32 - on an MI355X: a measured reference (tools/eager_gpu_yardstick.py,
+            # profiles/r03_eager_gpu_yardstick.jsonl; MIOpen / hipBLASLt, no SMPL forward inside its steps), not re-measured here
+            out["eager_torch_f32_on_mi355x"] = {"faithful_bodies_per_s": 32.0, "hoisted_bodies_per_s": 280.0, "unit": "bodies/s",
+                                                "note": "same graph as plain torch ops on the GPU, B256 DDPM-100, 2 GCN passes; 'faithful' re-encodes image and scene in every "
+                                                        "step like the reference (egohmr.py:182-223); its per-step SMPL forward is left out (favours it)",
+                                                "source": "profiles/r03_eager_gpu_yardstick.jsonl"}
         print(json.dumps(out))
     edist.barrier()
 

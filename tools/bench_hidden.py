@@ -32,7 +32,9 @@ if os.environ.get("EHM_STACK"):      # time the sampler's own call instead: all 
     bufs = (C.c_void_p * 3)(X.data_ptr(), Y1.data_ptr(), Y2.data_ptr())
     res = C.c_int(0)
     nl = 2 * model.diffusion_model.num_layers
-    for _ in range(2):
+    # the first launches after start-up run at ramping clocks (5 timed launches after 2 warm-up ones read 160 us per split-f16 conv, 400 read 125):
+    # warm up for real unless a profiler pass wants few dispatches (EHM_WARMUP=2 in tools/profile_round.sh / pmc_round.sh)
+    for _ in range(int(os.environ.get("EHM_WARMUP", "40"))):
         _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), None))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,7 +19,7 @@ cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_ddpm100_kernel_sta
 MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c3 -o kt -- python $R/bench.py --workload c3_guided --steps 2 --warmup 1 --cpu-seconds 0 --no-legs > $O/bench_c3_under_rocprof.json 2>> $O/rocprof.err
 cp $(find $O/kt_c3 -name "*kernel_stats.csv" | head -1) $O/bench_c3_guided_kernel_stats.csv
 for p in f16 f16x3; do for c in FETCH_SIZE WRITE_SIZE; do
-  MIOPEN_FIND_MODE=FAST EHM_STACK=1 timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${p}_$c -o pmc -- python $R/tools/bench_hidden.py $p 5 > $O/pmc_${p}_$c.log 2>&1
+  MIOPEN_FIND_MODE=FAST EHM_STACK=1 EHM_WARMUP=2 timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${p}_$c -o pmc -- python $R/tools/bench_hidden.py $p 5 > $O/pmc_${p}_$c.log 2>&1
 done; done
 python $R/tools/pmc_traffic.py $O > $O/pmc_traffic.json; cat $O/pmc_traffic.json
 rm -rf $O/kt $O/kt_c3

@@ -185,7 +185,7 @@ Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* ba
 }  // namespace
 
 extern "C" int64_t ehm_sample_workspace_bytes(const ehm_sample_desc* d, int hid_dim, int num_verts) {
-  if (!d || d->B <= 0 || (d->passes != 1 && d->passes != 2) || hid_dim <= 0 || num_verts <= 0) return EHM_EINVAL;
+  EHM_CHECK_ARG(d && d->B > 0 && (d->passes == 1 || d->passes == 2) && hid_dim > 0 && num_verts > 0);
   return carve(d, hid_dim, num_verts, 64 + kJ, nullptr).total_bytes;
 }
 

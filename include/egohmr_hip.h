@@ -20,6 +20,7 @@
 #ifndef EGOHMR_HIP_H
 #define EGOHMR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

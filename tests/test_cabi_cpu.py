@@ -29,6 +29,37 @@ def test_library_exports_every_declared_symbol():
     assert L.ehm_gcn_row_tile() == 192
 
 
+def test_header_is_plain_c_and_a_c_program_binds_the_library(tmp_path):
+    """include/egohmr_hip.h is the drop-in boundary: it must compile as strict C99 (and C++17) on its own, and a C program that includes it
+    must link against the library and call through it (no torch, no Python types) - here the GPU-free entry points only."""
+    import shutil
+    import subprocess
+    from egohmr_amd import _lib
+    _lib.build()
+    inc = os.path.join(REPO, "include")
+    so = _lib.library_path() if hasattr(_lib, "library_path") else os.path.join(REPO, "egohmr_amd", "libegohmr_hip.so")
+    src = tmp_path / "bind.c"
+    src.write_text(
+        '#include "egohmr_hip.h"\n#include <stdio.h>\n#include <string.h>\n'
+        "int main(void) {\n"
+        "  ehm_sample_desc d; memset(&d, 0, sizeof d);\n"
+        '  if (strcmp(ehm_target_arch(), "gfx950") != 0) return 1;\n'
+        "  if (ehm_gcn_row_tile() != 192) return 2;\n"
+        "  if (ehm_sample_workspace_bytes(NULL, 1024, 6890) != -22) return 3;          /* EHM_EINVAL without touching a GPU */\n"
+        '  if (strstr(ehm_last_error(), "bad argument") == NULL) return 4;\n'
+        '  printf("%d %s\\n", (int)sizeof d, ehm_target_arch());\n'
+        "  return 0;\n}\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
+    exe = tmp_path / "bind"
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), so, "-o", str(exe), "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.split()[1] == "gfx950"
+    import ctypes
+    assert int(out.stdout.split()[0]) == ctypes.sizeof(_lib.SampleDesc), "the ctypes mirror of ehm_sample_desc has drifted from the header"
+
+
 def test_cabi_rejects_bad_arguments_without_a_gpu():
     from egohmr_amd import _lib
     L = _lib.lib()

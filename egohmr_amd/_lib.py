@@ -236,3 +236,12 @@ def f32(t, device=None):
 
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(dev):
+    """Context for a native call: the HIP device of the tensors it is given becomes the current one (the library launches on the CURRENT
+    device's stream; a model living on cuda:1 of a process whose current device is cuda:0 must not launch there).  CPU devices pass through -
+    the call sites reject CPU tensors themselves (EgoHMRHipError)."""
+    import contextlib
+    dev = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    return torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()

@@ -165,13 +165,14 @@ class ResNet50Features(nn.Module):
             x = _lib.f32(x)
             if x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
                 raise _lib.EgoHMRHipError(f"the fused stem needs [N,3,H,W] images with H, W multiples of 32 (the reference feeds 224 x 224 crops); got {tuple(x.shape)}")
-            if x2_activations:
-                return run_x2(x)
-            x = stem_mc(x)                                                          # NHWC float32 from here on
-            for c1, c2, c3, ds in blocks:
-                y = conv_mc(conv_mc(x, c1), c2)
-                x = conv_mc(y, c3, res=x if ds is None else conv_mc(x, ds, relu=False))
-            return x.mean(dim=(1, 2))
+            with _lib.on_device(x.device):                                          # the library launches on the CURRENT device's stream
+                if x2_activations:
+                    return run_x2(x)
+                x = stem_mc(x)                                                      # NHWC float32 from here on
+                for c1, c2, c3, ds in blocks:
+                    y = conv_mc(conv_mc(x, c1), c2)
+                    x = conv_mc(y, c3, res=x if ds is None else conv_mc(x, ds, relu=False))
+                return x.mean(dim=(1, 2))
 
         return run
 
@@ -251,6 +252,11 @@ class ResnetPointnet(nn.Module):
         from . import _lib
         if not p.is_cuda:
             raise _lib.EgoHMRHipError("ResnetPointnet runs on the HIP kernels only (got a CPU tensor); there is no CPU path")
+        with _lib.on_device(p.device):                                                   # the library launches on the CURRENT device's stream
+            return self._forward_on_device(p)
+
+    def _forward_on_device(self, p):
+        from . import _lib
         L, dev, H = _lib.lib(), p.device, self.hidden_dim
         P = self._prepare(dev)
         p = _lib.f32(p)

@@ -136,6 +136,10 @@ class FusedSampler:
     @torch.no_grad()
     def prepare(self, batch) -> _Prepared:
         """Everything in EgoHMR.forward that does not depend on x_t / t (egohmr.py:182-223, :263-265)."""
+        with _lib.on_device(self.model.device):          # every native call below launches on the CURRENT device's stream
+            return self._prepare_on_device(batch)
+
+    def _prepare_on_device(self, batch) -> _Prepared:
         m = self.model
         # Cache key = identity AND version of every tensor the conditioning is computed from, and of every weight it passes
         # through.  The cached entry keeps strong references to those input tensors, so neither their id() nor their storage can be
@@ -635,6 +639,10 @@ class FusedSampler:
             defer_status=False, lowprec=None):
         """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
         Returns the reference's dict(sample, pred_xstart, other_outputs)."""
+        with _lib.on_device(self.model.device):
+            return self._run_on_device(diffusion, batch, noise_stack, ddim, guided, cond_grad_weight, trace, prepared, denom_items, defer_status, lowprec)
+
+    def _run_on_device(self, diffusion, batch, noise_stack, ddim, guided, cond_grad_weight, trace, prepared, denom_items, defer_status, lowprec):
         m, L = self.model, _lib.lib()
         nonlocal_ci = m.diffusion_model.non_local.inter_channels if m.diffusion_model.nonlocal_layer else 0
         if nonlocal_ci and m.gcn_precision == "f16":

@@ -19,7 +19,8 @@ class _Rot6dToRotmat(torch.autograd.Function):
         x = _lib.f32(x).reshape(-1, 6)
         n = x.shape[0]
         R = torch.empty(n, 3, 3, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().ehm_rot6d_to_rotmat(_lib.ptr(x), _lib.ptr(R), n, mode, _lib.stream_ptr()), "ehm_rot6d_to_rotmat")
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().ehm_rot6d_to_rotmat(_lib.ptr(x), _lib.ptr(R), n, mode, _lib.stream_ptr()), "ehm_rot6d_to_rotmat")
         ctx.save_for_backward(x)
         ctx.mode = mode
         return R
@@ -29,8 +30,9 @@ class _Rot6dToRotmat(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         gR = _lib.f32(gR)
         gx = torch.empty_like(x)
-        _lib.check(_lib.lib().ehm_rot6d_to_rotmat_bwd(_lib.ptr(x), _lib.ptr(gR), _lib.ptr(gx), x.shape[0], ctx.mode,
-                                                      _lib.stream_ptr()), "ehm_rot6d_to_rotmat_bwd")
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().ehm_rot6d_to_rotmat_bwd(_lib.ptr(x), _lib.ptr(gR), _lib.ptr(gx), x.shape[0], ctx.mode,
+                                                          _lib.stream_ptr()), "ehm_rot6d_to_rotmat_bwd")
         return gx, None
 
 

@@ -245,6 +245,10 @@ class EgoHMR(nn.Module):
 
     def forward(self, batch, timesteps, eval_with_uncond=True):
         """One denoising evaluation (egohmr.py:173-303).  Conditioning is cached per batch object."""
+        with _lib.on_device(self.device):                 # native calls launch on the CURRENT device's stream
+            return self._forward_on_device(batch, timesteps, eval_with_uncond)
+
+    def _forward_on_device(self, batch, timesteps, eval_with_uncond):
         fs = self.fused_sampler
         st = fs.prepare(batch)
         x_t = _lib.f32(batch["x_t"], self.device).reshape(-1, 144)

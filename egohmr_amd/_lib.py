@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EHM_LIB_PATH") or os.path.join(_HERE, "libegohmr_hip.so")   # EHM_LIB_PATH: A/B a second build (experiments)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip"]
+SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip", "prep.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -75,6 +75,27 @@ class ConvX2Desc(C.Structure):
                 ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
                 ("w_scale", C.c_float)]
+
+
+class ItemPrepDesc(C.Structure):
+    """ehm_item_prep_desc"""
+    _fields_ = [("keypoints_2d", C.c_void_p), ("joint_map", C.c_void_p), ("NK", C.c_int), ("force_visible", C.c_int),
+                ("fx", C.c_void_p), ("cx", C.c_void_p), ("cy", C.c_void_p), ("box_center", C.c_void_p), ("box_size", C.c_void_p), ("transl", C.c_void_p),
+                ("fx_norm", C.c_float), ("with_bbox", C.c_int), ("with_cam_center", C.c_int),
+                ("tW1", C.c_void_p), ("tb1", C.c_void_p), ("tW2", C.c_void_p), ("tb2", C.c_void_p), ("t_hidden", C.c_int), ("t_out", C.c_int),
+                ("img_rowsum", C.c_void_p), ("scene_rowsum", C.c_void_p), ("other", C.c_void_p), ("other_ld", C.c_int), ("other_col0", C.c_int),
+                ("vis", C.c_void_p), ("mask_slot", C.c_void_p), ("mask_items", C.c_void_p), ("count", C.c_void_p), ("finite", C.c_void_p),
+                ("need_scratch", C.c_void_p), ("pass_group", C.c_int), ("B", C.c_int)]
+
+
+class PackDesc(C.Structure):
+    """ehm_pack_desc"""
+    _fields_ = [("B", C.c_int), ("J", C.c_int), ("V", C.c_int), ("finite", C.c_void_p), ("chk", C.c_void_p), ("chk_rows", C.c_int),
+                ("last_noise", C.c_void_p), ("x_final", C.c_void_p), ("x0", C.c_void_p), ("pose6d", C.c_void_p), ("R", C.c_void_p),
+                ("verts", C.c_void_p), ("joints", C.c_void_p), ("betas_in", C.c_void_p), ("betas_out", C.c_void_p),
+                ("transl", C.c_void_p), ("fx", C.c_void_p), ("cx", C.c_void_p), ("cy", C.c_void_p), ("fx_norm", C.c_float),
+                ("global_orient", C.c_void_p), ("body_pose", C.c_void_p), ("kp3d_full", C.c_void_p), ("kp2d_full", C.c_void_p),
+                ("focal", C.c_void_p), ("center", C.c_void_p), ("finite_out", C.c_void_p)]
 
 
 class StepCoefs(C.Structure):
@@ -145,6 +166,8 @@ PROTOTYPES = {
     "ehm_nn_dist2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ehm_sample_workspace_bytes": (_L, [C.POINTER(SampleDesc), _I, _I]),
     "ehm_sample_loop": (_I, [_P, _P, C.POINTER(SampleDesc), C.POINTER(StepCoefs)] + [_P] * 18 + [_L, _P]),
+    "ehm_item_prep": (_I, [C.POINTER(ItemPrepDesc), _P]),
+    "ehm_pack_outputs": (_I, [C.POINTER(PackDesc), _P]),
     "ehm_profile_begin": (_I, []),
     "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }

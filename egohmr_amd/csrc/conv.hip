@@ -561,12 +561,11 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 
 // X2 [rows, C] -> float32 mean over groups of `hw` consecutive rows: the global average pool behind the last bottleneck
 __global__ void x2_group_mean_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int hw, int C) {
-  const int img = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < hw; ++r) s += split_load<32>(X, (size_t)img * hw + r, c, C);
-    Y[(size_t)img * C + c] = s / (float)hw;
-  }
+  const int img = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;        // thread = channel: a wave reads 64 consecutive halves per row
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < hw; ++r) s += split_load<32>(X, (size_t)img * hw + r, c, C);
+  Y[(size_t)img * C + c] = s / (float)hw;
 }
 
 }  // namespace
@@ -629,7 +628,7 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
 
 extern "C" int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, void* stream) {
   EHM_CHECK_ARG(X && Y && groups > 0 && rows_per_group > 0 && C > 0 && C % 32 == 0);
-  hipLaunchKernelGGL(x2_group_mean_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, (const half_t*)X, Y, rows_per_group, C);
+  hipLaunchKernelGGL(x2_group_mean_kernel, dim3((unsigned)groups, (unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X, Y, rows_per_group, C);
   EHM_LAUNCH_CHECK();
   return 0;
 }

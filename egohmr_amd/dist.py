@@ -91,10 +91,17 @@ def agree_schedule(fused_sampler, diffusion, batch, ddim=False, guided=False, co
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     info = None
     if not multi or dist.get_rank() == 0:
-        info = fused_sampler.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, denom_items=B, **kw)
+        try:
+            info = fused_sampler.calibrate_schedule(diffusion, batch, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, denom_items=B, **kw)
+        except Exception as e:                      # the other ranks are waiting in the broadcast below: tell them instead of leaving them there
+            if not multi:
+                raise
+            info = {"error": f"{type(e).__name__}: {e}"}
     if multi:
         box = [info]
         dist.broadcast_object_list(box, src=0)
         info = box[0]
+        if "error" in info:
+            raise RuntimeError(f"agree_schedule: rank 0's calibration failed: {info['error']}")
         fused_sampler.install_schedule(diffusion, info, ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, denom_items=B)
     return info

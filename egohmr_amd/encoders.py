@@ -16,6 +16,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# measurement hook (tools/exp_encoder_precision.py): called with every X2 activation buffer an encoder kernel has just written, (buffer, channels).
+# None on the product path.
+_x2_debug_hook = None
+
+
 class _Bottleneck(nn.Module):
     def __init__(self, cin, width, stride, project):
         super().__init__()
@@ -132,6 +137,8 @@ class ResNet50Features(nn.Module):
             y = x2_buffer(N * (H // 4) * (W // 4), 64, x.device, clear_last=True) if x2 else torch.empty(N, H // 4, W // 4, 64, device=x.device)
             _lib.check(lib.ehm_resnet_stem(x.data_ptr(), stem_wt.data_ptr(), stem_b.data_ptr(), scratch.data_ptr(), y.data_ptr(), N, H, W,
                                            1 if x2 else 0, _lib.stream_ptr()), "ehm_resnet_stem")
+            if x2 and _x2_debug_hook is not None:
+                _x2_debug_hook(y, 64)
             return y
 
         def conv_x2(x, shape, p, res=None, relu=True):
@@ -143,6 +150,8 @@ class ResNet50Features(nn.Module):
             d = _lib.ConvX2Desc(x.data_ptr(), x.shape[0], buf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
                                 N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale)
             _lib.check(_lib.lib().ehm_conv_x2(C.byref(d), _lib.stream_ptr()), "ehm_conv_x2")
+            if _x2_debug_hook is not None:
+                _x2_debug_hook(y, Co)
             return y, (N, Ho, Wo)
 
         def run_x2(x):
@@ -278,6 +287,8 @@ class ResnetPointnet(nn.Module):
                                 M=M, N=H, K0=K0, K1=K1, rows_per_group=Np, valid_rows_per_group=N, relu_in0=int(relu_in0),
                                 relu_out=int(relu_out), w_scale=W[1])
             _lib.check(L.ehm_linear_split(d, st), "ehm_linear_split")
+            if Y is not None and _x2_debug_hook is not None:
+                _x2_debug_hook(Y, H)
 
         def small(x, Wt, bias):
             """[B,K] x [K,N] (+ bias) in exact float32: the per-body vectors between the big GEMMs.  The BLAS ran each of these

@@ -118,6 +118,7 @@ class FusedSampler:
             except Exception:
                 pass
             self._gcn = None
+            self._nl_set = None          # a new handle may reuse the freed one's address: the non-local block must be installed again
 
     def __del__(self):
         self._free()
@@ -140,7 +141,7 @@ class FusedSampler:
             return self._prepare_on_device(batch)
 
     def _prepare_on_device(self, batch) -> _Prepared:
-        m = self.model
+        m, L = self.model, _lib.lib()
         # Cache key = identity AND version of every tensor the conditioning is computed from, and of every weight it passes
         # through.  The cached entry keeps strong references to those input tensors, so neither their id() nor their storage can be
         # recycled for a different batch while the entry is alive; in-place edits bump _version.
@@ -160,24 +161,44 @@ class FusedSampler:
             scene = scene - transl.unsqueeze(1)                                        # :211
         scene = scene.contiguous()
         img = g("img")
-        # pass pruning map (ehm_gcn_set_pass_map): items with an invisible joint need the second pass.  Its count is the ONE host
-        # read-back of a batch.  It is REQUESTED first (fixed-size device ops + an asynchronous copy into pinned memory + an event) and
-        # LOOKED AT after the encoders have been enqueued: in a pipeline of batches the copy sits behind the previous batch's sampling
-        # loop, the host spends that time enqueuing this batch's encoders, and when the event fires the GPU walks straight into them
-        # while the host enqueues the loop - the GPU never waits for Python.  (Read back at the end of prepare() with a blocking
-        # nonzero(), the GPU idled while Python built the step table: -6 %; read back with a blocking nonzero() at the top, it idled
-        # ~0.5 ms per batch until the first encoder kernels arrived: same-box A/B 3493 / 3505 -> 3504 / 3506 bodies/s, DDIM-10 +1-3 %.)
-        vis = m.visibility({"orig_keypoints_2d": batch["orig_keypoints_2d"].to(dev)})
-        need = ~vis.all(dim=1)
-        order = torch.argsort((~need).to(torch.uint8), stable=True).to(torch.int32)        # items that need the second pass first, ascending
-        mask_slot = torch.where(need, torch.cumsum(need.to(torch.int32), 0) - 1, torch.full_like(need, -1, dtype=torch.int32)).to(torch.int32).contiguous()
+        B, f, st = img.shape[0], self._folded, _lib.stream_ptr()
+        # ---- per-item scalars in two launches (csrc/prep.hip): joint visibility (:186-188), the pass-pruning map (ehm_gcn_set_pass_map: items
+        # with an invisible joint need the second pass), TranslEnc (:217) and the camera features (:195-205) written straight into the padded
+        # [scene | transl | cam] operand of the projections, and the per-item "inputs are finite" flag.  The reference's float32 graph carries a
+        # NaN / Inf of an item's inputs into every output of THAT item (ReLU and max-pool propagate NaN in torch); the kernels' v_max /
+        # saturating conversions would swallow it, so the flag travels beside the data (ehm_pack_outputs).  A row sum is non-finite exactly
+        # when the row holds a NaN / Inf - or finite values whose float32 sum overflows, which no image or point cloud in metres does.
+        # The count of second passes is the ONE host read-back of a batch.  It is REQUESTED here (an asynchronous copy into pinned memory +
+        # an event) and LOOKED AT after the encoders have been enqueued: in a pipeline of batches the copy sits behind the previous batch's
+        # sampling loop, the host spends that time enqueuing this batch's encoders, and the GPU never waits for Python.
+        kp = g("orig_keypoints_2d")
+        fx, cx, cy, bc, bs = g("fx"), g("cam_cx"), g("cam_cy"), g("box_center"), g("box_size")
+        te = m.transl_enc.layers
+        tw = [_lib.f32(te[0].weight, dev), _lib.f32(te[0].bias, dev), _lib.f32(te[2].weight, dev), _lib.f32(te[2].bias, dev)]
+        n_scene, n_tr = m.scene_enc.fc_c.out_features, te[2].out_features
+        n_other = n_scene + n_tr + 1 + (3 if m.with_bbox_info else 0) + (2 if m.with_cam_center else 0)
+        jm = getattr(self, "_joint_map", None)
+        if jm is None or jm[0] != (tuple(m.openpose_to_smpl), str(dev)):
+            jm = self._joint_map = ((tuple(m.openpose_to_smpl), str(dev)), torch.tensor(m.openpose_to_smpl, dtype=torch.int32, device=dev))
+        oth = torch.empty(B, f.k_oth, device=dev)
+        vis = torch.empty(B, 24, dtype=torch.uint8, device=dev)
+        flags = torch.empty(2, B, dtype=torch.uint8, device=dev)                       # finite | need (scratch)
+        maps = torch.empty(2 * B + 1, dtype=torch.int32, device=dev)                   # mask_slot | mask_items | count
+        sums = (img.reshape(B, -1).sum(dim=1), scene.reshape(B, -1).sum(dim=1))
+        d = _lib.ItemPrepDesc(keypoints_2d=kp.data_ptr(), joint_map=jm[1].data_ptr(), NK=kp.shape[1], force_visible=8, fx=fx.data_ptr(), cx=cx.data_ptr(),
+                              cy=cy.data_ptr(), box_center=bc.data_ptr(), box_size=bs.data_ptr(), transl=transl.data_ptr(), fx_norm=m.cfg.CAM.FX_NORM_COEFF,
+                              with_bbox=int(m.with_bbox_info), with_cam_center=int(m.with_cam_center), tW1=tw[0].data_ptr(), tb1=tw[1].data_ptr(),
+                              tW2=tw[2].data_ptr(), tb2=tw[3].data_ptr(), t_hidden=te[0].out_features, t_out=n_tr, img_rowsum=sums[0].data_ptr(),
+                              scene_rowsum=sums[1].data_ptr(), other=oth.data_ptr(), other_ld=f.k_oth, other_col0=n_scene, vis=vis.data_ptr(),
+                              mask_slot=maps.data_ptr(), mask_items=maps[B:].data_ptr(), count=maps[2 * B:].data_ptr(), finite=flags.data_ptr(),
+                              need_scratch=flags[1].data_ptr(), pass_group=int(getattr(m, "pass_group", 1)), B=B)
+        _lib.check(L.ehm_item_prep(C.byref(d), st), "ehm_item_prep")
         if getattr(self, "_count_host", None) is None:
             self._count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._count_host.copy_(need.sum(dtype=torch.int32).reshape(1), non_blocking=True)
+        self._count_host.copy_(maps[2 * B:], non_blocking=True)
         count_ready = torch.cuda.Event()
         count_ready.record(torch.cuda.current_stream(dev))
-        # The two encoders are independent, and complementary on the chip: ResNet-50's early layers stream 0.8 GB float32 activations
-        # per conv (HBM-bound, matrix cores idle), the PointNet's GEMMs are matrix-core bound.  Run them on two HIP streams.
+        # The two encoders are independent; on two HIP streams the PointNet's matrix-bound GEMMs run beside ResNet-50's HBM-bound early layers.
         if m.overlap_encoders:
             cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
@@ -193,74 +214,57 @@ class FusedSampler:
         else:
             img_feats = self._backbone_fn()(img)
             scene_feats = m.scene_enc(scene)
-        transl_feat = m.transl_enc(transl)                                             # :217
-        fx, cx, cy = g("fx"), g("cam_cx"), g("cam_cy")
-        ofx = fx * m.cfg.CAM.FX_NORM_COEFF
-        bc, bs = g("box_center"), g("box_size")
-        cam = [fx.unsqueeze(1)]                                                        # :195-205 (prepended in this order)
-        if m.with_bbox_info:
-            cam = [torch.stack([bc[:, 0] / ofx, bc[:, 1] / ofx, bs / ofx], -1)] + cam
-        if m.with_cam_center:
-            cam = [torch.stack([cx / ofx, cy / ofx], -1)] + cam
-        cam = torch.cat(cam, dim=1)
-        other = torch.cat([scene_feats, transl_feat, cam], dim=1)                      # :220-221
-        f = self._folded
-        h_img, h_oth, betas = self._project(img_feats.contiguous(), other)
-        # The reference's float32 graph carries a NaN / Inf of an item's inputs into every output of THAT item (ReLU and max-pool propagate NaN
-        # in torch); the kernels' v_max / saturating conversions would swallow it.  One flag per item, applied to the outputs (_pack_output).
-        # (a row sum is non-finite exactly when the row holds a NaN / Inf - or finite values whose float32 sum overflows, which no image or
-        # point cloud in metres does: one read of the tensor, no 38 M-element temporary)
-        rows_ok = lambda t: torch.isfinite(t.reshape(t.shape[0], -1).sum(dim=1))
-        finite = rows_ok(img) & rows_ok(scene) & rows_ok(transl) & torch.isfinite(fx)
-        if m.with_bbox_info:
-            finite = finite & rows_ok(bc) & torch.isfinite(bs)
-        if m.with_cam_center:
-            finite = finite & torch.isfinite(cx) & torch.isfinite(cy)
+        oth[:, :n_scene].copy_(scene_feats)                                            # :220-221 [scene | transl | cam] (the rest was written by ehm_item_prep)
+        h_img, h_oth, betas = self._project(img_feats.contiguous(), oth, n_other)
         count_ready.synchronize()
         num_masked = int(self._count_host[0])
-        mask_items = order[:num_masked].contiguous()
-        self._prep = _Prepared(B=img_feats.shape[0], h_img=h_img, h_oth=h_oth, vis=vis.to(torch.uint8).contiguous(), vis_bool=vis,
+        mask_slot, mask_items = maps[:B], maps[B:B + num_masked]
+        self._prep = _Prepared(B=B, h_img=h_img, h_oth=h_oth, vis=vis, vis_bool=vis.view(torch.bool),
                                betas=betas, scene=scene, transl=transl, fx=fx, cam_cx=cx, cam_cy=cy, img_feats=img_feats,
-                               scene_feats=scene_feats, finite=finite)
+                               scene_feats=scene_feats, finite=flags[0].view(torch.bool))
         self._prep.inputs = ins                  # strong references (see the key above)
         self._prep.mask_items, self._prep.mask_slot, self._prep.num_masked = mask_items, mask_slot, num_masked
         self._prep_key = key
         return self._prep
 
-    def _project(self, img_feats, other):
+    def _project(self, img_feats, oth, n_other):
         """The step-invariant slices of the input graph conv ([B,2,hid] each: image features, scene + translation + camera features)
-        and the beta head (egohmr.py:263-265) as exact-float32 matrix-core GEMMs built for M = B rows (ehm_skinny_gemm_f32)."""
+        and the beta head (egohmr.py:263-265, Linear -> ReLU -> Linear + init_betas) as exact-float32 matrix-core GEMMs built for M = B
+        rows (ehm_skinny_gemm_f32).  oth = [scene | transl | cam] zero-padded to a multiple of 32 columns, n_other of them live."""
         m, f, L = self.model, self._folded, _lib.lib()
         B, dev, hid = img_feats.shape[0], img_feats.device, m.diffusion_model.hid_dim
         st = _lib.stream_ptr()
-        if img_feats.shape[1] % 32:
-            raise _lib.EgoHMRHipError(f"image feature width {img_feats.shape[1]} is not a multiple of 32")
-        oth = torch.zeros(B, f.k_oth, device=dev)
-        oth[:, :other.shape[1]] = other
+        a = img_feats.shape[1]
+        l1, l2 = m.beta_layer.layers[0], m.beta_layer.layers[2]
+        if a % 32 or l1.out_features % 32 or l1.in_features != a + n_other or l2.out_features > 32:
+            raise _lib.EgoHMRHipError(f"conditioning widths the projection kernels are not built for: image features {a}, beta head "
+                                      f"{l1.in_features} -> {l1.out_features} -> {l2.out_features}, other features {n_other}")
         h_img = torch.empty(B, 2, hid, device=dev)
         h_oth = torch.empty(B, 2, hid, device=dev)
-        _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(img_feats), _lib.ptr(f.W_img_cat), None, _lib.ptr(h_img), B, img_feats.shape[1], 2 * hid, 0, st), "ehm_skinny_gemm_f32")
+        _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(img_feats), _lib.ptr(f.W_img_cat), None, _lib.ptr(h_img), B, a, 2 * hid, 0, st), "ehm_skinny_gemm_f32")
         _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(oth), _lib.ptr(f.W_oth_cat), None, _lib.ptr(h_oth), B, f.k_oth, 2 * hid, 0, st), "ehm_skinny_gemm_f32")
-        # beta head: Linear(2048 + 646 -> 1024) + ReLU on the same kernel (weights transposed and padded once per weight version), the
-        # 1024 -> 10 layer and init_betas in torch
-        l1, l2 = m.beta_layer.layers[0], m.beta_layer.layers[2]
-        key = (l1.weight.data_ptr(), l1.weight._version, l1.bias.data_ptr(), l1.bias._version, str(dev))
+        # beta head: both layers on the same kernel (weights transposed and zero-padded once per weight version; init_betas folded into
+        # the second bias)
+        ib = m.beta_layer.init_betas
+        key = tuple((t.data_ptr(), t._version) for t in (l1.weight, l1.bias, l2.weight, l2.bias, ib)) + (str(dev),)
         if getattr(self, "_beta_key", None) != key:
-            a = img_feats.shape[1]
             Wt = torch.zeros(a + f.k_oth, l1.out_features, device=dev)
             w = l1.weight.detach().float().to(dev)
             Wt[:a] = w[:, :a].t()
-            Wt[a:a + other.shape[1]] = w[:, a:].t()
-            self._beta_w1, self._beta_b1, self._beta_key = Wt.contiguous(), l1.bias.detach().float().to(dev).contiguous(), key
-        if l1.out_features % 32 == 0 and l1.in_features == img_feats.shape[1] + other.shape[1]:
-            xb = torch.cat([img_feats, oth], dim=1)
-            hb = torch.empty(B, l1.out_features, device=dev)
-            _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(xb), _lib.ptr(self._beta_w1), _lib.ptr(self._beta_b1), _lib.ptr(hb), B, xb.shape[1], l1.out_features, 1, st),
-                       "ehm_skinny_gemm_f32")
-            betas = (l2(hb) + m.beta_layer.init_betas).contiguous()
-        else:
-            betas = m.beta_layer(torch.cat([img_feats, other], dim=1)).contiguous()
-        return h_img, h_oth, betas
+            Wt[a:a + n_other] = w[:, a:].t()
+            W2 = torch.zeros(l1.out_features, 32, device=dev)
+            W2[:, :l2.out_features] = l2.weight.detach().float().to(dev).t()
+            b2 = torch.zeros(32, device=dev)
+            b2[:l2.out_features] = (l2.bias.detach().float().to(dev) + ib.detach().float().to(dev).reshape(-1))
+            self._beta_w = (Wt.contiguous(), l1.bias.detach().float().to(dev).contiguous(), W2.contiguous(), b2)
+            self._beta_key = key
+        W1, b1, W2, b2 = self._beta_w
+        xb = torch.cat([img_feats, oth], dim=1)
+        hb = torch.empty(B, l1.out_features, device=dev)
+        _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(xb), _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(hb), B, xb.shape[1], l1.out_features, 1, st), "ehm_skinny_gemm_f32")
+        b32 = torch.empty(B, 32, device=dev)
+        _lib.check(L.ehm_skinny_gemm_f32(_lib.ptr(hb), _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(b32), B, l1.out_features, 32, 0, st), "ehm_skinny_gemm_f32")
+        return h_img, h_oth, b32[:, :l2.out_features].contiguous()
 
     def _cond_param_key(self):
         m = self.model
@@ -286,14 +290,38 @@ class FusedSampler:
             self._pk = self._ck = self._bbk = None
 
     @torch.no_grad()
-    def timestep_vectors(self, t_orig: torch.Tensor) -> torch.Tensor:
+    def timestep_vectors(self, t_orig) -> torch.Tensor:
         """[n] original timesteps -> [n,2,hid]: TimestepEmbedder (egohmr.py:642-643) pushed through the timestep
-        slice of the input conv, plus the folded InputProcess bias."""
+        slice of the input conv, plus the folded InputProcess bias.  A python sequence of ints (the sampler's timestep map) is cached per
+        (weights, sequence): the embedding MLP and its float64 projection ran again on every sampling call."""
         m = self.model
         self.gcn()
+        ckey = None
+        if not torch.is_tensor(t_orig):
+            ckey = (self._param_key(), self._cond_param_key(), tuple(int(t) for t in t_orig))
+            hit = getattr(self, "_tv_cache", None)
+            if hit is not None and hit[0] == ckey:
+                return hit[1]
+            t_orig = torch.tensor(ckey[2], device=m.device, dtype=torch.long)
         temb = m.embed_timestep.time_embed(m.sequence_pos_encoder.pe[t_orig][:, 0])    # [n,512]
         tv = torch.einsum("ne,kef->nkf", temb.double(), self._folded.W_t) + self._folded.bx[None]
-        return tv.float().contiguous()
+        tv = tv.float().contiguous()
+        if ckey is not None:
+            self._tv_cache = (ckey, tv)
+        return tv
+
+    @staticmethod
+    def step_table(diffusion, ddim, cond_grad_weight, guided):
+        """The T ehm_step_coefs rows of a loop (newest first = execution order), cached on the diffusion object: every row costs a handful of
+        float32 CPU tensor ops (GaussianDiffusion.step_coefs keeps torch's roundings), 100 rows ~ 3 ms of host time per call."""
+        cache = diffusion.__dict__.setdefault("_ehm_step_tables", {})
+        key = (bool(ddim), float(cond_grad_weight), bool(guided))
+        if key not in cache:
+            T = diffusion.num_timesteps
+            rows = [diffusion.step_coefs(i, ddim, 0.0, cond_grad_weight, guided) for i in range(T - 1, -1, -1)]
+            first_guided = next((i for i, r in enumerate(rows) if r.grad_scale != 0.0), T)
+            cache[key] = ((_lib.StepCoefs * T)(*rows), first_guided)
+        return cache[key]
 
     # ------------------------------------------------------------------ granular denoiser (EgoHMR.forward)
     def _workspace(self, nbytes, device):
@@ -421,10 +449,12 @@ class FusedSampler:
     # ------------------------------------------------------------------ precision schedule: calibrated per checkpoint
     def schedule_key(self, diffusion, ddim: bool, n_guided: int, cond_grad_weight: float = 0.0, guide_denom: float = 1.0):
         """What a calibrated k is valid for: these denoiser / embedder weights (identity + version of every tensor), this sampler
-        (original timesteps visited, ancestral or DDIM), this guidance window and reduction, this tolerance."""
+        (original timesteps visited, ancestral or DDIM), this guidance window, weight and reduction, this tolerance.  The batch size behind a
+        `-loss.mean()` (guide_denom) is NOT part of the key: a ragged last batch, or ranks with different shard sizes, must find the job's one
+        calibration (the f16 steps end >= 8 steps before the guided window whatever its strength)."""
         m = self.model
         return (self._param_key(), self._cond_param_key(), tuple(diffusion.timestep_map), int(getattr(diffusion, "original_num_steps", diffusion.num_timesteps)),
-                bool(ddim), int(n_guided), float(cond_grad_weight) / float(guide_denom) if n_guided else 0.0, bool(m.guide_all_points) if n_guided else False,
+                bool(ddim), int(n_guided), (float(cond_grad_weight), str(m.guide_reduction)) if n_guided else None, bool(m.guide_all_points) if n_guided else False,
                 bool(m.diffuse_fuse),
                 float(m.schedule_tol))
 
@@ -518,7 +548,14 @@ class FusedSampler:
             m.schedule_tol = old_tol
         if not force and key in self._sched_cache:
             return self._sched_cache[key]
-        st = self._subset(st_full, min(int(bodies), st_full.B))
+        # always `bodies` bodies: the finite items of the batch, replicated by index when there are fewer (each copy gets its own noise), so
+        # that a first call with B = 2 does not fix k from two bodies for every later batch; items with non-finite inputs are left out (they
+        # would turn every trial distance into NaN and cache k = T)
+        good = torch.nonzero(st_full.finite).reshape(-1)
+        if good.numel() == 0:
+            return {"k": int(T), "T": int(T), "f16_steps": 0, "tol_m": tol, "criterion": "no item with finite inputs in the batch: not calibrated, not cached",
+                    "bodies": 0, "ddim": bool(ddim), "guided_steps": int(n_guided), "trials": []}
+        st = self._subset(st_full, good[torch.arange(int(bodies), device=good.device) % good.numel()])
         nb, dev = st.B, m.device
         sub_batch = dict(batch) if batch is not None else {}
 
@@ -654,12 +691,10 @@ class FusedSampler:
         B, T, hid, V = st.B, diffusion.num_timesteps, m.diffusion_model.hid_dim, m.smpl.num_verts
         noise = _lib.f32(noise_stack, m.device)
         assert noise.shape[0] >= T + 1 and noise.shape[1] == B and noise.shape[2] == 144, noise.shape
-        steps = (_lib.StepCoefs * T)(*[diffusion.step_coefs(i, ddim, 0.0, cond_grad_weight, guided) for i in range(T - 1, -1, -1)])
-        any_guided = any(s.grad_scale != 0.0 for s in steps)
-        first_guided = next((i for i, s in enumerate(steps) if s.grad_scale != 0.0), T)
+        steps, first_guided = self.step_table(diffusion, ddim, cond_grad_weight, guided)
+        any_guided = first_guided < T
         n_guided = T - first_guided                       # (the reference guides a contiguous tail: t < 10, gaussian_diffusion.py:378-385)
-        tmap = torch.tensor([diffusion.timestep_map[i] for i in range(T - 1, -1, -1)], device=m.device, dtype=torch.long)
-        tvecs = self.timestep_vectors(tmap)                                            # [T,2,hid]
+        tvecs = self.timestep_vectors([diffusion.timestep_map[i] for i in range(T - 1, -1, -1)])   # [T,2,hid]
         passes = 2 if m.diffuse_fuse else 1
         # precision schedule: an explicit `lowprec` (calibration runs), else EgoHMR.f16x3_last_steps; 'auto' = the k calibrated for THESE
         # weights and THIS sampler - measured now, on this batch's first items, when it is not cached yet (auto_calibrate) - or no f16 step
@@ -742,14 +777,11 @@ class FusedSampler:
         x_final, x0, verts, joints, R, pose6d = o.x_final, o.x0, o.verts, o.joints, o.R, o.pose6d
         # non-finite noise: x_T or a step's draw poisons the item from the next denoiser evaluation on; the LAST step's draw is multiplied by
         # nonzero_mask = 0 (DDIM: by sigma = 0 too) and 0 * NaN = NaN lands in that element of `sample` only (gaussian_diffusion.py:357-359, :575-580)
-        st_out = _Prepared(**vars(st))
-        st_out.finite = st.finite & torch.isfinite(noise[:T]).all(dim=2).all(dim=0)
-        x_final.masked_fill_(~st_out.finite[:, None] | ~torch.isfinite(noise[T]), float("nan"))
         self.last_trace = tr
         if tr is not None:
             batch["x_t"] = tr[-1]
         batch["vis_mask_smpl"] = st.vis_bool
-        out = m._pack_output(batch, st_out, x0, pose6d, R, verts, joints)
+        out = m._pack_output(batch, st, x0, pose6d, R, verts, joints, chk=noise, chk_rows=T, last_noise=noise[T], x_final=x_final)
         # a chained launch that gave up on a producer wait (GPU shared / preempted) flags the handle instead of hanging: one read-back
         # per sampling call (the call's only host wait, after everything has been enqueued) turns that into an exception rather than
         # silently wrong bodies

@@ -207,6 +207,7 @@ class EgoHMR(nn.Module):
         self.guide_denom_override = None       # sharded / sub-batch runs: the GLOBAL batch size of `-loss.mean()`, else None
         self.guide_all_points = False          # COAP variant: bbox-selected scene points (egohmr.py:550-552); True = all points (egohmr_volsmpl.py:609-612)
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        self.pass_group = 1                # second passes pruned per item (1) or per group of this many consecutive items (FusedSampler.prepare)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)
         self.overlap_encoders = True       # ResNet-50 and the scene PointNet on two HIP streams (FusedSampler.prepare)
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
@@ -277,33 +278,41 @@ class EgoHMR(nn.Module):
                                                      _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(R), _lib.ptr(pose6d), None, B,
                                                      _lib.stream_ptr()), "ehm_smpl_forward_rot6d")
         batch["vis_mask_smpl"] = st.vis_bool
-        st_out = type(st)(**vars(st))
-        st_out.finite = st.finite & torch.isfinite(x_t).all(dim=1)
-        return self._pack_output(batch, st_out, x0, pose6d, R, verts, joints)
+        return self._pack_output(batch, st, x0, pose6d, R, verts, joints, chk=x_t.contiguous(), chk_rows=1)
 
-    def _pack_output(self, batch, st, x0, pose6d, R, verts, joints):
-        # items with a NaN / Inf in their inputs come out as NaN, like the reference's float32 graph gives them (FusedSampler.prepare)
-        bad = ~st.finite
-        nan = float("nan")
-        for t in (x0, pose6d, R, verts, joints):
-            t.masked_fill_(bad.reshape(-1, *([1] * (t.dim() - 1))), nan)
-        betas = st.betas.masked_fill(bad[:, None], nan)
+    def _pack_output(self, batch, st, x0, pose6d, R, verts, joints, chk=None, chk_rows=0, last_noise=None, x_final=None):
+        """The output dict of EgoHMR.forward (egohmr.py:283-303) in one launch (ehm_pack_outputs): items with a NaN / Inf in their inputs
+        (st.finite) or in a row of `chk` come out as NaN, like the reference's float32 graph gives them."""
+        import ctypes as C
+        B, J, dev = x0.shape[0], joints.shape[1], x0.device
+        buf = torch.empty(B * (10 + 216 + 5 * J + 4), device=dev)
+        cuts, off = [], 0
+        for n in (10, 9, 207, 3 * J, 2 * J, 2, 2):
+            cuts.append(buf[off:off + B * n].view(B, n))
+            off += B * n
+        betas, go, bp, kp3d, kp2d, focal, center = cuts
+        d = _lib.PackDesc(B=B, J=J, V=verts.shape[1], finite=st.finite.data_ptr(), chk=chk.data_ptr() if chk is not None else None, chk_rows=int(chk_rows),
+                          last_noise=last_noise.data_ptr() if last_noise is not None else None, x_final=x_final.data_ptr() if x_final is not None else None,
+                          x0=x0.data_ptr(), pose6d=pose6d.data_ptr(), R=R.data_ptr(), verts=verts.data_ptr(), joints=joints.data_ptr(),
+                          betas_in=st.betas.data_ptr(), betas_out=betas.data_ptr(), transl=st.transl.data_ptr(), fx=st.fx.data_ptr(), cx=st.cam_cx.data_ptr(),
+                          cy=st.cam_cy.data_ptr(), fx_norm=self.cfg.CAM.FX_NORM_COEFF, global_orient=go.data_ptr(), body_pose=bp.data_ptr(),
+                          kp3d_full=kp3d.data_ptr(), kp2d_full=kp2d.data_ptr(), focal=focal.data_ptr(), center=center.data_ptr(), finite_out=None)
+        for t in (x0, pose6d, R, verts, joints, st.betas, st.transl, st.fx, st.cam_cx, st.cam_cy, st.finite):
+            assert t.is_contiguous()
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ehm_pack_outputs(C.byref(d), _lib.stream_ptr()), "ehm_pack_outputs")
         self.scene_pcd_verts = st.scene
         self.input_transl = st.transl
         self.smpl_output = smpl_mod.SMPLOutput(vertices=verts, joints=joints, full_pose=R)
-        focal = st.fx.unsqueeze(-1).repeat(1, 2) * self.cfg.CAM.FX_NORM_COEFF          # :283-285
-        center = torch.stack([st.cam_cx, st.cam_cy], dim=-1)
-        self.focal_length, self.camera_center_full = focal, center
-        kp2d = geometry.perspective_projection(joints, st.transl, focal, center)        # :295-298
-        kp2d = torch.stack([kp2d[..., 0] / 1920 - 0.5, kp2d[..., 1] / 1080 - 0.5], dim=-1)
+        self.focal_length, self.camera_center_full = focal, center                     # :283-285
         return {
             "pred_x_start": x0,
-            "pred_smpl_params": {"global_orient": R[:, [0]].clone(), "body_pose": R[:, 1:].clone(), "betas": betas},
+            "pred_smpl_params": {"global_orient": go.view(B, 1, 3, 3), "body_pose": bp.view(B, 23, 3, 3), "betas": betas},
             "pred_pose_6d": pose6d,
             "pred_keypoints_3d": joints,
             "pred_vertices": verts,
-            "pred_keypoints_3d_full": joints + st.transl.unsqueeze(1),
-            "pred_keypoints_2d_full": kp2d,
+            "pred_keypoints_3d_full": kp3d.view(B, J, 3),
+            "pred_keypoints_2d_full": kp2d.view(B, J, 2),                              # :295-301
         }
 
     def guide_coll(self, batch, output, t, compute_grad="x_t"):

@@ -317,6 +317,62 @@ int ehm_guidance_grad_finish(const float* gpose6d, const float* loss, float* gra
  * x [B,P1,3], y [B,P2,3] -> dist2 [B,P1], idx [B,P1] int32 or NULL. */
 int ehm_nn_dist2(const float* x, const float* y, float* dist2, int32_t* idx, int B, int P1, int P2, void* stream);
 
+/* ------------------------------------------------------------------ per-item scalars ---------- */
+/* The per-item scalar work of EgoHMR.forward in front of the encoders, in two launches:
+ *   vis [B,24] u8       models/egohmr/egohmr.py:186-188: confidence > 0, OpenPose joint `force_visible` (8) always on, gathered by joint_map
+ *   mask_slot [B], mask_items [count], count [1] (int32)   which items need the image-masked second pass (:249-254: any invisible
+ *                       joint), as ehm_gcn_set_pass_map wants them: slot of the item among those that do (ascending) or -1, and the
+ *                       items in slot order.  pass_group > 1 rounds the need up to groups of pass_group consecutive items.
+ *   other[:, other_col0 ...] = TranslEnc(transl) (:217, Linear(3,t_hidden) -> ReLU -> Linear(t_hidden,t_out), torch [out,in] weights)
+ *                       | camera features (:195-205: [cx, cy] / (fx*fx_norm), [box_center, box_size] / (fx*fx_norm), fx), zero-filled
+ *                       up to other_ld (row stride of `other`; columns [0, other_col0) are the caller's: the scene features)
+ *   finite [B] u8       0 when transl / fx / cx / cy / box / img_rowsum / scene_rowsum of the item hold a NaN or Inf (the float32
+ *                       graph of the reference turns every output of such an item into NaN; see ehm_pack_outputs)
+ * need_scratch: B bytes of device memory. */
+typedef struct ehm_item_prep_desc {
+  const float* keypoints_2d; /* [B, NK, 3] */
+  const int32_t* joint_map;  /* [24] device */
+  int NK, force_visible;
+  const float *fx, *cx, *cy, *box_center, *box_size, *transl; /* [B], [B], [B], [B,2], [B], [B,3]; cx/cy/box may be NULL when unused */
+  float fx_norm;
+  int with_bbox, with_cam_center;
+  const float *tW1, *tb1, *tW2, *tb2;
+  int t_hidden, t_out;
+  const float *img_rowsum, *scene_rowsum; /* [B] or NULL */
+  float* other;
+  int other_ld, other_col0;
+  uint8_t* vis;
+  int32_t *mask_slot, *mask_items, *count;
+  uint8_t* finite;
+  uint8_t* need_scratch;
+  int pass_group;
+  int B;
+} ehm_item_prep_desc;
+int ehm_item_prep(const ehm_item_prep_desc* d, void* stream);
+
+/* The output garnish of EgoHMR.forward (egohmr.py:283-301) in one launch, in place on the loop's outputs:
+ *   bad item = !finite[b] or a non-finite value in chk[0..chk_rows)[b] (x_T and the draws that feed a denoiser evaluation, or the
+ *   x_t of a single forward): x0, pose6d, R, verts, joints, betas of a bad item become NaN; x_final (may be NULL) additionally takes
+ *   NaN where last_noise (the last step's draw, multiplied by nonzero_mask = 0: gaussian_diffusion.py:357-359) is not finite.
+ *   global_orient [B,1,3,3] / body_pose [B,23,3,3] = the split of R; focal [B,2] = fx*fx_norm; center [B,2]; kp3d_full [B,J,3] =
+ *   joints + transl; kp2d_full [B,J,2] = utils/geometry.py:78-116 perspective_projection, then x / 1920 - 0.5, y / 1080 - 0.5. */
+typedef struct ehm_pack_desc {
+  int B, J, V;
+  const uint8_t* finite; /* [B] or NULL */
+  const float* chk;      /* [chk_rows, B, 144] or NULL */
+  int chk_rows;
+  const float* last_noise; /* [B,144] or NULL */
+  float* x_final;          /* [B,144] or NULL */
+  float *x0, *pose6d, *R, *verts, *joints;
+  const float* betas_in;
+  float* betas_out;
+  const float *transl, *fx, *cx, *cy;
+  float fx_norm;
+  float *global_orient, *body_pose, *kp3d_full, *kp2d_full, *focal, *center;
+  uint8_t* finite_out; /* [B] or NULL */
+} ehm_pack_desc;
+int ehm_pack_outputs(const ehm_pack_desc* d, void* stream);
+
 /* ------------------------------------------------------------------ whole sampling loop ------- */
 /* One executed step of the loop (host-side table lookup already done, float32 like
  * _extract_into_tensor, gaussian_diffusion.py:794). */

@@ -47,8 +47,9 @@ def test_header_is_plain_c_and_a_c_program_binds_the_library(tmp_path):
         "  if (ehm_gcn_row_tile() != 192) return 2;\n"
         "  if (ehm_sample_workspace_bytes(NULL, 1024, 6890) != -22) return 3;          /* EHM_EINVAL without touching a GPU */\n"
         '  if (strstr(ehm_last_error(), "bad argument") == NULL) return 4;\n'
-        '  printf("%d %s %d %d %d %d %d %d\\n", (int)sizeof d, ehm_target_arch(), (int)sizeof(ehm_gconv_params), (int)sizeof(ehm_linear_desc),\n'
-        "         (int)sizeof(ehm_conv_desc), (int)sizeof(ehm_conv_x2_desc), (int)sizeof(ehm_step_coefs), (int)sizeof(ehm_nonlocal_params));\n"
+        '  printf("%d %s %d %d %d %d %d %d %d %d\\n", (int)sizeof d, ehm_target_arch(), (int)sizeof(ehm_gconv_params), (int)sizeof(ehm_linear_desc),\n'
+        "         (int)sizeof(ehm_conv_desc), (int)sizeof(ehm_conv_x2_desc), (int)sizeof(ehm_step_coefs), (int)sizeof(ehm_nonlocal_params),\n"
+        "         (int)sizeof(ehm_item_prep_desc), (int)sizeof(ehm_pack_desc));\n"
         "  return 0;\n}\n")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
@@ -59,7 +60,8 @@ def test_header_is_plain_c_and_a_c_program_binds_the_library(tmp_path):
     assert out.stdout.split()[1] == "gfx950"
     import ctypes
     f = out.stdout.split()
-    mirrors = [_lib.SampleDesc, None, _lib.GConvParams, _lib.LinearDesc, _lib.ConvDesc, _lib.ConvX2Desc, _lib.StepCoefs, _lib.NonlocalParams]
+    mirrors = [_lib.SampleDesc, None, _lib.GConvParams, _lib.LinearDesc, _lib.ConvDesc, _lib.ConvX2Desc, _lib.StepCoefs, _lib.NonlocalParams,
+               _lib.ItemPrepDesc, _lib.PackDesc]
     for i, cls in enumerate(mirrors):
         if cls is not None:
             assert int(f[i]) == ctypes.sizeof(cls), f"the ctypes mirror {cls.__name__} has drifted from the header ({f[i]} vs {ctypes.sizeof(cls)})"

@@ -113,7 +113,7 @@ class NonlocalParams(C.Structure):
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int), ("loop_engine", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -171,7 +171,7 @@ PROTOTYPES = {
     "ehm_profile_begin": (_I, []),
     "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }
-PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance")   # EHM_PROF_* of the header
+PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "loop_f16x3", "loop_f16")   # EHM_PROF_* of the header
 
 _lib = None
 

@@ -269,7 +269,6 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(GcnInputArgs a) {
 //   gcn_out_dot_kernel   HBM-bound: every activation row is read once (float4); [rows,K] x [K,12] on the exact-f32 MFMA.
 //   gcn_out_mix_kernel   per body: modulated adjacency mix of the [24 x 12] responses, bias, pass selection by visibility.
 // ------------------------------------------------------------------------------------------------
-constexpr int OUT_ROWS_PER_BLOCK = 16;
 
 // [rows, K] x [K, 12] on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32: 16 rows x 16 columns, 12 used).  Block = 16 rows, its 4 waves
 // split K; a wave's lane (row = l&15, q = l>>4) streams float4 X[row][kw + 16 i + 4 q ..+3] - the k order inside an MFMA step is a
@@ -279,69 +278,7 @@ constexpr int OUT_ROWS_PER_BLOCK = 16;
 template <bool HALF_IN>   // HALF_IN: X holds f16 rows (the 'f16' mode's last hidden conv), converted on load
 __global__ __launch_bounds__(256) void gcn_out_dot_kernel(const float* __restrict__ X, OutDev O, float* __restrict__ hs, int64_t rows) {
   __shared__ float part[4][16][16];
-  const int K = O.K, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = lane & 15, q = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK;
-  const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
-  const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: a multiple of 16)
-  // a lane owns 8 consecutive k of every 32-k group (16 bytes of f16 / 32 bytes of float32 per load: the four lanes of a row cover a
-  // 64 / 128-byte segment); MFMA c of the group contracts element c of all lanes, i.e. k = c, 8 + c, 16 + c, 24 + c
-  const float* xr = X + r * K + (size_t)wave * kq + 8 * q;
-  const half_t* xh = (const half_t*)X + r * K + (size_t)wave * kq + 8 * q;
-  const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 8 * q;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: the dependent-accumulator latency (40 cyc) exceeds the issue interval
-#pragma unroll 4
-  for (int k = 0; k + 32 <= kq; k += 32) {
-    float xv[8];
-    if (HALF_IN) {
-      const half8 hv = *(const half8*)(xh + k);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) xv[c] = (float)hv[c];
-    } else {
-      const f32x4 x0 = *(const f32x4*)(xr + k), x1 = *(const f32x4*)(xr + k + 4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { xv[c] = x0[c]; xv[4 + c] = x1[c]; }
-    }
-    f32x4 w0 = *(const f32x4*)(wr + k), w1 = *(const f32x4*)(wr + k + 4);
-    if (row >= 12) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
-#pragma unroll
-    for (int c = 0; c < 4; c += 2) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], w0[c], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], w0[c + 1], acc2, 0, 0, 0);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c += 2) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[4 + c], w1[c], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[5 + c], w1[c + 1], acc2, 0, 0, 0);
-    }
-  }
-  if (kq & 16) {                                                      // hid % 128 != 0: one last 16-k group, four k per lane
-    const int k = kq - 16 - 4 * q;                                    // (undo the 8 q of the pointers: this group's lane stride is 4)
-    f32x4 xv;
-    if (HALF_IN) {
-      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-      const half4_t hv = *(const half4_t*)(xh + k);
-      xv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-    } else {
-      xv = *(const f32x4*)(xr + k);
-    }
-    f32x4 wv = *(const f32x4*)(wr + k);
-    if (row >= 12) wv = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; c += 2) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], wv[c], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], wv[c + 1], acc2, 0, 0, 0);
-    }
-  }
-  acc += acc2;
-  // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-  for (int c = 0; c < 4; ++c) part[wave][4 * q + c][row] = acc[c];
-  __syncthreads();
-  if (tid < 16 * 12) {
-    const int rr = tid / 12, cc = tid % 12;
-    if (r0 + rr < rows) hs[(r0 + rr) * 12 + cc] = (part[0][rr][cc] + part[1][rr][cc]) + (part[2][rr][cc] + part[3][rr][cc]);
-  }
+  gcn_out_dot_rows16<HALF_IN, 0>(X, O, hs, (int64_t)blockIdx.x * OUT_ROWS_PER_BLOCK, rows, part, (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(192) void gcn_out_mix_kernel(const float* __restrict__ hs, OutDev O, const uint8_t* __restrict__ vis,
@@ -495,12 +432,14 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
         hipMemcpyAsync(g->hidden_dev, g->hidden, sizeof(LayerDev) * num_hidden, hipMemcpyHostToDevice, st) != hipSuccess)
       rc = EHM_ENOMEM;
   }
+  if (rc == 0 && hipMalloc(&g->loop_extra, EHM_LOOP_EXTRA_BYTES) != hipSuccess) rc = EHM_ENOMEM;
   if (rc == 0 && (hipMalloc(&g->chain_sticky, 64) != hipSuccess || hipMemsetAsync(g->chain_sticky, 0, 64, st) != hipSuccess)) rc = EHM_ENOMEM;
   if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
   if (rc == 0) rc = ehm_gcn_reserve_rows(g, 2 * 256 * kJ);   // the benchmark shape; larger batches grow it on first use (ehm_gcn_reserve)
   if (rc != 0) {
     if (g->hidden_dev) (void)hipFree(g->hidden_dev);
     if (g->chain_sticky) (void)hipFree(g->chain_sticky);
+    if (g->loop_extra) (void)hipFree(g->loop_extra);
     if (g->chain_sync) (void)hipFree(g->chain_sync);
     if (g->hs) (void)hipFree(g->hs);
     (void)hipFree(g->arena);
@@ -519,6 +458,7 @@ extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
   if (h->hidden_dev) (void)hipFree(h->hidden_dev);
   if (h->chain_sync) (void)hipFree(h->chain_sync);
   if (h->chain_sticky) (void)hipFree(h->chain_sticky);
+  if (h->loop_extra) (void)hipFree(h->loop_extra);
   delete h;
 }
 
@@ -616,7 +556,7 @@ extern "C" int ehm_gcn_stack_status_async(ehm_gcn* h, uint32_t* host_flag, void*
 
 int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad) {
   if (rows_pad <= h->reserved_rows) return 0;
-  const size_t need = 8 + (size_t)(h->num_hidden > 0 ? h->num_hidden : 1) * (size_t)ceil_div(rows_pad, BM) + 8;
+  const size_t need = 8 + (size_t)((h->num_hidden > 0 ? h->num_hidden : 1) + 3) * (size_t)ceil_div(rows_pad, BM) + 32;   // (+ 3 x m_tiles: the one-launch loop's INPUT / OUT / BODY counters)
   if (h->chain_sync) EHM_HIP(hipFree(h->chain_sync));
   h->chain_sync = nullptr;
   h->chain_sync_words = 0;
@@ -699,6 +639,7 @@ int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const
 
 int ehm_gcn_hid(const ehm_gcn* h) { return h->hid; }
 int ehm_gcn_num_hidden(const ehm_gcn* h) { return h->num_hidden; }
+int ehm_gcn_chain_enabled(const ehm_gcn* h) { return h->chain != 0 && h->precision != EHM_PREC_F32; }
 
 extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
   EHM_CHECK_ARG(h && (mode == EHM_PREC_F32 || mode == EHM_PREC_F16X3 || mode == EHM_PREC_F16));

@@ -40,6 +40,7 @@ struct OutDev {
 
 
 enum { EHM_PREC_F32 = 0, EHM_PREC_F16X3 = 1, EHM_PREC_F16 = 2 };
+constexpr size_t EHM_LOOP_EXTRA_BYTES = 2048;
 
 struct ehm_gcn {
   int hid = 0;
@@ -64,6 +65,7 @@ struct ehm_gcn {
   float* hs = nullptr;      // [hs_rows,12] responses of the output conv (gcn_out_dot_kernel -> gcn_out_mix_kernel)
   int64_t hs_rows = 0;
   int64_t reserved_rows = 0;   // rows_pad the sync words / hs scratch were sized for (ehm_gcn_reserve)
+  void* loop_extra = nullptr;       // EHM_LOOP_EXTRA_BYTES of device memory: the one-launch loop's per-segment argument block (gcn_tile.hip: LoopExtra)
   ehm_nonlocal_params nonlocal{};   // optional non-local block of the one-call loop (ehm_gcn_set_nonlocal); Ci == 0: none
 };
 
@@ -202,9 +204,11 @@ struct GcnInputArgs {
   int total_vb, ny;          // grid of the standalone launch: total_vb x ny blocks of 256 threads
 };
 
-// One block of the input conv: virtual body `bx`, channels 256 * by .. + 255.  T = 24 * 256 floats of LDS.
+// One block of the input conv: virtual body `bx`, channels 256 * by .. + 255.  T = 24 * 256 floats of LDS.  `tid` = 0..255 (the calling
+// 256 threads; a 512-thread block runs two of these side by side on two T regions), `xb_in` = the body's 144 x_t values when the caller has
+// staged them itself (the one-launch loop reads them with agent-scope loads: another block of the SAME launch wrote them), else nullptr.
 template <int OUT>   // 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows
-__device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const GcnInputArgs& a) {
+__device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by, const GcnInputArgs& a, const float* xb_in) {
   const float* __restrict__ h_img = a.h_img; const float* __restrict__ h_oth = a.h_oth; const uint8_t* __restrict__ vis = a.vis;
   const float* __restrict__ x = a.x; const float* __restrict__ Wx = a.Wx; const float* __restrict__ tvec = a.tvec;
   const LayerDev& L = a.L;
@@ -215,7 +219,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
   const int N = L.N;
   const int vb = bx;                   // virtual body: [0, B) = conditional pass of item vb; B + k = second pass of item mask_items[k] (or k)
   const int p = vb >= B ? 1 : 0, b = p ? (mask_items ? mask_items[vb - B] : vb - B) : vb;
-  const int n_raw = by * 256 + threadIdx.x;
+  const int n_raw = by * 256 + tid;
   const int n = n_raw < N ? n_raw : N - 1;                        // lanes past N recompute the last channel; their stores are dropped
   float base[2], img[2], wx[2][6];
 #pragma unroll
@@ -225,7 +229,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
 #pragma unroll
     for (int c = 0; c < 6; ++c) wx[k][c] = Wx[(k * 6 + c) * N + n];
   }
-  const float* xb = x + (size_t)b * kPoseDim;   // wave-uniform -> scalar loads
+  const float* xb = xb_in ? xb_in : x + (size_t)b * kPoseDim;   // wave-uniform -> scalar loads (standalone launches)
   const uint8_t* vb_ = vis + (size_t)b * kJ;
   float h0[kJ], h1[kJ];
   const float sh = L.shift[n];
@@ -250,7 +254,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
     // channels (P) and upper 32 channels (Q).  6 MFMA + ~100 VALU per wave instead of 576 v_fmac per lane.
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     f32x16 DA, DB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { DA[r] = 0.f; DB[r] = 0.f; }
@@ -291,7 +295,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
 #pragma unroll
       for (int jp = 0; jp < kJ; ++jp) sacc = fmaf(Ac[j * kJ + jp], h1[jp], sacc);
       if (relu) sacc = fmaxf(sacc, 0.f);
-      T[j * 256 + threadIdx.x] = sacc;
+      T[j * 256 + tid] = sacc;
     }
   }
   __syncthreads();
@@ -299,7 +303,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
   const int nb = by * 256;                               // first channel of this block (N % 256 may leave a partial block)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int u = threadIdx.x + 256 * i, j = u >> 5, c8 = (u & 31) * 8;   // (joint, 8 consecutive channels)
+    const int u = tid + 256 * i, j = u >> 5, c8 = (u & 31) * 8;   // (joint, 8 consecutive channels)
     if (nb + c8 >= N) continue;
     const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -326,4 +330,228 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
     }
   }
 }
+template <int OUT>
+__device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const GcnInputArgs& a) {
+  gcn_input_body<OUT>(T, (int)threadIdx.x, bx, by, a, nullptr);
+}
 
+// The same input conv for the 8 virtual bodies vb0 .. vb0 + 7 of ONE row tile, channels 256 * by .. + 255, by 256 threads (an item of the
+// one-launch loop, gcn_tile.hip): the channel's constants (D, M1, Wx, shift, timestep vector) are fetched ONCE, the eight bodies'
+// conditioning slices together, so that a block pays the global-load latency a few times per item instead of a dozen times per body (eight
+// calls of gcn_input_body took ~100 us in a block that has the CU's issue slots mostly to itself).  Arithmetic and operation order per
+// output are gcn_input_body's (bit-equal).  xs = the eight bodies' x_t rows [8][144] (LDS, staged by the caller); T = 24 x 256 floats.
+template <int OUT>   // 1 = X2<32> split rows, 2 = plain f16 rows, 0 = float32 rows
+__device__ __forceinline__ void gcn_input_rows8(float* T, int tid, int vb0, int by, const GcnInputArgs& a, const float* xs) {
+  const LayerDev& L = a.L;
+  const int N = L.N, B = a.B;
+  const int n_raw = by * 256 + tid;
+  const int n = n_raw < N ? n_raw : N - 1;
+  const int p = vb0 >= B ? 1 : 0;
+  const int b0 = p ? vb0 - B : vb0;                               // (no pass map in the loop: second pass of item b is virtual body B + b)
+  float dj[kJ], mj[kJ], wx[2][6], tv[2];
+  const float sh = L.shift[n];
+#pragma unroll
+  for (int j = 0; j < kJ; ++j) { dj[j] = L.D[j * N + n]; mj[j] = L.M1[j * N + n]; }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    tv[k] = a.tvec[k * N + n];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) wx[k][c] = a.Wx[(k * 6 + c) * N + n];
+  }
+  float oth[8][2], img[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      oth[i][k] = (p == 1 && a.mask_all) ? 0.f : a.h_oth[((size_t)(b0 + i) * 2 + k) * N + n];
+      img[i][k] = (p == 0) ? a.h_img[((size_t)(b0 + i) * 2 + k) * N + n] : 0.f;
+    }
+  typedef const float __attribute__((address_space(4))) cfloat;
+  const cfloat* Ac = (const cfloat*)(uintptr_t)L.Aoff;
+  const bool relu = L.relu != 0;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int nb = by * 256;
+  for (int i = 0; i < 8; ++i) {
+    const float* xb = xs + i * kPoseDim;
+    const uint8_t* vb_ = a.vis + (size_t)(b0 + i) * kJ;
+    const float base0 = oth[i][0] + tv[0], base1 = oth[i][1] + tv[1];
+    float h0[kJ], h1[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+      const float v = vb_[j] ? 1.f : 0.f;
+      float s0 = fmaf(v, img[i][0], base0), s1 = fmaf(v, img[i][1], base1);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float xv = xb[j * 6 + c];
+        s0 = fmaf(xv, wx[0][c], s0);
+        s1 = fmaf(xv, wx[1][c], s1);
+      }
+      h0[j] = fmaf(dj[j], s0, sh);
+      h1[j] = mj[j] * s1;
+    }
+    static_assert(OUT != 2, "gcn_input_rows8: the matrix-core mix of the plain-f16 mode is not built here (the loop runs split-f16)");
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+      float sacc = h0[j];
+#pragma unroll
+      for (int jp = 0; jp < kJ; ++jp) sacc = fmaf(Ac[j * kJ + jp], h1[jp], sacc);
+      if (relu) sacc = fmaxf(sacc, 0.f);
+      T[j * 256 + tid] = sacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int u = tid + 256 * it, j = u >> 5, c8 = (u & 31) * 8;
+      if (nb + c8 >= N) continue;
+      const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
+      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const size_t row = (size_t)(vb0 + i) * kJ + j;
+      if (OUT != 0) {
+        half8 hh, ll;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
+          hh[k] = (half_t)c;
+          ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
+        }
+        half_t* q = (half_t*)a.Y + split_off<32>(row, nb + c8, N);
+        *(u32x4*)q = __builtin_bit_cast(u32x4, hh);
+        *(u32x4*)(q + 32) = __builtin_bit_cast(u32x4, ll);
+      } else {
+        float* q = a.Y + row * (size_t)N + nb + c8;
+        *(f32x4*)q = v0;
+        *(f32x4*)(q + 4) = v1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- output conv responses of 16 rows (gcn.hip: gcn_out_dot_kernel; the one-launch loop of gcn_tile.hip calls it per row tile) --------------
+constexpr int OUT_ROWS_PER_BLOCK = 16;
+// [rows, K] x [K, 12] on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32: 16 rows x 16 columns, 12 used).  256 threads = 4 waves split K; a
+// wave's lane (row = l&15, q = l>>4) streams float4 X[row][kw + 16 i + 4 q ..+3] - the k order inside an MFMA step is a
+// permutation applied to both operands, which a sum does not see - and the matching float4 of the 12 x K weights (48 KiB, L2 hits).
+// The four partial 16x16 tiles meet in 4 KiB of LDS (`part`).  AUX = cache policy of the activation loads (0: plain; 16 = sc1).
+template <bool HALF_IN, int AUX>
+__device__ __forceinline__ void gcn_out_dot_rows16(const float* __restrict__ X, const OutDev& O, float* __restrict__ hs, int64_t r0, int64_t rows,
+                                                   float (*part)[16][16], int tid) {
+  const int K = O.K, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 15, q = lane >> 4;
+    const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
+  const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: a multiple of 16)
+  // a lane owns 8 consecutive k of every 32-k group (16 bytes of f16 / 32 bytes of float32 per load: the four lanes of a row cover a
+  // 64 / 128-byte segment); MFMA c of the group contracts element c of all lanes, i.e. k = c, 8 + c, 16 + c, 24 + c
+  const float* xr = X + r * K + (size_t)wave * kq + 8 * q;
+  const half_t* xh = (const half_t*)X + r * K + (size_t)wave * kq + 8 * q;
+  typedef unsigned int u32x4_od __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(X);           // AUX != 0: the rows were written by other blocks of THIS launch - cache-bypassing loads
+  const unsigned int vox = (unsigned int)((r * K + (size_t)wave * kq + 8 * q) * (HALF_IN ? 2 : 4));
+  (void)rsX; (void)vox;
+  const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 8 * q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: the dependent-accumulator latency (40 cyc) exceeds the issue interval
+#pragma unroll 4
+  for (int k = 0; k + 32 <= kq; k += 32) {
+    float xv[8];
+    if (HALF_IN) {
+      const half8 hv = AUX ? __builtin_bit_cast(half8, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 2, AUX)) : *(const half8*)(xh + k);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xv[c] = (float)hv[c];
+    } else {
+      const f32x4 x0 = AUX ? __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4, AUX)) : *(const f32x4*)(xr + k);
+      const f32x4 x1 = AUX ? __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4 + 16, AUX)) : *(const f32x4*)(xr + k + 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xv[c] = x0[c]; xv[4 + c] = x1[c]; }
+    }
+    f32x4 w0 = *(const f32x4*)(wr + k), w1 = *(const f32x4*)(wr + k + 4);
+    if (row >= 12) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], w0[c], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], w0[c + 1], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[4 + c], w1[c], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[5 + c], w1[c + 1], acc2, 0, 0, 0);
+    }
+  }
+  if (kq & 16) {                                                      // hid % 128 != 0: one last 16-k group, four k per lane
+    const int k = kq - 16 - 4 * q;                                    // (undo the 8 q of the pointers: this group's lane stride is 4)
+    f32x4 xv;
+    if (HALF_IN) {
+      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+      const half4_t hv = *(const half4_t*)(xh + k);          // (hid % 128 != 0 only: not used by the one-launch loop, which needs AUX loads)
+      xv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    } else {
+      xv = *(const f32x4*)(xr + k);
+    }
+    f32x4 wv = *(const f32x4*)(wr + k);
+    if (row >= 12) wv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], wv[c], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], wv[c + 1], acc2, 0, 0, 0);
+    }
+  }
+  acc += acc2;
+  // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int c = 0; c < 4; ++c) part[wave][4 * q + c][row] = acc[c];
+  __syncthreads();
+  if (tid < 16 * 12) {
+    const int rr = tid / 12, cc = tid % 12;
+    if (r0 + rr < rows) hs[(r0 + rr) * 12 + cc] = (part[0][rr][cc] + part[1][rr][cc]) + (part[2][rr][cc] + part[3][rr][cc]);
+  }
+}
+
+// The same 16 rows by ONE wave (no LDS, no barrier): the four K quarters one after the other, each with the two accumulator chains of
+// gcn_out_dot_rows16, combined as (q0 + q1) + (q2 + q3) - the same sums in the same order, so the responses are bit-equal to the four-wave
+// form.  A wave of the one-launch loop's OUT item owns three such row groups; K % 128 == 0.
+template <bool HALF_IN, int AUX>
+__device__ __forceinline__ void gcn_out_dot_rows16_wave(const float* __restrict__ X, const OutDev& O, float* __restrict__ hs, int64_t r0, int64_t rows, int lane) {
+  const int K = O.K, row = lane & 15, q = lane >> 4, kq = K / 4;
+  const int64_t r = r0 + row < rows ? r0 + row : rows - 1;
+  typedef unsigned int u32x4_od __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(X);
+  f32x4 part[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned int vox = (unsigned int)((r * K + (size_t)w * kq + 8 * q) * (HALF_IN ? 2 : 4));
+    const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)w * kq + 8 * q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k + 32 <= kq; k += 32) {
+      float xv[8];
+      if (HALF_IN) {
+        const half8 hv = __builtin_bit_cast(half8, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 2, AUX));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[c] = (float)hv[c];
+      } else {
+        const f32x4 x0 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4, AUX));
+        const f32x4 x1 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4 + 16, AUX));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { xv[c] = x0[c]; xv[4 + c] = x1[c]; }
+      }
+      f32x4 w0 = *(const f32x4*)(wr + k), w1 = *(const f32x4*)(wr + k + 4);
+      if (row >= 12) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+#pragma unroll
+      for (int c = 0; c < 4; c += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], w0[c], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], w0[c + 1], acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[4 + c], w1[c], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[5 + c], w1[c + 1], acc2, 0, 0, 0);
+      }
+    }
+    part[w] = acc + acc2;
+  }
+  // C layout of the 16x16 tile: column (output channel) = lane & 15, row = 4 * (lane >> 4) + reg
+  if (row < 12) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (r0 + 4 * q + c < rows) hs[(r0 + 4 * q + c) * 12 + row] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  }
+}

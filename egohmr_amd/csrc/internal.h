@@ -15,7 +15,13 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
                        const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int do_pose,
                        const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
                        float* pose6d, int B, hipStream_t st, const struct GcnInputArgs* next_input = nullptr, int next_prec = 0,
-                       int* fused = nullptr);
+                       int* fused = nullptr, void* defer_pf = nullptr);   // defer_pf: write the blend fragments there and launch NO skinning (ehm_skin_steps_impl later)
+int ehm_skin_steps_impl(ehm_smpl* h, const float* A_steps, const void* pf_steps, int nsteps, int final_step, int B, float* verts, float* joints,
+                        float* scratch_verts, float* scratch_joints, hipStream_t st);
+int ehm_skin_min_bodies();
+int64_t ehm_skin_pf_bytes_per_step(int B);
+void ehm_smpl_dev(const ehm_smpl* h, void* out);   // copies the handle's SmplDev (smpl_dev.h) into *out
+size_t ehm_smpl_dev_size();
 int ehm_smpl_num_verts(const ehm_smpl* h);
 int ehm_smpl_num_extra(const ehm_smpl* h);
 // gcn.hip
@@ -26,6 +32,7 @@ int ehm_gcn_hid(const ehm_gcn* h);
 int ehm_gcn_nonlocal_ci(const ehm_gcn* h);
 const ehm_nonlocal_params* ehm_gcn_nonlocal(const ehm_gcn* h);
 int ehm_gcn_num_hidden(const ehm_gcn* h);
+int ehm_gcn_chain_enabled(const ehm_gcn* h);   // the hidden convs run as chained launches in the handle's precision (f16 modes, EHM_F16_CHAIN != 0)
 int ehm_gcn_virtual_bodies(const ehm_gcn* h, int B, int passes);   // B + second passes after pruning (ehm_gcn_set_pass_map)
 const int32_t* ehm_gcn_mask_slot(const ehm_gcn* h, int passes);
 // output conv, first half only: responses hs [passes*B*24, 12] = X . [W0 | W1] (scratch owned by the handle); *out_dev = the OutDev block
@@ -36,6 +43,21 @@ int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
                             hipStream_t st);
 int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
+// the one-launch sampling loop (gcn_tile.hip): launch description filled by sampler.hip
+struct ehm_loop_launch {
+  void* bufs[3];                 // activation ping-pong [passes * B * 24, hid]
+  int B, passes, nsteps;
+  const struct GcnInputArgs* in; // x = loop state [B,144], tvec = first step of the segment, Y = bufs[0]
+  const void* step_body;         // StepBodyArgs (step_dev.h): vis, x, noise (first step's draw), x_next = state, x0, ddim, passes, B, betas, mean, std, Rws, joints, pose6d, jstride
+  const ehm_step_coefs* coefs;   // DEVICE [nsteps]
+  const void* smpl_dev;          // SmplDev
+  float* A_steps; void* pf_steps; int64_t pf_bytes_per_step;
+  float* trace;                  // [nsteps,B,144] or nullptr
+  float* x_final;                // destination of the last step's x_{t-1}
+  int lbs_every_step, last_is_final;
+};
+int ehm_gcn_tile_loop_impl(ehm_gcn* h, const ehm_loop_launch* L, hipStream_t st);
+int ehm_upload_step_coefs(const ehm_step_coefs* host, ehm_step_coefs* dev, int n, hipStream_t st);
 void ehm_pack_half(const float* X, void* Y, size_t n, float scale, hipStream_t st);
 // gcn.hip
 int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad);   // sync words + output-conv scratch for up to rows_pad rows (allocates: not inside a capture)

@@ -25,6 +25,7 @@
 #include "internal.h"
 #include "gcn_dev.h"
 #include "smpl_dev.h"
+#include "step_dev.h"
 
 namespace {
 
@@ -74,88 +75,6 @@ __global__ void rot6d_kernel(const float* __restrict__ x, float* __restrict__ Ro
   else rot6d_to_R(p[0], p[1], p[2], p[3], p[4], p[5], R);
 #pragma unroll
   for (int k = 0; k < 9; ++k) Rout[i * 9 + k] = R[k];
-}
-
-// ------------------------------------------------------------------------------------------------ pose + chain
-// One wave per body, lane = joint.  `Rl` (may be nullptr): LDS copy [24][9] of the rotations for a caller that goes on to pack them.
-template <bool FROM_ROT6D>
-__device__ __forceinline__ void pose_chain_body(int b, int lane, const float* __restrict__ betas, const float* rot_or_x /* this body's row */,
-                                                const float* __restrict__ mean, const float* __restrict__ std_, const SmplDev& S,
-                                                float* __restrict__ Rws, float* __restrict__ Aout, float* __restrict__ joints,
-                                                float* __restrict__ pose6d_out, int joints_stride, float* Rl) {
-  const int j = lane < kJ ? lane : 0;
-  float R[9];
-  if (FROM_ROT6D) {
-    float p[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const int e = j * 6 + c;
-      p[c] = rot_or_x[e] * std_[e] + mean[e];                          // egohmr.py:258
-      if (pose6d_out && lane < kJ) pose6d_out[(size_t)b * kPoseDim + e] = p[c];
-    }
-    rot6d_to_R(p[0], p[2], p[4], p[1], p[3], p[5], R);                 // 'diffusion' layout
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = rot_or_x[j * 9 + k];
-  }
-  // joint regression: J = J_template + J_shape . beta
-  float Jx[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float s = 0.f;
-#pragma unroll
-    for (int l = 0; l < 10; ++l) s = fmaf(S.J_shape[j * 30 + c * 10 + l], betas[(size_t)b * 10 + l], s);
-    Jx[c] = S.J_template[j * 3 + c] + s;
-  }
-  const int par = S.tree.parent[j];
-  const int plane = par < 0 ? 0 : par;
-  float t[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float pj = __shfl(Jx[c], plane);
-    t[c] = par < 0 ? Jx[c] : Jx[c] - pj;     // rel_joints
-  }
-  // G = [R | t] for the root; children: G = G_parent * [R | t]
-  float G[12];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    G[r * 4 + 0] = R[r * 3 + 0]; G[r * 4 + 1] = R[r * 3 + 1]; G[r * 4 + 2] = R[r * 3 + 2]; G[r * 4 + 3] = t[r];
-  }
-  const int my_depth = S.tree.depth[j];
-  for (int d = 1; d <= S.tree.max_depth; ++d) {
-    float P[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) P[k] = __shfl(G[k], plane);
-    if (my_depth == d) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float p0 = P[r * 4 + 0], p1 = P[r * 4 + 1], p2 = P[r * 4 + 2], p3 = P[r * 4 + 3];
-        G[r * 4 + 0] = p0 * R[0] + p1 * R[3] + p2 * R[6];
-        G[r * 4 + 1] = p0 * R[1] + p1 * R[4] + p2 * R[7];
-        G[r * 4 + 2] = p0 * R[2] + p1 * R[5] + p2 * R[8];
-        G[r * 4 + 3] = p0 * t[0] + p1 * t[1] + p2 * t[2] + p3;
-      }
-    }
-  }
-  if (lane >= kJ) return;
-  const size_t o = (size_t)b * kJ + j;
-  if (Rws) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rws[o * 9 + k] = R[k];
-  }
-  if (Rl) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rl[j * 9 + k] = R[k];
-  }
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    joints[(size_t)b * joints_stride + j * 3 + r] = G[r * 4 + 3];           // posed joint = chain translation
-    const float gj = G[r * 4 + 0] * Jx[0] + G[r * 4 + 1] * Jx[1] + G[r * 4 + 2] * Jx[2];
-    Aout[o * 12 + r * 4 + 0] = G[r * 4 + 0];
-    Aout[o * 12 + r * 4 + 1] = G[r * 4 + 1];
-    Aout[o * 12 + r * 4 + 2] = G[r * 4 + 2];
-    Aout[o * 12 + r * 4 + 3] = G[r * 4 + 3] - gj;                              // rel_transforms
-  }
 }
 
 template <bool FROM_ROT6D>
@@ -286,7 +205,6 @@ __global__ __launch_bounds__(kVT, 2) void skin_kernel(const float* __restrict__ 
 // (x, y, z) so that afterwards lane (vertex, half) owns the blended position of its vertex for 16 bodies and finishes the
 // skinning (sparse-4 weights, transforms in LDS) without any transposition.  Both operands are stored in fragment order - every
 // load instruction reads 1 KiB contiguous - and go straight from L2 to registers.
-typedef _Float16 sk_half8 __attribute__((ext_vector_type(8)));
 
 __global__ void pd_pack_kernel(const float* __restrict__ posedirs, const float* __restrict__ shapedirs, sk_half8* __restrict__ out,
                                int V, int v_tiles, float scale) {
@@ -350,6 +268,10 @@ struct SkinArgs {
   const sk_half8* PF; const float* A; SmplDev S;
   float* verts; float* joints;
   int B, v_tiles, vt_groups;
+  // several steps of a sampling loop in ONE launch (ehm_skin_steps_impl): PF / A hold `nsteps` consecutive [B]-body sets, the set `final_step`
+  // writes verts / joints, the others scratch_verts / scratch_joints (same arithmetic, results of the intermediate steps are not consumed)
+  int nsteps = 1, final_step = 0;
+  float* scratch_verts = nullptr; float* scratch_joints = nullptr;
 };
 
 // One block (256 threads) of the matrix-core skinning; sA = 32 * 24 * 12 floats (36 KiB) of LDS: the skinning transforms of the block's
@@ -361,11 +283,16 @@ __device__ __forceinline__ void skin_mfma_body(float (*sA)[kJ][12], int bid, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order: the blocks of one XCD walk the body tiles of the same vertex-tile group back to back (basis fragments from L2)
   const int xcd = bid & 7, kk = bid >> 3;
-  const int b_tiles = (B + 31) / 32;
+  const int b_tiles_step = (B + 31) / 32, b_tiles = b_tiles_step * a.nsteps;
   const int vg = (kk / b_tiles) * 8 + xcd, bt = kk % b_tiles;
   if (vg >= vt_groups) return;
   SSTAMP(0);
-  const int b0 = 32 * bt, nb = min(32, B - b0);
+  const int step = bt / b_tiles_step;
+  const int b0 = 32 * (bt - step * b_tiles_step), nb = min(32, B - b0);
+  if (a.scratch_verts) {                                       // (legacy single-step launches: the pointers as given)
+    A += (size_t)step * B * kJ * 12;
+    if (step != a.final_step) { verts = a.scratch_verts; joints = joints ? a.scratch_joints : nullptr; }
+  }
   const int vt = min(4 * vg + wave, v_tiles - 1);             // (a surplus wave of the last group recomputes the last tile and stores nothing)
   const bool live = 4 * vg + wave < v_tiles;
 
@@ -679,114 +606,26 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
 //   (3) de-normalise, rot6d -> R, joint regression, 24-joint kinematic chain by wave shuffles -> R, skinning transforms A, joints
 //   (4) the body's blend coefficients [R[1:] - I | betas] as split-f16 MFMA fragments for skin_mfma_kernel.
 // One wave per body.
-struct StepBodyArgs {
-  const float* hs;          // [passes*B*24, 12] responses of the output conv (gcn_out_dot_kernel)
-  OutDev O;
-  const uint8_t* vis;       // [B,24]
-  const float* x;           // x_t [B,144]
-  const float* noise;       // [B,144]
-  const float* grad;        // [B,144] or nullptr
-  float* x_next;            // may alias x
-  float* x0;                // [B,144]
-  ehm_step_coefs c;
-  int ddim, passes, B, do_pose;
-  const int32_t* mask_slot; // pass pruning (ehm_gcn_set_pass_map) or nullptr
-  const float *betas, *mean, *std_;
-  float *Rws, *Aws, *joints, *pose6d;
-  int jstride;
-  sk_half8* pf;             // nullptr: VALU skinning path (B < 24), no fragments
-};
-
 __global__ __launch_bounds__(64) void step_body_kernel(StepBodyArgs a, SmplDev S) {
-  __shared__ float sh[2][kJ][12];
-  __shared__ float x0s[kPoseDim];
-  __shared__ float Rl[kJ * 9];
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const int slot = a.mask_slot ? a.mask_slot[b] : b;            // row block of my second pass: B + slot (slot < 0: pruned, every joint visible)
-  // stage the body's output-conv responses and the (tiny) adjacency / modulation tables: every global load of the kernel's first
-  // phase is requested before the first one is consumed (as an element-wise loop this was nine dependent round trips, and the mix
-  // below fetched its coefficients from global memory inside the inner loop)
-  __shared__ float sAo[kJ * kJ], sMo[kJ * 6];
-  {
-    float tmp[9], ta[9], tm[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int i = lane + 64 * k, p = i / (kJ * 12), rem = i % (kJ * 12);
-      tmp[k] = (i < a.passes * kJ * 12 && !(p == 1 && slot < 0)) ? a.hs[((size_t)(p ? a.B + slot : b) * kJ) * 12 + rem] : 0.f;
-      ta[k] = a.O.A[i < kJ * kJ ? i : 0];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tm[k] = a.O.M[lane + 64 * k < kJ * 6 ? lane + 64 * k : 0];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int i = lane + 64 * k;
-      if (i < a.passes * kJ * 12) (&sh[0][0][0])[i] = tmp[k];
-      if (i < kJ * kJ) sAo[i] = ta[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (lane + 64 * k < kJ * 6) sMo[lane + 64 * k] = tm[k];
-  }
-  __syncthreads();
-  for (int e = lane; e < kPoseDim; e += 64) {
-    const int j = e / 6, c = e % 6;
-    const int p = (a.passes == 2 && !a.vis[(size_t)b * kJ + j]) ? 1 : 0;          // egohmr.py:249-254
-    const float s = sAo[j * kJ + j] * (sMo[j * 6 + c] * sh[p][j][c]);
-    float t = 0.f;
-    for (int jp = 0; jp < kJ; ++jp)
-      if (jp != j) t = fmaf(sAo[j * kJ + jp], sMo[jp * 6 + c] * sh[p][jp][6 + c], t);
-    const float x0 = s + t + a.O.bias[c];
-    const size_t i = (size_t)b * kPoseDim + e;
-    a.x0[i] = x0;
-    x0s[e] = x0;
-    const float xv = a.x[i], nz = a.noise[i];
-    float out;
-    if (a.ddim) {
-      const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(a.c.sqrt_recip_ac, xv), x0), a.c.sqrt_recipm1_ac);
-      const float mean = __fadd_rn(__fmul_rn(x0, a.c.sqrt_ac_prev), __fmul_rn(a.c.dir_coef, eps));
-      out = __fadd_rn(mean, __fmul_rn(__fmul_rn(a.c.nonzero, a.c.sigma), nz));
-    } else {
-      float mean = __fadd_rn(__fmul_rn(a.c.coef1, x0), __fmul_rn(a.c.coef2, xv));
-      if (a.grad) mean = __fadd_rn(mean, __fmul_rn(a.c.grad_scale, a.grad[i]));
-      const float sd = expf(__fmul_rn(0.5f, a.c.log_variance));
-      out = __fadd_rn(mean, __fmul_rn(__fmul_rn(a.c.nonzero, sd), nz));
-    }
-    a.x_next[i] = out;
-  }
-  if (!a.do_pose) return;
-  __syncthreads();
-  pose_chain_body<true>(b, lane, a.betas, x0s, a.mean, a.std_, S, a.Rws, a.Aws, a.joints, a.pose6d, a.jstride, Rl);
-  if (!a.pf) return;
-  __syncthreads();
-  if (lane < 2 * kBlendSteps) {                                 // 28 lanes: (k-step s, lane half h) -> 8 coefficients, hi and lo fragments
-    const int s = lane >> 1, h = lane & 1;
-    sk_half8 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 16 * s + 8 * h + e;
-      float x = 0.f;
-      if (k < kPoseBasis) x = Rl[9 + k] - ((k % 9 == 0 || k % 9 == 4 || k % 9 == 8) ? 1.f : 0.f);   // R[1:] - I
-      else if (k < kPoseBasis + 10) x = a.betas[(size_t)b * 10 + (k - kPoseBasis)];
-      hi[e] = (_Float16)x;
-      lo[e] = (_Float16)(x - (float)hi[e]);
-    }
-    const size_t base = ((size_t)(b >> 5) * kBlendSteps + s) * 2;
-    a.pf[(base + 0) * 64 + (b & 31) + 32 * h] = hi;
-    a.pf[(base + 1) * 64 + (b & 31) + 32 * h] = lo;
-  }
+  __shared__ StepBodyLds L;
+  step_body_one(blockIdx.x, threadIdx.x, a, S, L, [] { __syncthreads(); });
 }
 
 // sampler.hip's per-step call: output-conv mix + sampler update + pose chain + fragment pack in one launch, then the skinning launch.
 int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const uint8_t* vis, const float* x, const float* noise,
                        const float* grad, float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int do_pose,
                        const float* betas, const float* mean, const float* std_, float* verts, float* joints, float* Rws, float* Aws,
-                       float* pose6d, int B, hipStream_t st, const GcnInputArgs* next_input, int next_prec, int* fused) {
+                       float* pose6d, int B, hipStream_t st, const GcnInputArgs* next_input, int next_prec, int* fused, void* defer_pf) {
   const SmplDev& d = h->d;
   if (fused) *fused = 0;
   constexpr int mfma_min = kSkinMfmaMinBodies;
   const bool mfma = d.PDf && B >= mfma_min;
   const int b_tiles = (int)ceil_div(B, 32);
-  if (mfma && 32 * b_tiles > h->pf_cap) {                    // grows on the first call with a larger batch only
+  if (defer_pf && !mfma) {
+    ehm_set_error("ehm_step_body_impl: deferred skinning needs the matrix-core skinning path");
+    return EHM_EINVAL;
+  }
+  if (mfma && !defer_pf && 32 * b_tiles > h->pf_cap) {                    // grows on the first call with a larger batch only
     if (h->pf) EHM_HIP(hipFree(h->pf));
     h->pf = nullptr;
     h->pf_cap = 0;
@@ -799,12 +638,13 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
   a.c = *c; a.ddim = ddim; a.passes = passes; a.B = B; a.do_pose = do_pose; a.mask_slot = mask_slot;
   a.betas = betas; a.mean = mean; a.std_ = std_; a.Rws = Rws; a.Aws = Aws; a.joints = joints; a.pose6d = pose6d;
   a.jstride = (kJ + d.n_extra) * 3;
-  a.pf = mfma ? (sk_half8*)h->pf : nullptr;
+  a.pf = defer_pf ? (sk_half8*)defer_pf : (mfma ? (sk_half8*)h->pf : nullptr);
   {
     EhmProfScope ps(EHM_PROF_STEP_BODY, st);
+    a.trace = nullptr;
     hipLaunchKernelGGL(step_body_kernel, dim3(B), dim3(64), 0, st, a, d);
   }
-  if (do_pose) {
+  if (do_pose && !defer_pf) {
     EhmProfScope ps(EHM_PROF_SKIN_INPUT, st);
     if (mfma) {
       const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
@@ -830,6 +670,31 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
   EHM_LAUNCH_CHECK();
   return 0;
 }
+
+// The skinning of `nsteps` consecutive steps of a sampling loop in one launch (the one-launch loop of gcn_tile.hip leaves every step's
+// transforms A_steps [nsteps,B,24,12] and blend-coefficient fragments pf_steps [nsteps, ceil(B/32), 14, 2, 64] behind): step `final_step`
+// writes verts / joints, the others the scratch buffers (any negative final_step: all of them).
+int ehm_skin_steps_impl(ehm_smpl* h, const float* A_steps, const void* pf_steps, int nsteps, int final_step, int B, float* verts, float* joints,
+                        float* scratch_verts, float* scratch_joints, hipStream_t st) {
+  const SmplDev& d = h->d;
+  if (!d.PDf || B < kSkinMfmaMinBodies || nsteps < 1) {
+    ehm_set_error("ehm_skin_steps_impl: needs the matrix-core skinning path (B >= %d) and nsteps >= 1", kSkinMfmaMinBodies);
+    return EHM_EINVAL;
+  }
+  const int b_tiles = (int)ceil_div(B, 32) * nsteps;
+  const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
+  const int64_t blocks = round_up(vt_groups, 8) * (int64_t)b_tiles;
+  SkinArgs sa{(const sk_half8*)pf_steps, A_steps, d, verts, d.n_extra ? joints : nullptr, B, v_tiles, vt_groups};
+  sa.nsteps = nsteps; sa.final_step = final_step; sa.scratch_verts = scratch_verts; sa.scratch_joints = scratch_joints;
+  EhmProfScope ps(EHM_PROF_SKIN_INPUT, st);
+  hipLaunchKernelGGL(skin_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sa);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+int ehm_skin_min_bodies() { return kSkinMfmaMinBodies; }
+int64_t ehm_skin_pf_bytes_per_step(int B) { return (int64_t)ceil_div(B, 32) * kBlendSteps * 2 * 64 * 16; }
+void ehm_smpl_dev(const ehm_smpl* h, void* out) { memcpy(out, &h->d, sizeof(SmplDev)); }
+size_t ehm_smpl_dev_size() { return sizeof(SmplDev); }
 
 int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_, float* Rws, float* Aws,
                        float* jws, int B, hipStream_t st) {

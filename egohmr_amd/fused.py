@@ -37,6 +37,7 @@ class FusedSampler:
         self._sched_cache = {}          # schedule_key -> calibration info (calibrate_schedule)
         self.schedule_info = None       # the calibration the most recent 'auto' run used (None: ran all-f16x3 / explicit k)
         self.last_lowprec = 0
+        self.last_engine = False
         self.last_trace = None
 
     @property
@@ -710,8 +711,17 @@ class FusedSampler:
                 self.schedule_info = self._sched_cache.get(skey)
             lowprec = self.lowprec_steps(T, n_guided, ddim, key=skey)
         self.last_lowprec = int(lowprec)                  # leading steps of THIS call on plain f16 operands
-        _, num_masked = self._apply_pass_map(st, passes)
-        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim),
+        # the one-launch loop (ehm_sample_desc.loop_engine) runs every item through both passes; exact pass pruning only pays
+        # more than it when a sizeable share of the items has every joint visible
+        engine = (bool(m.loop_engine) and not nonlocal_ci and B % 8 == 0 and B >= 24 and m.gcn_precision == "f16x3"
+                  and not (passes == 2 and m.prune_passes and st.num_masked < m.loop_engine_min_masked * B))
+        self.last_engine = bool(engine)                   # (runs of >= 2 unguided steps of this call go through the one-launch loop)
+        if engine:
+            _lib.check(L.ehm_gcn_set_pass_map(self.gcn(), None, None, -1), "ehm_gcn_set_pass_map")
+            num_masked = -1
+        else:
+            _, num_masked = self._apply_pass_map(st, passes)
+        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim), loop_engine=int(engine),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
                                guide_denom=self.guide_denom(denom_items or B), tau=m.collision_tau, num_masked=num_masked,
                                guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=int(lowprec), nonlocal_ci=int(nonlocal_ci))

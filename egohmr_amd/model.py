@@ -207,6 +207,10 @@ class EgoHMR(nn.Module):
         self.guide_denom_override = None       # sharded / sub-batch runs: the GLOBAL batch size of `-loss.mean()`, else None
         self.guide_all_points = False          # COAP variant: bbox-selected scene points (egohmr.py:550-552); True = all points (egohmr_volsmpl.py:609-612)
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
+        # runs of unguided steps as ONE persistent launch (csrc/gcn_tile.hip gcn_loop_kernel) when the batch is a multiple of 8 bodies; the loop runs
+        # both passes for every item, so it is used when at least this share of the items needs the second pass anyway
+        self.loop_engine = False
+        self.loop_engine_min_masked = 0.85
         self.pass_group = 1                # second passes pruned per item (1) or per group of this many consecutive items (FusedSampler.prepare)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)
         self.overlap_encoders = True       # ResNet-50 and the scene PointNet on two HIP streams (FusedSampler.prepare)

@@ -398,6 +398,9 @@ typedef struct {
                          (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */
   int nonlocal_ci;    /* inter_channels of the non-local block set with ehm_gcn_set_nonlocal, 0 = none (needs float32 features:
                          handle mode 0 or 1 and lowprec_steps == 0)                                                              */
+  int loop_engine;    /* 1 = runs of consecutive unguided steps execute as ONE persistent launch + one skinning launch (same arithmetic,
+                         same results) when the shape allows it: B % 8 == 0, B >= 24, no pass pruning map (num_masked = -1), an f16 /
+                         split-f16 handle mode, no non-local block; 0 = one launch sequence per step                                 */
 } ehm_sample_desc;
 
 /* GaussianDiffusion.p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508, :618-718)
@@ -429,7 +432,9 @@ enum {
   EHM_PROF_STEP_BODY = 5,    /* step_body_kernel                                                                         */
   EHM_PROF_SKIN_INPUT = 6,   /* skin_input_kernel (skinning of step t + input conv of step t+1) / skin_mfma_kernel       */
   EHM_PROF_GUIDANCE = 7,     /* the collision-guidance kernel sequence of a guided step                                  */
-  EHM_PROF_N = 8
+  EHM_PROF_LOOP_F16X3 = 8,   /* gcn_loop_kernel<3, 4>: a run of unguided steps in one launch (ehm_sample_desc.loop_engine), split-f16 */
+  EHM_PROF_LOOP_F16 = 9,     /* gcn_loop_kernel<1, 8>: the same on plain f16 operands                                    */
+  EHM_PROF_N = 10
 };
 int ehm_profile_begin(void);
 int ehm_profile_end(double* ms, int64_t* launches, int n);

@@ -1,0 +1,114 @@
+"""GPU (MI355X): the one-launch sampling loop (csrc/gcn_tile.hip gcn_loop_kernel, ehm_sample_desc.loop_engine) against the per-step launch
+sequence it replaces (diffusion/gaussian_diffusion.py:449-508 / :661-718 around models/egohmr/egohmr.py:232-278).
+
+Both routes run the same kernels' arithmetic per body - input conv, the chained hidden convs' tiles, the exact-f32 output responses, the
+per-body sampler / pose step, the matrix-core skinning - so their results must be BIT-equal; only the scheduling differs (per 8-body group
+with counters inside one persistent launch, groups running ahead into the next step, one skinning launch per run of steps)."""
+import pytest
+import torch
+
+from egohmr_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev, smpl_asset):
+    from egohmr_amd.factory import build_synthetic_model
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=100))
+    m.f16x3_last_steps = None
+    return m
+
+
+def _run(model, d, batch, noise, engine, **kw):
+    model.loop_engine = engine
+    fs = model.fused_sampler
+    fs.invalidate()
+    r = fs.run(d, dict(batch), noise, **kw)
+    o = r["other_outputs"]
+    torch.cuda.synchronize()
+    return {"sample": r["sample"].clone(), "x0": r["pred_xstart"].clone(), "verts": o["pred_vertices"].clone(), "joints": o["pred_keypoints_3d"].clone(),
+            "R": o["pred_smpl_params"]["body_pose"].clone(), "pose6d": o["pred_pose_6d"].clone()}, fs
+
+
+def _same(a, b):
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+
+
+@pytest.mark.parametrize("B,respacing,ddim,precision,lowprec", [
+    (32, "ddim10", True, "f16x3", None),          # four groups, one row tile per queue at most
+    (256, "ddim5", True, "f16x3", None),          # the benchmark shape: 64 row tiles, both classes in every queue
+    (40, "", False, "f16x3", 2),                  # ancestral sampling, 10 steps of 10; an explicit schedule: two segments (f16 then split-f16)
+])
+def test_one_launch_loop_is_bit_equal_to_the_per_step_loop(dev, model, B, respacing, ddim, precision, lowprec):
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device
+    n = 100 if respacing else 10
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=respacing)
+    T = d.num_timesteps
+    batch = batch_to_device(syn.make_batch(B, 512, seed=11), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(T, B, seed=11)).to(dev)
+    old = (model.gcn_precision, model.f16x3_last_steps)
+    model.gcn_precision = precision
+    model.f16x3_last_steps = (T - lowprec) if lowprec else None
+    try:
+        ref, _ = _run(model, d, batch, noise, False, ddim=ddim, trace=True)
+        tr_ref = model.fused_sampler.last_trace.clone()
+        out, fs = _run(model, d, batch, noise, True, ddim=ddim, trace=True)
+        tr = fs.last_trace.clone()
+        assert fs.last_engine, "the one-launch loop was not taken"
+    finally:
+        model.gcn_precision, model.f16x3_last_steps = old
+        model.loop_engine = False
+    assert torch.equal(tr, tr_ref), float((tr - tr_ref).abs().max())      # x_t fed to every step
+    _same(out, ref)
+
+
+def test_one_launch_loop_without_lbs_every_step_and_unfused_passes(dev, smpl_asset):
+    """passes = 1 (no diffuse_fuse) and lbs_every_step off: only the last step is skinned."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    m = build_synthetic_model(dev, 0, diffuse_fuse=False, smpl_asset=smpl_asset)
+    m.f16x3_last_steps = None
+    m.lbs_every_step = False
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    B = 24
+    batch = batch_to_device(syn.make_batch(B, 256, seed=5), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=5)).to(dev)
+    ref, _ = _run(m, d, batch, noise, False, ddim=True)
+    out, fs = _run(m, d, batch, noise, True, ddim=True)
+    assert fs.last_engine
+    _same(out, ref)
+
+
+def test_ineligible_shapes_fall_back_to_the_per_step_loop(dev, model):
+    """B not a multiple of 8, a batch where most items skip the second pass (the per-step loop with exact pass pruning runs), or the
+    plain-f16 tier (the loop kernel is built for the split-f16 mode)."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    for B, all_visible in ((12, False), (32, True)):
+        b = syn.make_batch(B, 256, seed=3)
+        if all_visible:
+            b["orig_keypoints_2d"][:, :, 2] = 1.0
+        batch = batch_to_device(b, dev)
+        noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=3)).to(dev)
+        out, fs = _run(model, d, batch, noise, True, ddim=True)
+        assert not fs.last_engine
+        assert torch.isfinite(out["verts"]).all()
+    batch = batch_to_device(syn.make_batch(32, 256, seed=3), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, 32, seed=3)).to(dev)
+    model.gcn_precision = "f16"
+    try:
+        out, fs = _run(model, d, batch, noise, True, ddim=True)
+    finally:
+        model.gcn_precision = "f16x3"
+        model.loop_engine = False
+    assert not fs.last_engine and torch.isfinite(out["verts"]).all()

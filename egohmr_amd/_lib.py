@@ -171,7 +171,8 @@ PROTOTYPES = {
     "ehm_profile_begin": (_I, []),
     "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }
-PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "loop_f16x3", "loop_f16")   # EHM_PROF_* of the header
+PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "loop_f16x3", "loop_f16",
+                "guid_nearest", "guid_skin_bwd", "guid_posefeat_bwd")   # EHM_PROF_* of the header
 
 _lib = None
 

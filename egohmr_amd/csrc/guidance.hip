@@ -711,9 +711,15 @@ int backward_impl(ehm_smpl* h, const float* betas, const float* x, const float* 
   const SmplDev& d = h->d;
   EHM_HIP(hipMemsetAsync(s.gA, 0, (size_t)B * kJ * 12 * sizeof(float), st));
   const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBG);
-  hipLaunchKernelGGL(skin_bwd_kernel, dim3((unsigned)(round_up(v_tiles, 8) * b_groups)), dim3(kVT), 0, st, betas, Rws, Aws, d, gverts,
-                     s.gA, B, v_tiles, b_groups);
-  hipLaunchKernelGGL(posefeat_bwd_kernel, dim3(kJ - 1, (unsigned)b_groups), dim3(256), 0, st, gverts, d, s.gpf, B);
+  {
+    EhmProfScope ps(EHM_PROF_G_SKIN_BWD, st);
+    hipLaunchKernelGGL(skin_bwd_kernel, dim3((unsigned)(round_up(v_tiles, 8) * b_groups)), dim3(kVT), 0, st, betas, Rws, Aws, d, gverts,
+                       s.gA, B, v_tiles, b_groups);
+  }
+  {
+    EhmProfScope ps(EHM_PROF_G_POSEFEAT_BWD, st);
+    hipLaunchKernelGGL(posefeat_bwd_kernel, dim3(kJ - 1, (unsigned)b_groups), dim3(256), 0, st, gverts, d, s.gpf, B);
+  }
   hipLaunchKernelGGL(chain_bwd_kernel, dim3(B), dim3(64), 0, st, betas, x, mean, std_, d, s.gA, s.gpf, gpose);
   EHM_LAUNCH_CHECK();
   return 0;
@@ -732,7 +738,10 @@ int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const 
   const int V = smpl->d.V;
   const Scratch s = carve_scratch(scratch, B, N);
   int rc = ehm_smpl_forward_impl(smpl, betas, x, true, mean, std_, verts_ws, joints_ws, R_ws, A_ws, nullptr, B, st);   // egohmr.py:528-537
-  if (rc == 0) rc = collision_impl(verts_ws, scene, loss, gverts, nullptr, B, V, N, tau, margin, s, st);
+  if (rc == 0) {
+    EhmProfScope ps(EHM_PROF_G_NEAREST, st);      // memsets + bbox + select + nearest_grid_kernel (the search dominates)
+    rc = collision_impl(verts_ws, scene, loss, gverts, nullptr, B, V, N, tau, margin, s, st);
+  }
   if (rc == 0) rc = backward_impl(smpl, betas, x, mean, std_, R_ws, A_ws, gverts, gpose, B, s, st);
   if (rc == 0) {
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)ceil_div((int64_t)B * kPoseDim, 256)), dim3(256), 0, st, gpose, grad, B, denom);

@@ -82,6 +82,17 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device) -> list:
+    """Every rank's scalar, in rank order (bench.py: per-rank throughput in the N > 1 line)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def agree_schedule(fused_sampler, diffusion, batch, ddim=False, guided=False, cond_grad_weight=1.0, denom_items=None, **kw):
     """One precision-schedule calibration for the whole job: rank 0 measures k on ITS batch (FusedSampler.calibrate_schedule - with the
     contiguous sharding of `shard_range` these are the first items of the data set whatever the world size), every rank installs that k.

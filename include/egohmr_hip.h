@@ -433,8 +433,11 @@ enum {
   EHM_PROF_SKIN_INPUT = 6,   /* skin_input_kernel (skinning of step t + input conv of step t+1) / skin_mfma_kernel       */
   EHM_PROF_GUIDANCE = 7,     /* the collision-guidance kernel sequence of a guided step                                  */
   EHM_PROF_LOOP_F16X3 = 8,   /* gcn_loop_kernel<3, 4>: a run of unguided steps in one launch (ehm_sample_desc.loop_engine), split-f16 */
-  EHM_PROF_LOOP_F16 = 9,     /* gcn_loop_kernel<1, 8>: the same on plain f16 operands                                    */
-  EHM_PROF_N = 10
+  EHM_PROF_LOOP_F16 = 9,     /* (reserved: the one-launch loop is built for the split-f16 mode)                          */
+  EHM_PROF_G_NEAREST = 10,   /* inside EHM_PROF_GUIDANCE: bbox + select + nearest_grid_kernel (the collision proxy's search) */
+  EHM_PROF_G_SKIN_BWD = 11,  /* inside EHM_PROF_GUIDANCE: skin_bwd_kernel (VJP of the skinning)                          */
+  EHM_PROF_G_POSEFEAT_BWD = 12, /* inside EHM_PROF_GUIDANCE: posefeat_bwd_kernel ([B, 20670] x [20670, 207] contraction) */
+  EHM_PROF_N = 13
 };
 int ehm_profile_begin(void);
 int ehm_profile_end(double* ms, int64_t* launches, int n);

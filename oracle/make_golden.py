@@ -475,6 +475,23 @@ def g16_sensitive_denoiser(asset, mean, std):
          **extra, **_pack_out(o))
 
 
+def g17_partially_sensitive_denoiser(asset, mean, std):
+    """A denoiser between the two synthetic weight sets: low-noise gain d x0 / d x_t = 0.3 (make_sensitive_state_dict(gain=0.3)), for which the
+    product's calibration picks a schedule with 0 < k < T (k = 36 of 100 at a 1e-5 m bar).  The reference's own DDPM-100 loop on it
+    gates a MIXED plain-f16 / split-f16 loop by the reference, not only by the product's own all-split loop."""
+    from diffusion.model_util import create_gaussian_diffusion
+    n, gain = 100, 0.3
+    m = build_reference_model(syn.make_sensitive_state_dict(0, n, gain=gain), asset, mean, std, diffuse_fuse=True)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing="")
+    Bc, N = 4, 1024
+    bb = to_torch_batch(syn.make_batch(Bc, num_scene_points=N, seed=65))
+    noise = torch.from_numpy(syn.make_noise_stack(n, Bc, seed=65))
+    with explicit_noise(noise), torch.no_grad():
+        o = d.val_losses(model=m, batch=bb, shape=[Bc, 144], progress=False, clip_denoised=False, cur_epoch=0, timestep_respacing="",
+                         cond_fn_with_grad=False, cond_grad_weight=0.0, compute_loss=False)
+    save("g17_e2e_ddpm100_gain03", batch_seed=65, noise_seed=65, B=Bc, N=N, n=n, gain=gain, respacing="", guided=False, cond_grad_weight=0.0, **_pack_out(o))
+
+
 def g13_gcn_nonlocal():
     """ModulatedGCN(nonlocal_layer=True) (modulated_gcn.py:93-110): the reference module itself, synthetic weights with a
     non-trivial W.1 BatchNorm (the reference initialises it to zero = identity block)."""
@@ -534,6 +551,9 @@ def main():
     if os.environ.get("GOLDEN_ONLY") == "g16":
         g16_sensitive_denoiser(asset, *syn.make_body_rep_stats(0))
         return
+    if os.environ.get("GOLDEN_ONLY") == "g17":
+        g17_partially_sensitive_denoiser(asset, *syn.make_body_rep_stats(0))
+        return
     g1_schedules()
     g2_g3_geometry()
     g4_gcn()
@@ -555,6 +575,7 @@ def main():
     g14_c4_c5_and_volsmpl(model, build_reference_model(sd, asset, mean, std, diffuse_fuse=True, volsmpl=True))
     g15_constructor_flags(asset, mean, std)
     g16_sensitive_denoiser(asset, mean, std)
+    g17_partially_sensitive_denoiser(asset, mean, std)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,14 @@ def test_bench_gpus_2_self_launches_two_ranks():
     assert "launching 2 ranks" in r.stderr
 
 
+def test_bench_gpus_8_launch_check():
+    """the shape of the driver's SCALE run: eight ranks rendezvous over 127.0.0.1 and agree on the world size"""
+    r = _run(["--gpus", "8", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8
+
+
 def test_bench_refuses_mismatched_world_size():
     r = _run(["--gpus", "2", "--launch-check"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0

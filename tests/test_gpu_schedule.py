@@ -204,3 +204,48 @@ def test_calibration_is_invalidated_by_a_weight_update(dev, model_base):
     with torch.no_grad():
         w.mul_(1.0)                                      # in-place update: same values, new version -> a different checkpoint as far as the cache knows
     assert fs.schedule_key(d, True, 0) != k0 and fs.schedule_key(d, True, 0) not in fs._sched_cache
+
+
+def _e2e_vs_golden(golden_dir, dev, model, name):
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device
+    g = _load(golden_dir, name)
+    B, N, n, rs = int(g["B"]), int(g["N"]), int(g["n"]), str(g["respacing"])
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+    b = batch_to_device(syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"])), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=int(g["noise_seed"]))).to(dev)
+    o = d.val_losses(model, b, shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False, noise_stack=noise)
+    return o, g, model.fused_sampler.schedule_info
+
+
+def test_mixed_schedule_on_partially_sensitive_weights_vs_reference_golden(golden_dir, dev, smpl_asset):
+    """A denoiser with low-noise gain d x0 / d x_t = 0.3: the calibration picks 0 < k < T, i.e. the loop really MIXES plain-f16 and split-f16
+    steps - and that loop is compared with the reference's own DDPM-100 on the same weights (golden G17), not only with the product's
+    all-split loop."""
+    from egohmr_amd.factory import build_synthetic_model
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=100, gain=0.3))
+    o, g, info = _e2e_vs_golden(golden_dir, dev, m, "g17_e2e_ddpm100_gain03")
+    assert info is not None and 0 < info["k"] < info["T"], info
+    assert m.fused_sampler.last_lowprec == info["T"] - info["k"] > 0
+    dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    print(f"[g17] gain 0.3: calibrated k = {info['k']} of {info['T']} at tol {info['tol_m']:g}; max|dverts| vs reference = {dv:.3e}")
+    _check_out(o, g)
+    # the contract's own bar (1e-4 m) allows a shorter split-f16 tail on these weights; it must still sit inside the bar against the REFERENCE
+    m.schedule_tol = 1e-4
+    o2, g2, info2 = _e2e_vs_golden(golden_dir, dev, m, "g17_e2e_ddpm100_gain03")
+    assert info2["tol_m"] == 1e-4 and info2["k"] <= info["k"]
+    dv2 = np.abs(o2["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    print(f"[g17] contract bar: k = {info2['k']}; max|dverts| vs reference = {dv2:.3e}")
+    _check_out(o2, g2)
+
+
+def test_contract_tol_schedule_on_sensitive_weights_vs_reference_golden(golden_dir, dev, smpl_asset):
+    """schedule_tol = 1e-4 m (the north-star bar itself; default 1e-5) on the trained-like weights against the reference golden G16."""
+    from egohmr_amd.factory import build_synthetic_model
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=100))
+    m.schedule_tol = 1e-4
+    o, g, info = _e2e_vs_golden(golden_dir, dev, m, "g16_e2e_ddpm100_sensitive")
+    assert info is not None and info["tol_m"] == 1e-4
+    dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    print(f"[g16 @ 1e-4] calibrated k = {info['k']} of {info['T']}; max|dverts| vs reference = {dv:.3e}")
+    _check_out(o, g)

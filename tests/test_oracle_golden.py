@@ -261,6 +261,18 @@ def test_g16_end_to_end_sensitive(golden_dir, sensitive_weights, smpl_asset, nam
     _check_out(o, g, atol=1e-4)
 
 
+def test_g17_end_to_end_gain03(golden_dir, smpl_asset):
+    """the oracle on the partially sensitive weights (low-noise gain 0.3) vs the reference's own DDPM-100 on them (golden G17: the
+    reference gate of a MIXED plain-f16 / split-f16 schedule, tests/test_gpu_schedule.py)."""
+    g = _load(golden_dir, "g17_e2e_ddpm100_gain03")
+    B, N, n, rs = int(g["B"]), int(g["N"]), int(g["n"]), str(g["respacing"])
+    b = _tt(syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"])))
+    tab = schedule.make_tables(n, rs)
+    noise = torch.from_numpy(syn.make_noise_stack(tab.num_timesteps, B, seed=int(g["noise_seed"])))
+    m = _model(syn.make_sensitive_state_dict(0, n, gain=float(g["gain"])), smpl_asset, faithful=False)
+    _check_out(sampler.val_losses(m, b, tab, noise, rs), g, atol=1e-4)
+
+
 def test_sensitive_weights_gain_profile(sensitive_weights, synth_weights, smpl_asset):
     """What the sensitive weights are FOR: d x0 / d x_t (directional, fp64 oracle) follows the MMSE gain of a Gaussian prior - a few
     percent at t ~ n, >= 0.8 for t <= 0.1 n - while the plain random network ignores x_t at every t (~0.05).  With gain -> 1 the

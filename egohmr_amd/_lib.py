@@ -74,7 +74,7 @@ class ConvX2Desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_rows", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
                 ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
-                ("w_scale", C.c_float)]
+                ("w_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class ItemPrepDesc(C.Structure):
@@ -153,6 +153,7 @@ PROTOTYPES = {
     "ehm_resnet_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ehm_conv_x2_rows": (C.c_int64, [C.c_int64]),
     "ehm_conv_x2": (_I, [C.POINTER(ConvX2Desc), _P]),
+    "ehm_conv_x2_workspace_bytes": (C.c_int64, [C.POINTER(ConvX2Desc)]),
     "ehm_x2_group_mean": (_I, [_P, _P, _I, _I, _I, _P]),
     "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
     "ehm_nonlocal_attention": (_I, [_P, _P, _L, _I, _P]),

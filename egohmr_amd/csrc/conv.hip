@@ -238,7 +238,14 @@ struct ConvX2Args {
   float inv_scale;
   long long M;
   unsigned int zero_off;       // float offset of the all-zero row of x
+  // stream-K (SK = true): the tiles' K tiles are dealt out to the blocks as ONE sequence in equal contiguous runs (pairs of K tiles), so a
+  // tile may be computed by two or three blocks; the block that holds a tile's FIRST K tiles finishes it (adds the others' partial sums in k
+  // order, epilogue), the others leave their accumulators in sk_part and count in sk_flags.
+  unsigned int* sk_flags;      // [tiles], zeroed by ehm_conv_x2
+  float* sk_part;              // [tiles][kSkMaxParts][acc floats per thread][256]
+  int sk_per;                  // pairs of K tiles per block
 };
+constexpr int kSkMaxParts = 3;
 
 template <int NU>
 struct XFrags {
@@ -247,7 +254,7 @@ struct XFrags {
 
 // NU = 2: 192 x 128 tiles (96 x 64 per wave); NU = 1: 192 x 64 tiles (96 x 32 per wave) for Co = 64 layers (no padding columns through
 // the matrix cores).
-template <int NU>
+template <int NU, bool SK>
 __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   constexpr int XBN = 64 * NU, XSTG = x_stage_floats(NU);
   __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 / 64 KiB; the ONLY LDS object
@@ -406,17 +413,44 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 
   if (blockIdx.x == 0)                                           // the output's own all-zero row (the next conv's out-of-image taps)
     for (int c = tid; c < p.Co; c += 256) ((float*)p.y)[(size_t)m_tiles * XBM * p.Co + c] = 0.f;
-  int it = 0, m, n;
-  if (!tile_of(0, m, n)) return;
-  set_tile(m, n);
+  // ---- work pieces: a whole tile (k0 = 0, k1 = KT), or with stream-K a contiguous run of K tiles of one tile
+  struct Piece { int m, n, k0, k1, tile; };
+  const int P2 = KT / 2;                                         // pairs of K tiles per tile (stream-K deals in pairs: every piece has >= 2 K tiles)
+  long long sk_cur = 0, sk_end = 0;
+  if constexpr (SK) {
+    const long long U2 = (long long)m_tiles * n_tiles * P2;
+    sk_cur = (long long)b * p.sk_per;
+    sk_end = sk_cur + p.sk_per < U2 ? sk_cur + p.sk_per : U2;
+  }
+  auto piece_of = [&](int it, Piece& o) -> bool {
+    if constexpr (SK) {
+      if (sk_cur >= sk_end) return false;
+      o.tile = (int)(sk_cur / P2);
+      const int kp0 = (int)(sk_cur % P2);
+      const long long left = sk_end - sk_cur;
+      const int kp1 = left < P2 - kp0 ? kp0 + (int)left : P2;
+      o.m = o.tile / n_tiles; o.n = o.tile % n_tiles;
+      o.k0 = 2 * kp0; o.k1 = 2 * kp1;
+      return true;
+    } else {
+      o.k0 = 0; o.k1 = KT; o.tile = 0;
+      return tile_of(it, o.m, o.n);
+    }
+  };
+  auto advance = [&](const Piece& o) { if constexpr (SK) sk_cur += (o.k1 - o.k0) / 2; };
+  int it = 0;
+  Piece pc;
+  if (!piece_of(0, pc)) return;
+  advance(pc);
+  set_tile(pc.m, pc.n);
 #pragma unroll
-  for (int i = 0; i < NBD; ++i) dma_b(0, 0, i);
+  for (int i = 0; i < NBD; ++i) dma_b(0, pc.k0, i);
 #pragma unroll
-  for (int i = 0; i < NBD; ++i) dma_b(1, 1, i);
+  for (int i = 0; i < NBD; ++i) dma_b(1, pc.k0 + 1, i);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+  for (int i = 0; i < 6; ++i) dma_a(0, pc.k0, i);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
+  for (int i = 0; i < 6; ++i) dma_a(1, pc.k0 + 1, i);
 
   while (true) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // everything but stage 1's six activation pieces (the last instructions issued)
@@ -437,25 +471,26 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     };
-    for (int kt = 0; kt < KT - 2; ++kt) {
-      const int buf = kt & 1;
+    const int KL = pc.k1 - pc.k0;                                // K tiles of this piece (>= 2)
+    for (int j = 0; j < KL - 2; ++j) {
+      const int buf = j & 1;
       first_phase(buf);
       read_frags(f0, buf ^ 1, 0);
-      stage(buf, kt + 2);
+      stage(buf, pc.k0 + j + 2);
       mfmas(f1);
       pin_reads_dma();
     }
     {
-      const int buf = (KT - 2) & 1;
+      const int buf = (KL - 2) & 1;
       first_phase(buf);
       read_frags(f0, buf ^ 1, 0);
       mfmas(f1);
       pin_reads();
     }
-    first_phase((KT - 1) & 1);
+    first_phase((KL - 1) & 1);
 
-    const int n0 = n * XBN;
-    const size_t row0 = (size_t)m * XBM;
+    const int n0 = pc.n * XBN;
+    const size_t row0 = (size_t)pc.m * XBM;
     const bool cols_live = n0 + 32 * NU * wn < p.Co;             // (NU = 2 with Co = 64: the upper column half of the tile is padding)
     float add[NU];
 #pragma unroll
@@ -465,22 +500,66 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     mfmas(f1);
-    int m_next, n_next;
-    const bool have_next = tile_of(it + 1, m_next, n_next);
+    Piece nx;
+    const bool have_next = piece_of(it + 1, nx);
     if (have_next) {
-      set_tile(m_next, n_next);
+      advance(nx);
+      set_tile(nx.m, nx.n);
 #pragma unroll
-      for (int i = 0; i < NBD; ++i) dma_b(0, 0, i);
+      for (int i = 0; i < NBD; ++i) dma_b(0, nx.k0, i);
 #pragma unroll
-      for (int i = 0; i < NBD; ++i) dma_b(1, 1, i);
+      for (int i = 0; i < NBD; ++i) dma_b(1, nx.k0 + 1, i);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dma_a(0, 0, i);
+      for (int i = 0; i < 6; ++i) dma_a(0, nx.k0, i);
+    }
+
+    // ---- stream-K hand-off.  A piece that does not start its tile leaves its accumulators for the block that does; the block that starts a
+    //      tile (always the LAST piece of its run) collects the later pieces - they were the FIRST pieces of their blocks' runs - in k order.
+    bool finish = true;
+    if constexpr (SK) {
+      constexpr int NACC = 3 * NU * 16;
+      const int owner = (int)(((long long)pc.tile * P2) / p.sk_per), last_blk = (int)(((long long)pc.tile * P2 + P2 - 1) / p.sk_per);
+      float* part = p.sk_part + (size_t)pc.tile * kSkMaxParts * NACC * 256;
+      if (pc.k0 != 0) {
+        finish = false;
+        float* mine = part + (size_t)(b - owner - 1) * NACC * 256 + tid;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[((t * NU + u) * 16 + r) * 256] = acc[t][u][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(p.sk_flags + pc.tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (last_blk > owner) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(last_blk - owner) && ++spins < (1 << 24))
+            __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        for (int q = 0; q < last_blk - owner; ++q) {
+          const float* theirs = part + (size_t)q * NACC * 256 + tid;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[t][u][r] += theirs[((t * NU + u) * 16 + r) * 256];
+        }
+      }
     }
 
     // Epilogue per wave through its six 1 KiB pieces of stage 1's activation region.  Accumulator register r of acc[t][u] is row
     // 32 t + 8 (r >> 2) + 4 g + (r & 3): row groups Gq = 4 t + (r >> 2) of 8 rows.  NU = 2: a pass turns 3 groups x 64 columns (piece
     // 2 gi + u), 4 passes; NU = 1: 6 groups x 32 columns (piece gi), 2 passes.  Read items = (row, 8 columns), three per lane.
-    if (cols_live) {
+    if (cols_live && finish) {
       constexpr int GP = NU == 2 ? 3 : 6, NPASS = 12 / GP;       // row groups per pass
       const unsigned int yrow = (unsigned int)p.Co * 4u;
       const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(p.y + (row0 + 96 * wm) * (size_t)yrow);
@@ -554,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     }
     if (!have_next) break;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dma_a(1, 1, i);
-    m = m_next; n = n_next; ++it;
+    for (int i = 0; i < 6; ++i) dma_a(1, nx.k0 + 1, i);
+    pc = nx; ++it;
   }
 }
 
@@ -592,6 +671,39 @@ extern "C" int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream) {
 
 extern "C" int64_t ehm_conv_x2_rows(int64_t pixels) { return round_up(pixels, XBM) + 1; }
 
+namespace {
+// stream-K plan of a conv: used when whole tiles would leave more than ~1/8 of the block slots idle in the last round (e.g. 524 tiles on
+// 512 slots: two rounds for 1.02 rounds of work) and the K loop is long enough to deal out in runs
+struct SkPlan { bool on; int per; int64_t tiles, flag_bytes, bytes; int nacc; };
+SkPlan sk_plan(const ehm_conv_x2_desc* d, int Ho, int Wo) {
+  SkPlan s{};
+  const int64_t M = (int64_t)d->N * Ho * Wo, slots = 2 * (int64_t)ehm_num_cus();
+  const bool narrow = d->Co % 128 != 0;
+  const int KT = d->KH * d->KW * (d->Ci / XRK);
+  s.tiles = ceil_div(M, XBM) * ceil_div(d->Co, narrow ? 64 : 128);
+  s.nacc = 3 * (narrow ? 1 : 2) * 16;
+  const int64_t rounds = ceil_div(s.tiles, slots);
+  const double eff = (double)s.tiles / (double)(rounds * slots);
+  // (K loops shorter than 64 K tiles: measured slower - the 96 KiB partial-sum hand-off of a cut tile costs more than the idle slots)
+  if (KT % 2 != 0 || KT < 64 || eff >= 0.875 || s.tiles < slots / 2 || getenv("EHM_CONV_NO_STREAMK")) return s;
+  const int P2 = KT / 2;
+  const int64_t U2 = s.tiles * P2;
+  s.per = (int)ceil_div(U2, slots);
+  if (s.per < 2 || ceil_div(P2, s.per) > kSkMaxParts) return s;
+  s.on = true;
+  s.flag_bytes = round_up(s.tiles * 4, 256);
+  s.bytes = s.flag_bytes + s.tiles * kSkMaxParts * s.nacc * 256 * 4;
+  return s;
+}
+}  // namespace
+
+extern "C" int64_t ehm_conv_x2_workspace_bytes(const ehm_conv_x2_desc* d) {
+  if (!d || d->Ci <= 0 || d->Co <= 0 || d->KH <= 0 || d->KW <= 0 || (d->stride != 1 && d->stride != 2)) return 0;
+  const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Wd + 2 * d->pad - d->KW) / d->stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  return sk_plan(d, Ho, Wo).bytes;
+}
+
 extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   EHM_CHECK_ARG(d && d->x && d->W && d->y);
   EHM_CHECK_ARG(d->N > 0 && d->H > 0 && d->Wd > 0 && d->Ci > 0 && d->Co > 0 && d->Ci % XRK == 0 && d->Co % 32 == 0);
@@ -619,9 +731,23 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   const int64_t slots = 2 * (int64_t)ehm_num_cus();
   const bool narrow = d->Co % 128 != 0;
   const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(d->Co, narrow ? 64 : 128);
+  const SkPlan sk = sk_plan(d, Ho, Wo);
+  a.sk_flags = nullptr; a.sk_part = nullptr; a.sk_per = 0;
+  if (sk.on && d->workspace && d->workspace_bytes >= sk.bytes) {
+    // stream-K: every slot gets the same number of K tiles; a tile cut by a run boundary is finished by the block that started it
+    a.sk_flags = (unsigned int*)d->workspace;
+    a.sk_part = (float*)((char*)d->workspace + sk.flag_bytes);
+    a.sk_per = sk.per;
+    EHM_HIP(hipMemsetAsync(a.sk_flags, 0, (size_t)sk.flag_bytes, (hipStream_t)stream));
+    const int64_t blocks = ceil_div(tiles * (d->KH * d->KW * (d->Ci / XRK) / 2), (int64_t)sk.per);
+    if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    EHM_LAUNCH_CHECK();
+    return 0;
+  }
   const int64_t blocks = tiles < slots ? tiles : slots;
-  if (narrow) hipLaunchKernelGGL(conv_x2_tile_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv_x2_tile_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((conv_x2_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -87,6 +87,7 @@ class ResNet50Features(nn.Module):
                 blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), fold(blk.conv3, blk.bn3),
                                fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
         packed = {}
+        sk_ws = {}                                         # device -> scratch of the stream-K convs (one conv at a time on a stream)
 
         def pack(p):
             """weights [Co,Ci,KH,KW] -> tap-major [Co_pad, KH*KW*Ci] X2 split format, scaled by a power of two"""
@@ -148,7 +149,13 @@ class ResNet50Features(nn.Module):
             Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
             y = x2_buffer(N * Ho * Wo, Co, x.device)
             d = _lib.ConvX2Desc(x.data_ptr(), x.shape[0], buf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
-                                N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale)
+                                N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale, None, 0)
+            need = int(_lib.lib().ehm_conv_x2_workspace_bytes(C.byref(d)))      # stream-K scratch (layers 3 / 4: tile counts that straddle the block slots)
+            if need:
+                ws = sk_ws.get(str(x.device))
+                if ws is None or ws.numel() < need:
+                    ws = sk_ws[str(x.device)] = torch.empty(need, dtype=torch.uint8, device=x.device)
+                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
             _lib.check(_lib.lib().ehm_conv_x2(C.byref(d), _lib.stream_ptr()), "ehm_conv_x2")
             if _x2_debug_hook is not None:
                 _x2_debug_hook(y, Co)

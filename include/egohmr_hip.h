@@ -255,8 +255,14 @@ typedef struct ehm_conv_x2_desc {
   int N, H, Wd, Ci, Co;
   int KH, KW, stride, pad, relu;
   float w_scale;
+  void* workspace;           /* ehm_conv_x2_workspace_bytes(d) bytes of device scratch, or NULL (then whole tiles only) */
+  int64_t workspace_bytes;
 } ehm_conv_x2_desc;
 int64_t ehm_conv_x2_rows(int64_t pixels);
+/* Scratch of the stream-K schedule: when a conv's tile count would leave a large share of the GPU's block slots idle in its last round
+ * (ResNet-50 layers 3 / 4 at B = 256: 524 or 264 tiles on 512 slots), the tiles' K loops are dealt out to the blocks in equal runs and a tile
+ * cut by a run boundary is finished by the block that started it (fixed summation order: deterministic).  0 = the conv runs whole tiles. */
+int64_t ehm_conv_x2_workspace_bytes(const ehm_conv_x2_desc* d);
 int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream);
 /* Y[g, c] = mean over the rows_per_group consecutive rows of group g of the X2 matrix X [groups*rows_per_group (+ padding), C]:
  * the global average pool behind the last bottleneck (models/resnet.py:148-149). */

@@ -540,6 +540,9 @@ def test_skinny_gemm_f32_vs_torch_fp64(dev, shape):
     (2, 15, 15, 64, 128, 3, 2, False, False),  # stride 2, odd size, no ReLU
     (5, 8, 8, 128, 256, 1, 2, True, True),     # strided 1x1 (downsample), two 128-wide column tiles, 80 rows
     (1, 20, 20, 32, 128, 3, 1, True, True),    # M = 400: three row tiles, ragged tail
+    (18, 56, 56, 256, 128, 3, 1, True, True),  # 294 tiles on 512 block slots, 72 K tiles: the STREAM-K schedule (K tiles dealt out in runs, tiles cut by a run boundary summed in k order)
+    (5, 56, 56, 64, 64, 3, 1, False, True),    # the same with 64-wide column tiles (Co = 64): 82 row tiles x 1 ... whole tiles (too few for stream-K)
+    (40, 28, 28, 128, 64, 1, 1, True, False),  # stream-K with the narrow tile: 164 x 1 ... whole tiles; kept as a shape check
 ])
 def test_conv_x2_vs_torch_fp64(dev, case):
     """ehm_conv_x2 (torchvision Bottleneck convs on X2 activations, models/resnet.py:139-150 via egohmr.py:183) against torch float64
@@ -583,7 +586,12 @@ def test_conv_x2_vs_torch_fp64(dev, case):
     rows_out = int(L.ehm_conv_x2_rows(N * Ho * Wo))
     y = torch.full((rows_out, Co), float("nan"), device=dev)
     d = _lib.ConvX2Desc(xd.data_ptr(), xd.shape[0], wbuf.data_ptr(), bd.data_ptr(), rd.data_ptr() if has_res else None, y.data_ptr(),
-                        N, H, W, Ci, Co, k, k, stride, pad, int(relu), scale)
+                        N, H, W, Ci, Co, k, k, stride, pad, int(relu), scale, None, 0)
+    need = int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))
+    assert (need > 0) == (case[0] == 18), need                    # only the 294-tile case qualifies for stream-K
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    if need:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
     _lib.check(L.ehm_conv_x2(C.byref(d), None), "ehm_conv_x2")
     out = torch.empty(rows_out, Co, device=dev)
     _lib.check(L.ehm_gcn_unpack_activations(y.data_ptr(), out.data_ptr(), rows_out, Co, 32, None))

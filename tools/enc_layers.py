@@ -70,7 +70,11 @@ for name, Hin, Ci, Co, k, s, has_res in convs:
         res = x2_random(rout, Co) if has_res else None
         y = torch.empty(rout, Co, device=dev)
         d = _lib.ConvX2Desc(x.data_ptr(), rin, buf.data_ptr(), bias.data_ptr(), res.data_ptr() if has_res else None, y.data_ptr(),
-                            B, Hin, Hin, Ci, Co, k, k, s, pad, 1, 1024.0)
+                            B, Hin, Hin, Ci, Co, k, k, s, pad, 1, 1024.0, None, 0)
+        need = int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))           # stream-K scratch (EHM_CONV_NO_STREAMK=1: whole tiles only)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        if need:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), need
         call = lambda: _lib.check(L.ehm_conv_x2(C.byref(d), None))
     else:
         x = torch.randn(B, Hin, Hin, Ci, device=dev)

@@ -158,8 +158,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     model = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=sens)
     model.lbs_every_step = not args.no_lbs_every_step
     model.gcn_precision = args.precision
-    if os.environ.get("EHM_NO_ENGINE"):
-        model.loop_engine = False
+    if os.environ.get("EHM_LOOP_ENGINE"):        # measurement aid: the one-launch sampling loop (opt-in; measured slower)
+        model.loop_engine = os.environ["EHM_LOOP_ENGINE"] not in ("0", "")
     if args.f16x3_last_steps is not None:
         model.f16x3_last_steps = int(args.f16x3_last_steps)
     diffusion = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)

@@ -12,7 +12,7 @@ timeout 300 python bench.py --workload c2_ddim10 --cpu-seconds 0 > $O/bench_c2_d
 timeout 400 python bench.py --workload c3_guided --cpu-seconds 0 --steps 2 > $O/bench_c3_guided.json 2>> $O/bench_ddpm100.err; tail -1 $O/bench_c3_guided.json | cut -c1-200
 timeout 300 python bench.py --weights insensitive --cpu-seconds 0 --no-legs > $O/bench_ddpm100_insensitive_weights.json 2>> $O/bench_ddpm100.err; tail -1 $O/bench_ddpm100_insensitive_weights.json | cut -c1-200
 cd /tmp
-MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-legs --f16x3-last-steps $(python -c "import json,sys; print(json.loads(open(\"$O/bench_ddpm100.json\").read().strip().splitlines()[-1])[\"schedule\"][\"f16x3_last_steps\"])") > $O/bench_ddpm100_under_rocprof.json 2> $O/rocprof.err
+MIOPEN_FIND_MODE=FAST timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-legs --no-configs --f16x3-last-steps $(python -c "import json,sys; print(json.loads(open(\"$O/bench_ddpm100.json\").read().strip().splitlines()[-1])[\"schedule\"][\"f16x3_last_steps\"])") > $O/bench_ddpm100_under_rocprof.json 2> $O/rocprof.err
 tail -1 $O/bench_ddpm100_under_rocprof.json | cut -c1-200
 python $R/tools/kstats.py $O/kt 40
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_ddpm100_kernel_stats.csv

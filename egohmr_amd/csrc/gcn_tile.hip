@@ -89,6 +89,8 @@ struct ChainArgs {
   unsigned int* sticky;     // never cleared by a launch: accumulates err over a whole sampling loop (ehm_gcn_stack_status)
   unsigned int* finished;   // blocks that ran out of tickets; the last one audits done[nl-1][*]
   int nq;                   // queues = XCDs
+  int slab_groups;          // 1: a queue's tickets run (layer, row tile, channel tile); g > 1 (measurement, EHM_CHAIN_SLAB_GROUPS): (layer, channel-tile
+                            // group, row tile, channel tile in the group) - a group's 1/g of the layer's weight slab is shared by all row tiles in flight
 };
 
 // The one-launch sampling loop (MODE 2 of run_tiles): `nsteps` consecutive unguided denoising steps of ONE precision in a single persistent
@@ -558,8 +560,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       o.step = (int)(v >> 40);
     } else if constexpr (CHAIN) {
       const int layer = (int)(t / ipl), r = (int)(t % ipl);
-      o.m_tile = (int)q + a.nq * (r / a.n_tiles);
-      o.n_tile = r % a.n_tiles;
+      if (a.slab_groups > 1) {
+        const int per = (int)ipl / a.slab_groups, nt = a.n_tiles / a.slab_groups, grp = r / per, rr = r % per;
+        o.m_tile = (int)q + a.nq * (rr / nt);
+        o.n_tile = grp * nt + rr % nt;
+      } else {
+        o.m_tile = (int)q + a.nq * (r / a.n_tiles);
+        o.n_tile = r % a.n_tiles;
+      }
       o.layer = layer;
       o.kind = K_HIDDEN; o.step = 0;
     }
@@ -1288,6 +1296,11 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   a.nq = ehm_num_cus() / 32;
   if (a.nq < 1) a.nq = 1;
   if (a.nq > 8) a.nq = 8;
+  a.slab_groups = 1;
+  if (const char* e = getenv("EHM_CHAIN_SLAB_GROUPS")) {      // measurement switch (DESIGN 3.2 "slab order"): results are the same bits either way
+    const int g = atoi(e);
+    if (g > 1 && n_tiles % g == 0) a.slab_groups = g;
+  }
   if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 4>), dim3(blocks), dim3(256), 0, st, a);
   else if (wide) hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 8>), dim3(blocks), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 4>), dim3(blocks), dim3(256), 0, st, a);
@@ -1344,6 +1357,7 @@ int ehm_gcn_tile_loop_impl(ehm_gcn* h, const ehm_loop_launch* L, hipStream_t st)
   a.c.nq = ehm_num_cus() / 32;
   if (a.c.nq < 1) a.c.nq = 1;
   if (a.c.nq > 8) a.c.nq = 8;
+  a.c.slab_groups = 1;
   a.nsteps = L->nsteps; a.passes = L->passes; a.ngroups = ngroups; a.ny = (int)ceil_div(h->hid, 256);
   LoopExtra e{};
   e.in = *L->in;

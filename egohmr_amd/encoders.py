@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+
 
 # measurement hook (tools/exp_encoder_precision.py): called with every X2 activation buffer an encoder kernel has just written, (buffer, channels).
 # None on the product path.
@@ -35,10 +37,8 @@ class _Bottleneck(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(width * 4))
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+        raise _lib.EgoHMRHipError("_Bottleneck is a parameter container: the arithmetic runs in ResNet50Features.folded() (csrc/conv.hip); "
+                                  "egohmr_amd has no eager / CPU route (tools/_eager.py holds the eager yardstick)")
 
 
 class ResNet50Features(nn.Module):
@@ -56,10 +56,18 @@ class ResNet50Features(nn.Module):
                 cin = width * 4
             setattr(self, f"layer{i}", nn.Sequential(*blocks))
 
+    def current(self):
+        """folded() for the weights as they are now: rebuilt when a parameter / buffer changes (storage or version counter)."""
+        if getattr(self, "_fold_key_fn", None) is None:
+            self._fold_key_fn = _lib.TensorKey(self)
+        key = self._fold_key_fn()
+        if getattr(self, "_fold_key", None) != key:
+            self._fold_fn, self._fold_key = self.folded(), key
+        return self._fold_fn
+
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        return x.mean(dim=(2, 3))
+        """The module call IS the HIP path (models/resnet.py:139-150 in eval mode); there is no eager route."""
+        return self.current()(x)
 
     # ------------------------------------------------------------------ inference form: BatchNorm folded into the convolutions
     @torch.no_grad()
@@ -201,7 +209,7 @@ class _ResBlockFC(nn.Module):
         self.shortcut = nn.Linear(cin, cout, bias=False)
 
     def forward(self, x):
-        return self.shortcut(x) + self.fc_1(F.relu(self.fc_0(F.relu(x))))
+        raise _lib.EgoHMRHipError("_ResBlockFC is a parameter container: ResnetPointnet.forward runs the block on the HIP kernels (csrc/linear.hip)")
 
 
 class ResnetPointnet(nn.Module):

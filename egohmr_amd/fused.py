@@ -126,13 +126,7 @@ class FusedSampler:
 
     def _backbone_fn(self):
         """ResNet-50 with BatchNorm folded into the convolutions, rebuilt when the backbone weights change."""
-        bb = self.model.backbone
-        if getattr(self, "_bbk", None) is None or self._bbk.modules[0] is not bb:
-            self._bbk = _lib.TensorKey(bb)
-        key = self._bbk()
-        if getattr(self, "_bb_key", None) != key:
-            self._bb_fn, self._bb_key = bb.folded(), key
-        return self._bb_fn
+        return self.model.backbone.current()
 
     # ------------------------------------------------------------------ step-invariant conditioning
     @torch.no_grad()

@@ -89,3 +89,51 @@ def test_resnet_activation_offsets_beyond_2_gib(dev, synth_weights):
     torch.cuda.empty_cache()
     with pytest.raises(_lib.EgoHMRHipError):
         fwd(torch.zeros(1400, 3, 224, 224, device=dev))
+
+
+def test_timestep_vectors_against_the_reference_embedding(dev, model, golden_dir):
+    """Product side of G5 (models/egohmr/egohmr.py:642-643 TimestepEmbedder, generated by importing the reference): the module's
+    embedding itself, and FusedSampler.timestep_vectors = that embedding through the timestep slice of the folded input conv -
+    for a tensor of timesteps, for a python list (the cached route the sampling loop takes) and for the cache hit."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g5_timestep_embed.npz"))
+    t = torch.from_numpy(g["t"]).to(dev)
+    with torch.no_grad():
+        emb = model.embed_timestep.time_embed(model.sequence_pos_encoder.pe[t][:, 0])
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"].reshape(len(g["t"]), -1), atol=1e-6)
+    fs = model.fused_sampler
+    fs.gcn()
+    want = (torch.einsum("ne,kef->nkf", torch.from_numpy(g["emb"].reshape(len(g["t"]), -1)).to(dev).double(), fs._folded.W_t) + fs._folded.bx[None]).float()
+    tv = fs.timestep_vectors(t)
+    tl = fs.timestep_vectors([int(v) for v in g["t"]])
+    again = fs.timestep_vectors([int(v) for v in g["t"]])
+    scale = float(want.abs().max())
+    assert float((tv - want).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert torch.equal(tl, tv) and again is tl                       # the list route is the same arithmetic, then a cache hit
+    other = fs.timestep_vectors([0, 1])
+    assert other.shape[0] == 2 and torch.equal(other, tv[:2])        # a different sequence replaces the cache entry
+
+
+def test_module_calls_are_the_hip_path(dev, model, golden_dir):
+    """model.backbone(img) and model.scene_enc(pts) run the HIP kernels (G6 from the reference); the parameter containers below them refuse
+    to run eager arithmetic, and CPU tensors are refused - there is no second implementation to fall into."""
+    import os
+    from egohmr_amd import _lib
+    g = np.load(os.path.join(golden_dir, "g6_resnet50.npz"))
+    rng = np.random.Generator(np.random.PCG64(int(g["img_seed"])))
+    rng.uniform(-1, 1, size=(2, 257, 3))
+    img = torch.from_numpy(rng.normal(size=(2, 3, 224, 224)).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        out = model.backbone(img)
+    np.testing.assert_allclose(out.cpu().numpy(), g["feat"], atol=3e-5)
+    assert model.backbone.current() is model.fused_sampler._backbone_fn()          # one packed copy of the weights
+    with pytest.raises(_lib.EgoHMRHipError):
+        model.backbone(img.cpu())
+    with pytest.raises(_lib.EgoHMRHipError):
+        model.backbone.layer1[0](torch.zeros(1, 64, 56, 56, device=dev))
+    with pytest.raises(_lib.EgoHMRHipError):
+        model.scene_enc.block_0(torch.zeros(1, 8, 256, device=dev))
+    p = np.load(os.path.join(golden_dir, "g6_pointnet.npz"))
+    with torch.no_grad():
+        c = model.scene_enc(torch.from_numpy(p["pts"]).to(dev))
+    np.testing.assert_allclose(c.cpu().numpy(), p["feat"], atol=2e-5)

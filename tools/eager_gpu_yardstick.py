@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egohmr_amd import synthetic as syn  # noqa: E402
 from egohmr_amd.diffusion import create_gaussian_diffusion  # noqa: E402
 from egohmr_amd.factory import batch_to_device, build_synthetic_model  # noqa: E402
+from _eager import resnet50_eager  # noqa: E402
 
 dev = torch.device("cuda:0")
 steps_timed = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -66,7 +67,7 @@ def pointnet(pts, p="scene_enc."):                           # respointnet.py:33
 
 
 def encode(batch):                                           # egohmr.py:182-223
-    img_feats = model.backbone(batch["img"])                 # ResNet50Features.forward = plain eager torch (MIOpen)
+    img_feats = resnet50_eager(model.backbone, batch["img"])   # plain eager torch (MIOpen): tools/_eager.py
     transl = batch["smpl_params"]["transl"]
     scene_feats = pointnet(batch["scene_pcd_verts_full"] - transl.unsqueeze(1))
     tf = F.linear(transl, sd["transl_enc.0.weight"], sd["transl_enc.0.bias"]) if "transl_enc.0.weight" in sd else model.transl_enc(transl)

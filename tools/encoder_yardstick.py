@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egohmr_amd.encoders import ResNet50Features, ResnetPointnet  # noqa: E402
+from _eager import resnet50_eager  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, N = 256, 4096
@@ -53,13 +54,13 @@ with torch.no_grad():
     rn_cl = ResNet50Features().to(dev).eval().to(memory_format=torch.channels_last)
     rn_cl.load_state_dict(rn.state_dict())
     ours = rn.folded()
-    ref = rn(img)
+    ref = resnet50_eager(rn, img)
     err = float((ours(img) - ref).abs().max() / ref.abs().max())
     rows = [("resnet50 B256: this package (split-f16 X2 trunk, f32-grade)", timed(lambda: ours(img))),
-            ("resnet50 B256: eager float32 NCHW (MIOpen)", timed(lambda: rn(img))),
-            ("resnet50 B256: eager float32 channels_last (MIOpen)", timed(lambda: rn_cl(img_cl)))]
+            ("resnet50 B256: eager float32 NCHW (MIOpen)", timed(lambda: resnet50_eager(rn, img))),
+            ("resnet50 B256: eager float32 channels_last (MIOpen)", timed(lambda: resnet50_eager(rn_cl, img_cl)))]
     with torch.autocast("cuda", dtype=torch.float16):
-        rows.append(("resnet50 B256: eager float16 autocast channels_last (MIOpen; not f32-grade)", timed(lambda: rn_cl(img_cl))))
+        rows.append(("resnet50 B256: eager float16 autocast channels_last (MIOpen; not f32-grade)", timed(lambda: resnet50_eager(rn_cl, img_cl))))
     for name, ms in rows:
         print(json.dumps({"what": name, "ms": round(ms, 3), "ours_vs_eager_f32_rel_err": err}), flush=True)
     pn = ResnetPointnet().to(dev).eval()

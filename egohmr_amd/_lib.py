@@ -74,7 +74,8 @@ class ConvX2Desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_rows", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
                 ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
-                ("w_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("w_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("x2", C.c_void_p), ("x2_rows", C.c_int64), ("H2", C.c_int), ("W2", C.c_int), ("Ci2", C.c_int), ("stride2", C.c_int)]
 
 
 class ItemPrepDesc(C.Structure):

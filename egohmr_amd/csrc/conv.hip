@@ -244,6 +244,12 @@ struct ConvX2Args {
   unsigned int* sk_flags;      // [tiles], zeroed by ehm_conv_x2
   float* sk_part;              // [tiles][kSkMaxParts][acc floats per thread][256]
   int sk_per;                  // pairs of K tiles per block
+  // second K segment (DS = true): a 1 x 1 convolution of ANOTHER tensor x2 [N, H2, W2, Ci2] with stride stride2, accumulated into the same
+  // output - a bottleneck's projection shortcut inside its last conv (torchvision Bottleneck.forward: out = conv3(.) + downsample(x)): the
+  // weights are [W | W2] along K, the K tiles past the first segment gather x2's pixels (2 stride2 ho, stride2 wo)
+  const float* x2;
+  int H2, W2, Ci2, stride2;
+  unsigned int zero_off2;
 };
 constexpr int kSkMaxParts = 3;
 
@@ -254,16 +260,18 @@ struct XFrags {
 
 // NU = 2: 192 x 128 tiles (96 x 64 per wave); NU = 1: 192 x 64 tiles (96 x 32 per wave) for Co = 64 layers (no padding columns through
 // the matrix cores).
-template <int NU, bool SK>
+template <int NU, bool SK, bool DS = false>
 __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
+  static_assert(!(SK && DS), "the dual-source conv runs whole tiles");
   constexpr int XBN = 64 * NU, XSTG = x_stage_floats(NU);
   __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 / 64 KiB; the ONLY LDS object
 
   constexpr int KS = 2, NM = 9 * NU, NR = 6 + 2 * NU, NBD = 2 * NU;
   const int tid = threadIdx.x;
-  const int K = p.KH * p.KW * p.Ci;
+  const int K = p.KH * p.KW * p.Ci + (DS ? p.Ci2 : 0);
   const int cpt = p.Ci / XRK;                    // K tiles per tap
-  const int KT = p.KH * p.KW * cpt;
+  const int KT1 = p.KH * p.KW * cpt;             // K tiles of the first segment
+  const int KT = KT1 + (DS ? p.Ci2 / XRK : 0);
   const int n_tiles = (p.Co + XBN - 1) / XBN;
   const int m_tiles = (int)((p.M + XBM - 1) / XBM);
 
@@ -312,6 +320,8 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   // offset per lane and piece (the gathered pixel, or the zero row), the weights' piece in the scalar offset
   unsigned int pbase[6];        // byte offset (mod 2^32: border pixels start below zero) of the (kh = 0, kw = 0) tap pixel's channel 0 + my swizzled chunk
   unsigned int pmask[6];
+  [[maybe_unused]] unsigned int pbase2[6];   // DS: byte offset of my rows' pixels in x2 (or its zero row)
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsX2 = ehm_buffer_rsrc_4g(DS ? p.x2 : p.x);
   const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(p.x);      // lane offsets address the whole activation tensor (< 2^30 elements = 4 GiB, checked by ehm_conv_x2)
   __amdgpu_buffer_rsrc_t rsB;
   int voB;
@@ -323,8 +333,10 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
       const long long gm = (long long)m * XBM + r0 + 32 * i;
       pmask[i] = 0u;
       pbase[i] = 0u;
+      if constexpr (DS) pbase2[i] = (p.zero_off2 + (unsigned int)swz) * 4u;
       if (gm < p.M) {
         const int nimg = (int)(gm / hw), rem = (int)(gm % hw);
+        if constexpr (DS) pbase2[i] = (unsigned int)(((nimg * p.H2 + (rem / p.Wo) * p.stride2) * p.W2 + (rem % p.Wo) * p.stride2) * p.Ci2 + swz) * 4u;
         const int hi0 = (rem / p.Wo) * p.stride - p.pad, wi0 = (rem % p.Wo) * p.stride - p.pad;
         pbase[i] = (unsigned int)(((nimg * p.H + hi0) * p.Wd + wi0) * p.Ci + swz) * 4u;
         for (int kh = 0; kh < p.KH; ++kh)
@@ -336,6 +348,12 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     voB = (r0 * K + swz) * 4;
   };
   auto dma_a = [&](int buf, int kt, int i) {
+    if constexpr (DS) {
+      if (kt >= KT1) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (AS3 void*)(lds + buf * XSTG + (wave + 4 * i) * 256), 16, (int)pbase2[i], (kt - KT1) * XRK * 4, 0, 0);
+        return;
+      }
+    }
     const int tap = kt / cpt, cg = kt - tap * cpt;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const unsigned int toff = (unsigned int)((kh * p.Wd + kw) * p.Ci + cg * XRK) * 4u;   // (wave-uniform, bytes)
@@ -685,7 +703,7 @@ SkPlan sk_plan(const ehm_conv_x2_desc* d, int Ho, int Wo) {
   const int64_t rounds = ceil_div(s.tiles, slots);
   const double eff = (double)s.tiles / (double)(rounds * slots);
   // (K loops shorter than 64 K tiles: measured slower - the 96 KiB partial-sum hand-off of a cut tile costs more than the idle slots)
-  if (KT % 2 != 0 || KT < 64 || eff >= 0.875 || s.tiles < slots / 2 || getenv("EHM_CONV_NO_STREAMK")) return s;
+  if (d->x2 != nullptr || KT % 2 != 0 || KT < 64 || eff >= 0.875 || s.tiles < slots / 2 || getenv("EHM_CONV_NO_STREAMK")) return s;
   const int P2 = KT / 2;
   const int64_t U2 = s.tiles * P2;
   s.per = (int)ceil_div(U2, slots);
@@ -711,6 +729,16 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   EHM_CHECK_ARG(d->w_scale > 0.f);
   const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Wd + 2 * d->pad - d->KW) / d->stride + 1;
   EHM_CHECK_ARG(Ho > 0 && Wo > 0 && d->KH * d->KW * (d->Ci / XRK) >= 2);
+  const bool dual = d->x2 != nullptr;
+  if (dual) {
+    EHM_CHECK_ARG(d->Ci2 > 0 && d->Ci2 % XRK == 0 && (d->stride2 == 1 || d->stride2 == 2) && d->H2 > 0 && d->W2 > 0 && d->Co % 128 == 0);
+    EHM_CHECK_ARG((d->H2 - 1) / d->stride2 + 1 == Ho && (d->W2 - 1) / d->stride2 + 1 == Wo);
+    if (d->x2_rows < ehm_conv_x2_rows((int64_t)d->N * d->H2 * d->W2) || d->x2_rows * d->Ci2 >= ((int64_t)1 << 30)) {
+      ehm_set_error("ehm_conv_x2: x2_rows = %lld, need ehm_conv_x2_rows(N*H2*W2) = %lld rows and x2 below 2^30 elements", (long long)d->x2_rows,
+                    (long long)ehm_conv_x2_rows((int64_t)d->N * d->H2 * d->W2));
+      return EHM_EINVAL;
+    }
+  }
   const int64_t in_rows = (int64_t)d->N * d->H * d->Wd;
   if (d->x_rows < ehm_conv_x2_rows(in_rows) || (d->x_rows * d->Ci) >= ((int64_t)1 << 30) ||       // (32-bit BYTE offsets into x: the operand pieces use buffer addressing)
       ehm_conv_x2_rows((int64_t)d->N * Ho * Wo) * d->Co >= ((int64_t)1 << 31)) {
@@ -725,6 +753,8 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   a.inv_scale = 1.f / d->w_scale;
   a.M = (long long)d->N * Ho * Wo;
   a.zero_off = (unsigned int)((d->x_rows - 1) * d->Ci);
+  a.x2 = (const float*)d->x2; a.H2 = d->H2; a.W2 = d->W2; a.Ci2 = dual ? d->Ci2 : 0; a.stride2 = d->stride2;
+  a.zero_off2 = dual ? (unsigned int)((d->x2_rows - 1) * d->Ci2) : 0u;
   // 64-wide column tiles only when Co is not a multiple of 128 (Co = 64: no padding columns through the matrix cores; 0.42 -> 0.29 ms
   // on the 3x3 convs of layer 1).  For layer 4's 264-tile convs they LOSE although they would give every CU two blocks (0.26 ->
   // 0.31 ms): a 96 x 32 wave tile reads 8 fragments per 9 MFMAs.
@@ -746,7 +776,8 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
     return 0;
   }
   const int64_t blocks = tiles < slots ? tiles : slots;
-  if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (dual) hipLaunchKernelGGL((conv_x2_tile_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((conv_x2_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;

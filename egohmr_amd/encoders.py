@@ -71,7 +71,7 @@ class ResNet50Features(nn.Module):
 
     # ------------------------------------------------------------------ inference form: BatchNorm folded into the convolutions
     @torch.no_grad()
-    def folded(self, x2_activations: bool = True):
+    def folded(self, x2_activations: bool = True, fuse_shortcut: bool = True):
         """Eval-mode ResNet-50 on the matrix cores with every BatchNorm2d folded into its convolution (w' = w * g/sqrt(v+eps),
         b' = beta - mean * g/sqrt(v+eps); exact up to float re-association).  x2_activations=True (the product path): the activations
         stay in the X2 split format from the stem to the average pool (ehm_conv_x2); False: float32 NHWC activations between the
@@ -150,14 +150,38 @@ class ResNet50Features(nn.Module):
                 _x2_debug_hook(y, 64)
             return y
 
-        def conv_x2(x, shape, p, res=None, relu=True):
-            """one bottleneck conv on X2 activations (csrc/conv.hip conv_x2_tile_kernel); shape = (N, H, W) of x"""
-            buf, scale, bias, (Co, Ci, KH, KW), stride, pad = pack(p)
+        def pack_dual(p, ds):
+            """a bottleneck's last conv and its projection shortcut as ONE weight matrix [Co_pad, Ci + Ci_in] (both 1 x 1), common scale, summed bias"""
+            key = (id(p[0]), id(ds[0]))
+            if key in packed:
+                return packed[key]
+            w, wd = p[0], ds[0]
+            Co, Ci = w.shape[:2]
+            assert w.shape[2:] == (1, 1) and wd.shape[2:] == (1, 1) and wd.shape[0] == Co and Co % 128 == 0
+            K = Ci + wd.shape[1]
+            w2 = torch.cat([w.reshape(Co, Ci), wd.reshape(Co, -1)], dim=1).contiguous()
+            amax = float(w2.abs().max())
+            scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
+            buf = torch.empty(Co, K, device=w.device)
+            _lib.check(_lib.lib().ehm_split_pack(w2.data_ptr(), buf.data_ptr(), Co, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
+            packed[key] = (buf, scale, (p[1].double() + ds[1].double()).float().contiguous(), (Co, Ci, 1, 1), p[2][0], p[3][0], wd.shape[1], ds[2][0])
+            return packed[key]
+
+        def conv_x2(x, shape, p, res=None, relu=True, shortcut=None):
+            """one bottleneck conv on X2 activations (csrc/conv.hip conv_x2_tile_kernel); shape = (N, H, W) of x.
+            shortcut = (block input, its shape, folded downsample): the projection shortcut accumulates inside this conv (second K segment)."""
             N, H, W = shape
+            if shortcut is not None:
+                buf, scale, bias, (Co, Ci, KH, KW), stride, pad, Ci2, stride2 = pack_dual(p, shortcut[2])
+            else:
+                buf, scale, bias, (Co, Ci, KH, KW), stride, pad = pack(p)
             Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
             y = x2_buffer(N * Ho * Wo, Co, x.device)
             d = _lib.ConvX2Desc(x.data_ptr(), x.shape[0], buf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
                                 N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale, None, 0)
+            if shortcut is not None:
+                x_in, (_, H2, W2) = shortcut[0], shortcut[1]
+                d.x2, d.x2_rows, d.H2, d.W2, d.Ci2, d.stride2 = x_in.data_ptr(), x_in.shape[0], H2, W2, Ci2, stride2
             need = int(_lib.lib().ehm_conv_x2_workspace_bytes(C.byref(d)))      # stream-K scratch (layers 3 / 4: tile counts that straddle the block slots)
             if need:
                 ws = sk_ws.get(str(x.device))
@@ -177,8 +201,12 @@ class ResNet50Features(nn.Module):
             for c1, c2, c3, ds in blocks:
                 y, s1 = conv_x2(x, shp, c1)
                 y, s2 = conv_x2(y, s1, c2)
-                idn = x if ds is None else conv_x2(x, shp, ds, relu=False)[0]
-                x, shp = conv_x2(y, s2, c3, res=idn)
+                if ds is None:
+                    x, shp = conv_x2(y, s2, c3, res=x)
+                elif fuse_shortcut:
+                    x, shp = conv_x2(y, s2, c3, shortcut=(x, shp, ds))          # out = conv3(.) + downsample(x) in one launch: no shortcut tensor
+                else:
+                    x, shp = conv_x2(y, s2, c3, res=conv_x2(x, shp, ds, relu=False)[0])
             out = torch.empty(N, x.shape[1], device=x.device)
             _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], _lib.stream_ptr()), "ehm_x2_group_mean")
             return out

@@ -193,7 +193,7 @@ class FusedSampler:
         self._count_host.copy_(maps[2 * B:], non_blocking=True)
         count_ready = torch.cuda.Event()
         count_ready.record(torch.cuda.current_stream(dev))
-        # The two encoders are independent; on two HIP streams the PointNet's matrix-bound GEMMs run beside ResNet-50's HBM-bound early layers.
+        # The two encoders are independent, but each fills the chip on its own: two HIP streams measured slower than one (model.overlap_encoders).
         if m.overlap_encoders:
             cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:

@@ -213,7 +213,8 @@ class EgoHMR(nn.Module):
         self.loop_engine_min_masked = 0.85
         self.pass_group = 1                # second passes pruned per item (1) or per group of this many consecutive items (FusedSampler.prepare)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)
-        self.overlap_encoders = True       # ResNet-50 and the scene PointNet on two HIP streams (FusedSampler.prepare)
+        self.overlap_encoders = False      # True: ResNet-50 and the scene PointNet on two HIP streams - measured 0.5 ms SLOWER than one after the other
+                                           # (17.27 vs 16.75 ms, tools/enc_split.py, three alternations: both fill the chip on their own)
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
         # precision schedule: only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'), the

@@ -257,6 +257,13 @@ typedef struct ehm_conv_x2_desc {
   float w_scale;
   void* workspace;           /* ehm_conv_x2_workspace_bytes(d) bytes of device scratch, or NULL (then whole tiles only) */
   int64_t workspace_bytes;
+  /* Optional second K segment (x2 != NULL): y = act( conv(x) + conv1x1_stride2(x2) + bias (+ residual) ) - a bottleneck's projection
+   * shortcut accumulated inside its last convolution (torchvision Bottleneck.forward: out = bn3(conv3(.)) + downsample(x)), so that the
+   * shortcut tensor never exists.  x2 is X2 [x2_rows, Ci2] over [N, H2, W2] pixels with its own zero row, (H2 - 1) / stride2 + 1 == Ho
+   * (same for W); W then holds [Co_pad][KH*KW*Ci + Ci2] with the shortcut's weights behind the main ones (one common w_scale), bias
+   * the SUM of the two folded biases; Co % 128 == 0. */
+  const void* x2; int64_t x2_rows;
+  int H2, W2, Ci2, stride2;
 } ehm_conv_x2_desc;
 int64_t ehm_conv_x2_rows(int64_t pixels);
 /* Scratch of the stream-K schedule: when a conv's tile count would leave a large share of the GPU's block slots idle in its last round

@@ -605,6 +605,81 @@ def test_conv_x2_vs_torch_fp64(dev, case):
     assert L.ehm_conv_x2(C.byref(d), None) != 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # N, Ho, Wo, Ci (main 1x1), Ci2 (shortcut input), stride2, Co
+    (3, 56, 56, 64, 64, 1, 256),       # layer 1 block 0: shortcut on the same grid
+    (3, 28, 28, 128, 256, 2, 512),     # layer 2 block 0: the shortcut samples every second pixel of a 56 x 56 input
+    (5, 7, 7, 512, 1024, 2, 2048),     # layer 4 block 0: ragged row tile (245 rows), odd input size 13 -> (13 - 1) / 2 + 1 = 7
+])
+def test_conv_x2_projection_shortcut_inside_the_last_conv(dev, case):
+    """ehm_conv_x2 with the second K segment (ehm_conv_x2_desc.x2): relu(conv1x1(h) + b3 + conv1x1_stride(x) + bd) - torchvision
+    Bottleneck.forward's `out = bn3(conv3(out)) + downsample(x)` (models/resnet.py:139-150) in ONE launch - against torch float64, and
+    against the two-launch route (shortcut conv, then the last conv with it as residual) that it replaces."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from egohmr_amd import _lib
+    N, Ho, Wo, Ci, Ci2, s2, Co = case
+    H2, W2 = (Ho - 1) * s2 + 1, (Wo - 1) * s2 + 1
+    g = torch.Generator().manual_seed(23)
+    h = torch.randn(N, Ho, Wo, Ci, generator=g)
+    x = torch.randn(N, H2, W2, Ci2, generator=g)
+    w3 = torch.randn(Co, Ci, generator=g) / Ci ** 0.5
+    wd = torch.randn(Co, Ci2, generator=g) / Ci2 ** 0.5
+    b3, bd = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+    ref = (F.conv2d(h.permute(0, 3, 1, 2).double(), w3.double()[:, :, None, None], b3.double())
+           + F.conv2d(x.permute(0, 3, 1, 2).double(), wd.double()[:, :, None, None], bd.double(), stride=s2)).clamp_min(0).permute(0, 2, 3, 1)
+    L = _lib.lib()
+
+    def to_x2(t, pixels, ch):
+        rows = int(L.ehm_conv_x2_rows(pixels))
+        src = torch.zeros(rows, ch)
+        src[:pixels] = t.reshape(pixels, ch)
+        src[pixels:rows - 1] = 7.0
+        src, dst = src.to(dev), torch.empty(rows, ch, device=dev)
+        _lib.check(L.ehm_split_pack(src.data_ptr(), dst.data_ptr(), rows, ch, ch, 1.0, None))
+        return dst
+
+    def pack_w(w):
+        wdv, buf = w.contiguous().to(dev), torch.empty(w.shape[0], w.shape[1], device=dev)
+        _lib.check(L.ehm_split_pack(wdv.data_ptr(), buf.data_ptr(), w.shape[0], w.shape[1], w.shape[1], 256.0, None))
+        return buf
+
+    hd, xd = to_x2(h, N * Ho * Wo, Ci), to_x2(x, N * H2 * W2, Ci2)
+    rows_out = int(L.ehm_conv_x2_rows(N * Ho * Wo))
+
+    def unpack(y):
+        out = torch.empty(rows_out, Co, device=dev)
+        _lib.check(L.ehm_gcn_unpack_activations(y.data_ptr(), out.data_ptr(), rows_out, Co, 32, None))
+        torch.cuda.synchronize()
+        return out[:N * Ho * Wo].cpu().double().reshape(N, Ho, Wo, Co)
+
+    wcat, bsum = pack_w(torch.cat([w3, wd], dim=1)), (b3 + bd).to(dev)
+    y = torch.full((rows_out, Co), float("nan"), device=dev)
+    d = _lib.ConvX2Desc(hd.data_ptr(), hd.shape[0], wcat.data_ptr(), bsum.data_ptr(), None, y.data_ptr(), N, Ho, Wo, Ci, Co, 1, 1, 1, 0, 1, 256.0, None, 0)
+    d.x2, d.x2_rows, d.H2, d.W2, d.Ci2, d.stride2 = xd.data_ptr(), xd.shape[0], H2, W2, Ci2, s2
+    assert int(L.ehm_conv_x2_workspace_bytes(C.byref(d))) == 0
+    _lib.check(L.ehm_conv_x2(C.byref(d), None), "ehm_conv_x2")
+    got = unpack(y)
+    err = (got - ref).abs().max().item()
+    # the route it replaces: shortcut tensor through HBM (rounded to the split format on the way)
+    ysc = torch.full((rows_out, Co), float("nan"), device=dev)
+    bdv, b3v, w3b, wdb = bd.to(dev), b3.to(dev), pack_w(w3), pack_w(wd)
+    d1 = _lib.ConvX2Desc(xd.data_ptr(), xd.shape[0], wdb.data_ptr(), bdv.data_ptr(), None, ysc.data_ptr(), N, H2, W2, Ci2, Co, 1, 1, s2, 0, 0, 256.0, None, 0)
+    _lib.check(L.ehm_conv_x2(C.byref(d1), None), "ehm_conv_x2")
+    y2 = torch.full((rows_out, Co), float("nan"), device=dev)
+    d2 = _lib.ConvX2Desc(hd.data_ptr(), hd.shape[0], w3b.data_ptr(), b3v.data_ptr(), ysc.data_ptr(), y2.data_ptr(), N, Ho, Wo, Ci, Co, 1, 1, 1, 0, 1, 256.0, None, 0)
+    _lib.check(L.ehm_conv_x2(C.byref(d2), None), "ehm_conv_x2")
+    two = unpack(y2)
+    print(f"[conv_x2 shortcut {case}] max|err| vs fp64 = {err:.3e}, two launches: {(two - ref).abs().max().item():.3e}")
+    assert err < 1e-5 and (two - got).abs().max().item() < 1e-5
+    d.H2 += 2                                                    # a shortcut grid that does not map onto the output grid is refused
+    assert L.ehm_conv_x2(C.byref(d), None) != 0
+    d.H2 -= 2
+    d.x2_rows -= 1                                               # so is an x2 buffer without its zero row
+    assert L.ehm_conv_x2(C.byref(d), None) != 0
+
+
 # --------------------------------------------------------------------------------------------- ResNet-50 backbone
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 96), (1, 32, 32)])

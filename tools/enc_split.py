@@ -17,7 +17,7 @@ b = batch_to_device(syn.make_batch(256, 4096, seed=100), dev)
 fs = model.fused_sampler
 
 
-def timed(fn, reps=5):
+def timed(fn, reps=20):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -34,10 +34,13 @@ pts = [v for k, v in b.items() if torch.is_tensor(v) and v.dim() == 3 and v.shap
 backbone = fs._backbone_fn()
 scene = model.scene_enc
 print("image", tuple(img.shape), "scene points", tuple(pts.shape))
-for name, fn in (("ResNet-50 trunk", lambda: backbone(img)), ("scene PointNet", lambda: scene(pts))):
+two_launch = model.backbone.folded(fuse_shortcut=False)
+for name, fn in (("ResNet-50 trunk", lambda: backbone(img)), ("ResNet-50, shortcut convs as own launches", lambda: two_launch(img)),
+                 ("ResNet-50 trunk", lambda: backbone(img)), ("ResNet-50, shortcut convs as own launches", lambda: two_launch(img)),
+                 ("scene PointNet", lambda: scene(pts))):
     wall, host = timed(fn)
-    print(f"{name:18s}: {wall:7.2f} ms wall, {host:6.2f} ms of it host-side issue")
-for mode in (False, True):
+    print(f"{name:42s}: {wall:7.2f} ms wall, {host:6.2f} ms of it host-side issue")
+for mode in (False, True, False, True, False, True):
     model.overlap_encoders = mode
 
     def prep():

@@ -376,9 +376,18 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
                       nb * (6890 * 3 * 4 + 21 * 3 * 4 + 24 * 12 * 4 + 2 * 224 * 2) + 19.3e6 + rows * hid * (act_b if act_b == 2 else 4) + nb * 2 * 2 * hid * 4,
                       "per body 82,680 B vertices + extra joints + transforms + blend coefficients (SURVEY 8d: ~84.1 KB/body-step incl. the inputs) + SMPL "
                       "constants 19.3 MB once per launch + the next step's input rows written (rows*hid) + h_img / h_oth read")
-        hbm_entry("step_body", "step_body_kernel (output mix + sampler update + rot6d + 24-joint chain; one wave per body)",
-                  nb * (2 * 24 * 12 * 4 + 5 * 576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2),
-                  "per body: responses 2,304 B + x_t / noise / x0 / x_next / pose6d 5 x 576 B + betas + R + A + joints + blend-coefficient fragments (latency-bound: 1 wave per body)")
+        if prof.get("step_fused", {}).get("launches_per_call"):
+            hbm_entry("step_fused", "step_fused_kernel (a step's output-conv responses + output mix + sampler update, then the NEXT step's hoisted input conv; one block per body)",
+                      rows * hid * act_b + rows * hid * (act_b if act_b == 2 else 4) + nb * (2 * 2 * hid * 4 + 4 * 576),
+                      "rows*hid activation rows read (last hidden conv) + rows*hid rows written (next input) + h_img / h_oth slices + x_t / noise / x0 / x_next")
+            n_pose = prof["step_body"]["launches_per_call"]
+            if n_pose:
+                hbm_entry("step_body", f"pose_steps_kernel (rot6d + 24-joint chain + blend fragments of {T / n_pose:g} steps x {nb} bodies in one launch; one wave per body-step)",
+                          T / n_pose * nb * (576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2), "per body-step: x0 576 B + betas + R + A + joints + blend-coefficient fragments")
+        else:
+            hbm_entry("step_body", "step_body_kernel (output mix + sampler update + rot6d + 24-joint chain; one wave per body)",
+                      nb * (2 * 24 * 12 * 4 + 5 * 576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2),
+                      "per body: responses 2,304 B + x_t / noise / x0 / x_next / pose6d 5 x 576 B + betas + R + A + joints + blend-coefficient fragments (latency-bound: 1 wave per body)")
         # collision guidance (SURVEY 8d / north_star "scene-point Chamfer/SDF guidance reduction"): the three kernels a guided step spends its time in
         guid = {}
         if prof["guidance"]["launches_per_call"]:

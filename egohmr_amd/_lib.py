@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EHM_LIB_PATH") or os.path.join(_HERE, "libegohmr_hip.so")   # EHM_LIB_PATH: A/B a second build (experiments)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip", "prep.hip"]
+SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip", "prep.hip", "step.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
@@ -31,7 +31,7 @@ class EgoHMRHipError(RuntimeError):
 def build(verbose: bool = False, force: bool = False) -> str:
     """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "smpl_dev.h"), os.path.join(CSRC, "gcn_dev.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "smpl_dev.h"), os.path.join(CSRC, "gcn_dev.h"), os.path.join(CSRC, "step_dev.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -174,7 +174,7 @@ PROTOTYPES = {
     "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }
 PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "loop_f16x3", "loop_f16",
-                "guid_nearest", "guid_skin_bwd", "guid_posefeat_bwd")   # EHM_PROF_* of the header
+                "guid_nearest", "guid_skin_bwd", "guid_posefeat_bwd", "step_fused")   # EHM_PROF_* of the header
 
 _lib = None
 

@@ -637,6 +637,7 @@ int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const
   return 0;
 }
 
+const void* ehm_gcn_out_dev(const ehm_gcn* h) { return &h->out; }
 int ehm_gcn_hid(const ehm_gcn* h) { return h->hid; }
 int ehm_gcn_num_hidden(const ehm_gcn* h) { return h->num_hidden; }
 int ehm_gcn_chain_enabled(const ehm_gcn* h) { return h->chain != 0 && h->precision != EHM_PREC_F32; }

@@ -233,18 +233,23 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
   const uint8_t* vb_ = vis + (size_t)b * kJ;
   float h0[kJ], h1[kJ];
   const float sh = L.shift[n];
+  // the two branches' sums as the halves of packed FMAs (v_pk_fma_f32: the same fused operations per half, two per instruction - this
+  // kernel is bound by vector-ALU issue: ~940 scalar FMAs per lane before, 4 cycles apiece for a wave)
+  const f32x2 img2 = {img[0], img[1]}, base2 = {base[0], base[1]};
+  f32x2 wx2[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) wx2[c] = f32x2{wx[0][c], wx[1][c]};
 #pragma unroll
   for (int j = 0; j < kJ; ++j) {
     const float v = vb_[j] ? 1.f : 0.f;
-    float s0 = fmaf(v, img[0], base[0]), s1 = fmaf(v, img[1], base[1]);
+    f32x2 s = __builtin_elementwise_fma(f32x2{v, v}, img2, base2);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const float xv = xb[j * 6 + c];
-      s0 = fmaf(xv, wx[0][c], s0);
-      s1 = fmaf(xv, wx[1][c], s1);
+      s = __builtin_elementwise_fma(f32x2{xv, xv}, wx2[c], s);
     }
-    h0[j] = fmaf(L.D[j * N + n], s0, sh);
-    h1[j] = L.M1[j * N + n] * s1;
+    h0[j] = fmaf(L.D[j * N + n], s[0], sh);
+    h1[j] = L.M1[j * N + n] * s[1];
   }
   // 24x24 adjacency mix per lane (one channel), then through a float [24][256] LDS tile so that the rows leave as 16-byte stores
   // (one dword per lane and joint is store-issue bound: 30 us for 48 MiB).
@@ -289,13 +294,24 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
     typedef const float __attribute__((address_space(4))) cfloat;
     const cfloat* Ac = (const cfloat*)(uintptr_t)L.Aoff;
     const bool relu = L.relu != 0;
+    // two output joints per packed FMA: the coefficient pair (Aoff[j][jp], Aoff[j+1][jp]) = (Aoff[jp][j], Aoff[jp][j+1]) - the matrix is exactly
+    // symmetric (gcn.hip: (a_ij + a_ji) / 2) - sits in an aligned SGPR pair of row jp's scalar load; jp outermost (one row of 24 coefficients
+    // live at a time - with j outermost the strided pairs spilled ~1000 SGPRs through v_writelane / v_readlane); every output's FMA chain
+    // still runs over jp in ascending order: bit-equal to the scalar form
+    f32x2 sacc[kJ / 2];
 #pragma unroll
-    for (int j = 0; j < kJ; ++j) {
-      float sacc = h0[j];
+    for (int jj = 0; jj < kJ / 2; ++jj) sacc[jj] = f32x2{h0[2 * jj], h0[2 * jj + 1]};
 #pragma unroll
-      for (int jp = 0; jp < kJ; ++jp) sacc = fmaf(Ac[j * kJ + jp], h1[jp], sacc);
-      if (relu) sacc = fmaxf(sacc, 0.f);
-      T[j * 256 + tid] = sacc;
+    for (int jp = 0; jp < kJ; ++jp) {
+      const f32x2 hh = {h1[jp], h1[jp]};
+#pragma unroll
+      for (int jj = 0; jj < kJ / 2; ++jj) sacc[jj] = __builtin_elementwise_fma(f32x2{Ac[jp * kJ + 2 * jj], Ac[jp * kJ + 2 * jj + 1]}, hh, sacc[jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < kJ / 2; ++jj) {
+      if (relu) { sacc[jj][0] = fmaxf(sacc[jj][0], 0.f); sacc[jj][1] = fmaxf(sacc[jj][1], 0.f); }
+      T[(2 * jj) * 256 + tid] = sacc[jj][0];
+      T[(2 * jj + 1) * 256 + tid] = sacc[jj][1];
     }
   }
   __syncthreads();
@@ -433,12 +449,12 @@ constexpr int OUT_ROWS_PER_BLOCK = 16;
 // wave's lane (row = l&15, q = l>>4) streams float4 X[row][kw + 16 i + 4 q ..+3] - the k order inside an MFMA step is a
 // permutation applied to both operands, which a sum does not see - and the matching float4 of the 12 x K weights (48 KiB, L2 hits).
 // The four partial 16x16 tiles meet in 4 KiB of LDS (`part`).  AUX = cache policy of the activation loads (0: plain; 16 = sc1).
+// One wave's share of a 16-row tile: K quarter `wave` of row `r` (lane: row = l & 15, q = l >> 4) -> the wave's partial 16 x 16 tile in MFMA C
+// layout (column = lane & 15, row = 4 (lane >> 4) + reg).  Shared by gcn_out_dot_rows16 and the fused step kernel (step.hip).
 template <bool HALF_IN, int AUX>
-__device__ __forceinline__ void gcn_out_dot_rows16(const float* __restrict__ X, const OutDev& O, float* __restrict__ hs, int64_t r0, int64_t rows,
-                                                   float (*part)[16][16], int tid) {
-  const int K = O.K, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ f32x4 gcn_out_dot_quarter(const float* __restrict__ X, const OutDev& O, int64_t r, int wave, int lane) {
+  const int K = O.K;
   const int row = lane & 15, q = lane >> 4;
-    const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
   const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: a multiple of 16)
   // a lane owns 8 consecutive k of every 32-k group (16 bytes of f16 / 32 bytes of float32 per load: the four lanes of a row cover a
   // 64 / 128-byte segment); MFMA c of the group contracts element c of all lanes, i.e. k = c, 8 + c, 16 + c, 24 + c
@@ -495,6 +511,16 @@ __device__ __forceinline__ void gcn_out_dot_rows16(const float* __restrict__ X, 
     }
   }
   acc += acc2;
+  return acc;
+}
+
+template <bool HALF_IN, int AUX>
+__device__ __forceinline__ void gcn_out_dot_rows16(const float* __restrict__ X, const OutDev& O, float* __restrict__ hs, int64_t r0, int64_t rows,
+                                                   float (*part)[16][16], int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 15, q = lane >> 4;
+  const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
+  const f32x4 acc = gcn_out_dot_quarter<HALF_IN, AUX>(X, O, r, wave, lane);
   // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
   for (int c = 0; c < 4; ++c) part[wave][4 * q + c][row] = acc[c];

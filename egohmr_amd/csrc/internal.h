@@ -18,6 +18,13 @@ int ehm_step_body_impl(ehm_smpl* h, const float* hs, const void* out_dev, const 
                        int* fused = nullptr, void* defer_pf = nullptr);   // defer_pf: write the blend fragments there and launch NO skinning (ehm_skin_steps_impl later)
 int ehm_skin_steps_impl(ehm_smpl* h, const float* A_steps, const void* pf_steps, int nsteps, int final_step, int B, float* verts, float* joints,
                         float* scratch_verts, float* scratch_joints, hipStream_t st);
+// step.hip: a step's tail (output responses, x0, x_{t-1}) + the next step's input conv in one launch; the poses of pending steps in one launch
+int ehm_step_fused_impl(const void* out_dev, const float* X, int prec, const uint8_t* vis, const float* x, const float* noise, const float* grad,
+                        float* x_next, float* x0, const ehm_step_coefs* c, int ddim, int passes, const int32_t* mask_slot, int B,
+                        const struct GcnInputArgs* next_input, int next_prec, hipStream_t st);
+int ehm_pose_steps_impl(ehm_smpl* smpl, const float* x0_steps, int nsteps, int final_step, int B, const float* betas, const float* mean,
+                        const float* std_, float* A_steps, void* pf_steps, float* R, float* joints, float* pose6d, float* x0_final,
+                        float* scratch_joints, hipStream_t st);
 int ehm_skin_min_bodies();
 int64_t ehm_skin_pf_bytes_per_step(int B);
 void ehm_smpl_dev(const ehm_smpl* h, void* out);   // copies the handle's SmplDev (smpl_dev.h) into *out
@@ -37,6 +44,7 @@ int ehm_gcn_virtual_bodies(const ehm_gcn* h, int B, int passes);   // B + second
 const int32_t* ehm_gcn_mask_slot(const ehm_gcn* h, int passes);
 // output conv, first half only: responses hs [passes*B*24, 12] = X . [W0 | W1] (scratch owned by the handle); *out_dev = the OutDev block
 int ehm_gcn_output_dot_impl(ehm_gcn* h, const float* X, int B, int passes, const float** hs, const void** out_dev, hipStream_t st);
+const void* ehm_gcn_out_dev(const ehm_gcn* h);   // the OutDev block (gcn_dev.h) of the output conv
 // sampler.hip
 int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 // gcn_tile.hip (f16 matrix-core hidden convs: 'f16x3' split operands and plain 'f16')

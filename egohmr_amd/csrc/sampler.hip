@@ -155,6 +155,7 @@ struct Workspace {
   void* loop_pf;                // [loop_seg, ceil(B/32), 14, 2, 64] x 16 B
   float* loop_verts;            // [B, V, 3]   vertices of the segment's intermediate steps (computed like the final ones, not consumed)
   float* loop_joints;           // [B, J, 3]
+  float* loop_x0;               // [skin_seg, B, 144]  x0 of the pending steps (their poses are computed in front of the skinning launch, step.hip)
   int loop_seg, skin_seg;
   int64_t rows, rows_pad;
   int64_t total_bytes;
@@ -198,6 +199,7 @@ Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* ba
     w.loop_pf = take((int64_t)w.skin_seg * (ehm_skin_pf_bytes_per_step(d->B) / 4));
     w.loop_verts = take((int64_t)d->B * V * 3);
     w.loop_joints = take((int64_t)d->B * n_joints * 3);
+    w.loop_x0 = take((int64_t)w.skin_seg * d->B * kPoseDim);
     if (engine) {
       w.loop_seg = w.skin_seg;
       w.loop_coefs = (ehm_step_coefs*)take(round_up(w.loop_seg, 64) * (int64_t)(sizeof(ehm_step_coefs) / 4));   // (uploaded in chunks of 64 rows)
@@ -301,11 +303,24 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   const bool defer_skin = w.skin_seg > 0 && d->lbs_every_step;
   const int64_t pf_bytes_step = ehm_skin_pf_bytes_per_step(B);
   int pending = 0;
+  bool pending_poses = false;       // the pending slots hold x0 only (fused step launches): their poses are still to be computed
+  // ---- fused step launches (step.hip): output responses + per-body update + the next step's input conv as ONE launch per step.  Needs the
+  //      step's pose off the per-step path: deferred skinning (poses computed per flush), or no per-step skinning at all (then the last step
+  //      takes the per-step launches below, which end in the pose and the skinning launch).
+  const char* fused_e = getenv("EHM_STEP_FUSED");                 // "0": the per-step launches (A/B runs, the bit-equality tests)
+  const bool fused_env = !(fused_e && fused_e[0] == '0');
+  const bool fused_steps = fused_env && hid % 64 == 0 && (defer_skin || !d->lbs_every_step);
   if (defer_skin && B % 32 != 0) EHM_HIP(hipMemsetAsync(w.loop_pf, 0, (size_t)w.skin_seg * pf_bytes_step, st));   // padding bodies of every slot's last 32-body tile
   auto flush_skin = [&](bool final_step_inside) -> int {
     if (pending == 0) return 0;
-    const int r = ehm_skin_steps_impl(smpl, w.loop_A, w.loop_pf, pending, final_step_inside ? pending - 1 : -1, B, verts, joints, w.loop_verts, w.loop_joints, st);
+    int r = 0;
+    if (pending_poses)
+      r = ehm_pose_steps_impl(smpl, w.loop_x0, pending, final_step_inside ? pending - 1 : -1, B, betas, mean, std_, w.loop_A, w.loop_pf, R, joints, pose6d,
+                              x0_final, w.loop_joints, st);
+    if (r == 0)
+      r = ehm_skin_steps_impl(smpl, w.loop_A, w.loop_pf, pending, final_step_inside ? pending - 1 : -1, B, verts, joints, w.loop_verts, w.loop_joints, st);
     pending = 0;
+    pending_poses = false;
     return r;
   };
   bool input_done = false;          // step k's input conv already ran inside step k-1's skinning launch
@@ -358,6 +373,27 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
       if (rc == 0) rc = ehm_conv_nhwc_split(&c2, st);
       feat = w.X[1];
     }
+    // ---- fused: responses + x0 + x_{t-1} + the next step's input conv in one launch (the same arithmetic as the launches below).  Not for a
+    //      step whose successor reads another activation format (the next rows would land on other bodies' rows of `feat`), nor - without
+    //      deferred skinning - for the last step (its pose and skinning follow at once).
+    if (rc == 0 && fused_steps && (last ? defer_skin : prec_of(k) == prec_of(k + 1))) {
+      if (defer_skin && pending > 0 && !pending_poses) rc = flush_skin(false);      // (slots filled by per-step launches carry their poses already)
+      const float* eps = noise + (int64_t)(1 + k) * n;
+      float* dst = last ? x_final : w.x_cur;
+      GcnInputArgs nin;
+      if (rc == 0 && !last) rc = ehm_gcn_input_args(gcn, h_img, h_oth, vis, dst, Wx, tvecs + (int64_t)(k + 1) * 2 * hid, w.X[0], B, d->passes, &nin);
+      if (rc == 0)
+        rc = ehm_step_fused_impl(ehm_gcn_out_dev(gcn), feat, prec_of(k), vis, w.x_cur, eps, grad, dst, defer_skin ? w.loop_x0 + (int64_t)pending * n : x0_final,
+                                 &c, d->ddim, d->passes, ehm_gcn_mask_slot(gcn, d->passes), B, last ? nullptr : &nin, prec_of(k + 1), st);
+      input_done = !last;
+      if (rc == 0 && defer_skin) {
+        pending_poses = true;
+        ++pending;
+        if (pending == w.skin_seg || last) rc = flush_skin(last);
+      }
+      continue;
+    }
+    if (rc == 0 && pending_poses) rc = flush_skin(false);        // this step fills its slot WITH its pose
     if (rc == 0) {
       EhmProfScope ps(EHM_PROF_OUT_DOT, st);
       rc = ehm_gcn_output_dot_impl(gcn, feat, B, d->passes, &hs, &out_dev, st);

@@ -116,42 +116,75 @@ struct StepBodyLds {
   float x0s[kPoseDim];
   float Rl[kJ * 9];
   float sAo[kJ * kJ], sMo[kJ * 6];
+  float xn[kPoseDim];       // x_{t-1} as written to x_next (a caller that goes on with the next step's input conv reads it here)
 };
 
 // One wave = one body `b`.  `sync` orders the wave's LDS traffic: __syncthreads() in the 64-thread kernel, a wave-local fence when several
 // waves of a larger block run different bodies side by side.
+// The body's pose from its x0 (LDS or global row `x0row`): de-normalise, rot6d -> R, kinematic chain, then the blend-coefficient fragments.
 template <class Sync>
-__device__ __forceinline__ void step_body_one(int b, int lane, const StepBodyArgs& a, const SmplDev& S, StepBodyLds& L, Sync sync) {
-
-  float (&sh)[2][kJ][12] = L.sh;
-  float (&x0s)[kPoseDim] = L.x0s;
+__device__ __forceinline__ void step_pose_part(int b, int lane, const StepBodyArgs& a, const SmplDev& S, StepBodyLds& L, Sync sync, const float* x0row) {
   float (&Rl)[kJ * 9] = L.Rl;
-  const int slot = a.mask_slot ? a.mask_slot[b] : b;            // row block of my second pass: B + slot (slot < 0: pruned, every joint visible)
-  // stage the body's output-conv responses and the (tiny) adjacency / modulation tables: every global load of the kernel's first
-  // phase is requested before the first one is consumed (as an element-wise loop this was nine dependent round trips, and the mix
-  // below fetched its coefficients from global memory inside the inner loop)
+  pose_chain_body<true>(b, lane, a.betas, x0row, a.mean, a.std_, S, a.Rws, a.Aws, a.joints, a.pose6d, a.jstride, Rl);
+  if (!a.pf) return;
+  sync();
+  if (lane < 2 * kBlendSteps) {                                 // 28 lanes: (k-step s, lane half h) -> 8 coefficients, hi and lo fragments
+    const int s = lane >> 1, h = lane & 1;
+    sk_half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * s + 8 * h + e;
+      float x = 0.f;
+      if (k < kPoseBasis) x = Rl[9 + k] - ((k % 9 == 0 || k % 9 == 4 || k % 9 == 8) ? 1.f : 0.f);   // R[1:] - I
+      else if (k < kPoseBasis + 10) x = a.betas[(size_t)b * 10 + (k - kPoseBasis)];
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+    const size_t base = ((size_t)(b >> 5) * kBlendSteps + s) * 2;
+    a.pf[(base + 0) * 64 + (b & 31) + 32 * h] = hi;
+    a.pf[(base + 1) * 64 + (b & 31) + 32 * h] = lo;
+  }
+}
+
+// HS_LDS: the caller has already put the body's responses into L.sh (the fused step kernel of step.hip computes them in the same block).
+// Stage the body's output-conv responses (unless HS_LDS: the caller computes them into L.sh) and the (tiny) adjacency / modulation tables: every
+// global load of the step's first phase is requested before the first one is consumed (as an element-wise loop this was nine dependent round
+// trips, and the mix fetched its coefficients from global memory inside the inner loop).  The caller orders this against step_body_one's reads.
+template <bool HS_LDS>
+__device__ __forceinline__ void step_stage_tables(int b, int lane, const StepBodyArgs& a, StepBodyLds& L) {
+  float (&sh)[2][kJ][12] = L.sh;
   float (&sAo)[kJ * kJ] = L.sAo;
   float (&sMo)[kJ * 6] = L.sMo;
-  {
-    float tmp[9], ta[9], tm[3];
+  const int slot = a.mask_slot ? a.mask_slot[b] : b;            // row block of my second pass: B + slot (slot < 0: pruned, every joint visible)
+  float tmp[9], ta[9], tm[3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int i = lane + 64 * k, p = i / (kJ * 12), rem = i % (kJ * 12);
-      tmp[k] = (i < a.passes * kJ * 12 && !(p == 1 && slot < 0)) ? a.hs[((size_t)(p ? a.B + slot : b) * kJ) * 12 + rem] : 0.f;
-      ta[k] = a.O.A[i < kJ * kJ ? i : 0];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tm[k] = a.O.M[lane + 64 * k < kJ * 6 ? lane + 64 * k : 0];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int i = lane + 64 * k;
-      if (i < a.passes * kJ * 12) (&sh[0][0][0])[i] = tmp[k];
-      if (i < kJ * kJ) sAo[i] = ta[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (lane + 64 * k < kJ * 6) sMo[lane + 64 * k] = tm[k];
+  for (int k = 0; k < 9; ++k) {
+    const int i = lane + 64 * k, p = i / (kJ * 12), rem = i % (kJ * 12);
+    tmp[k] = (!HS_LDS && i < a.passes * kJ * 12 && !(p == 1 && slot < 0)) ? a.hs[((size_t)(p ? a.B + slot : b) * kJ) * 12 + rem] : 0.f;
+    ta[k] = a.O.A[i < kJ * kJ ? i : 0];
   }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tm[k] = a.O.M[lane + 64 * k < kJ * 6 ? lane + 64 * k : 0];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int i = lane + 64 * k;
+    if (!HS_LDS && i < a.passes * kJ * 12) (&sh[0][0][0])[i] = tmp[k];
+    if (i < kJ * kJ) sAo[i] = ta[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (lane + 64 * k < kJ * 6) sMo[lane + 64 * k] = tm[k];
+}
+
+// WITH_POSE = false: the pose part is not even compiled in (the caller leaves it to pose_steps_kernel, step.hip).  STAGED: the caller has run
+// step_stage_tables itself (and ordered it).
+template <bool HS_LDS = false, bool WITH_POSE = true, bool STAGED = false, class Sync>
+__device__ __forceinline__ void step_body_one(int b, int lane, const StepBodyArgs& a, const SmplDev& S, StepBodyLds& L, Sync sync) {
+  float (&sh)[2][kJ][12] = L.sh;
+  float (&x0s)[kPoseDim] = L.x0s;
+  float (&sAo)[kJ * kJ] = L.sAo;
+  float (&sMo)[kJ * 6] = L.sMo;
+  if constexpr (!STAGED) step_stage_tables<HS_LDS>(b, lane, a, L);
   sync();
   for (int e = lane; e < kPoseDim; e += 64) {
     const int j = e / 6, c = e % 6;
@@ -178,26 +211,11 @@ __device__ __forceinline__ void step_body_one(int b, int lane, const StepBodyArg
       out = __fadd_rn(mean, __fmul_rn(__fmul_rn(a.c.nonzero, sd), nz));
     }
     a.x_next[i] = out;
+    L.xn[e] = out;
   }
-  if (!a.do_pose) return;
-  sync();
-  pose_chain_body<true>(b, lane, a.betas, x0s, a.mean, a.std_, S, a.Rws, a.Aws, a.joints, a.pose6d, a.jstride, Rl);
-  if (!a.pf) return;
-  sync();
-  if (lane < 2 * kBlendSteps) {                                 // 28 lanes: (k-step s, lane half h) -> 8 coefficients, hi and lo fragments
-    const int s = lane >> 1, h = lane & 1;
-    sk_half8 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 16 * s + 8 * h + e;
-      float x = 0.f;
-      if (k < kPoseBasis) x = Rl[9 + k] - ((k % 9 == 0 || k % 9 == 4 || k % 9 == 8) ? 1.f : 0.f);   // R[1:] - I
-      else if (k < kPoseBasis + 10) x = a.betas[(size_t)b * 10 + (k - kPoseBasis)];
-      hi[e] = (_Float16)x;
-      lo[e] = (_Float16)(x - (float)hi[e]);
-    }
-    const size_t base = ((size_t)(b >> 5) * kBlendSteps + s) * 2;
-    a.pf[(base + 0) * 64 + (b & 31) + 32 * h] = hi;
-    a.pf[(base + 1) * 64 + (b & 31) + 32 * h] = lo;
+  if constexpr (WITH_POSE) {
+    if (!a.do_pose) return;
+    sync();
+    step_pose_part(b, lane, a, S, L, sync, x0s);
   }
 }

@@ -442,7 +442,7 @@ enum {
   EHM_PROF_CHAIN_F16 = 2,    /* gcn_hidden_chain_kernel<1, 8>: the same on plain f16 operands                            */
   EHM_PROF_HIDDEN_F32 = 3,   /* gcn_hidden_kernel x 8 (f32-input MFMA) or per-conv tile launches                         */
   EHM_PROF_OUT_DOT = 4,      /* gcn_out_dot_kernel                                                                       */
-  EHM_PROF_STEP_BODY = 5,    /* step_body_kernel                                                                         */
+  EHM_PROF_STEP_BODY = 5,    /* step_body_kernel; with the fused step launches: pose_steps_kernel (the pending steps' poses, per flush) */
   EHM_PROF_SKIN_INPUT = 6,   /* skin_input_kernel (skinning of step t + input conv of step t+1) / skin_mfma_kernel       */
   EHM_PROF_GUIDANCE = 7,     /* the collision-guidance kernel sequence of a guided step                                  */
   EHM_PROF_LOOP_F16X3 = 8,   /* gcn_loop_kernel<3, 4>: a run of unguided steps in one launch (ehm_sample_desc.loop_engine), split-f16 */
@@ -450,7 +450,8 @@ enum {
   EHM_PROF_G_NEAREST = 10,   /* inside EHM_PROF_GUIDANCE: bbox + select + nearest_grid_kernel (the collision proxy's search) */
   EHM_PROF_G_SKIN_BWD = 11,  /* inside EHM_PROF_GUIDANCE: skin_bwd_kernel (VJP of the skinning)                          */
   EHM_PROF_G_POSEFEAT_BWD = 12, /* inside EHM_PROF_GUIDANCE: posefeat_bwd_kernel ([B, 20670] x [20670, 207] contraction) */
-  EHM_PROF_N = 13
+  EHM_PROF_STEP_FUSED = 13,  /* step_fused_kernel: a step's output responses + per-body update + the NEXT step's input conv, one block per body */
+  EHM_PROF_N = 14
 };
 int ehm_profile_begin(void);
 int ehm_profile_end(double* ms, int64_t* launches, int n);

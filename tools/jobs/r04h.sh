@@ -1,12 +1,8 @@
-set -x
+#!/bin/bash
+# full GPU suite + default bench line
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04h; mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_gpu_loop_engine.py -x -q > $O/pytest_engine.txt 2>&1; tail -5 $O/pytest_engine.txt
-for w in c2_ddim10 ddpm100; do
-timeout 600 python bench.py --workload $w --cpu-seconds 0 --no-legs --steps 5 --warmup 2 > $O/bench_$w.json 2> $O/bench_$w.err; python - <<P
-import json
-d=json.loads(open('/root/repo/gpurun_out/r04h/bench_$w.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], json.dumps(d['breakdown_ms']))
-P
-done
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 | tee $O/tests.log
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

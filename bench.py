@@ -419,7 +419,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
             "per_rank_bodies_per_s": per_rank, "all_gather_ms": gather_ms,
             "multi_gpu_note": None if world == 1 else ("weak scaling: every rank runs the whole N = 1 job on its own items, value = all items / the slowest rank's time; expect a "
                                                        "few percent below N x the one-GPU number: N sockets at their own 1400 W caps clock independently (box-to-box spread "
-                                                       "was +-3 %), and each rank's Python thread enqueues ~400 launches per call"),
+                                                       "was +-3 %), and each rank's Python thread enqueues ~200 launches per call"),
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": dt / steps * 1e3,

@@ -404,8 +404,12 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
             g_entry("guid_skin_bwd", "skin_bwd_kernel (VJP of the skinning: d loss / d transforms, d loss / d blended rest pose)",
                     "hbm", nb * (6890 * 12 * 2 + 24 * 12 * 4) + 19.3e6, PEAK_HBM_GBS, "GB/s",
                     "per body: vertex gradient read + rest-pose gradient written (2 x 82,680 B) + transform gradient; SMPL constants 19.3 MB once per launch")
-            g_entry("guid_posefeat_bwd", "posefeat_bwd_kernel ([bodies, 20670] x [20670, 207] contraction with the pose-corrective basis)",
-                    "valu_f32", nb * 2.0 * 20670 * 207, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "2 x bodies x 20670 x 207 flop, float32 vector ALU (peak = the f32 vector rate, 157.3 TFLOP/s)")
+            valu = os.environ.get("EHM_POSEFEAT_VALU") == "1"
+            g_entry("guid_posefeat_bwd", ("posefeat_bwd_kernel" if valu else "posefeat_bwd_mfma_kernel + posefeat_sum_kernel") +
+                    " ([bodies, 20670] x [20670, 207] contraction with the pose-corrective basis)",
+                    "valu_f32" if valu else "mfma", nb * 2.0 * 20670 * 207, PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
+                    "2 x bodies x 20670 x 207 flop, " + ("float32 vector ALU (peak = the f32 vector rate, 157.3 TFLOP/s)" if valu else
+                                                       "exact-f32 MFMA (v_mfma_f32_32x32x2_f32; 224 of 207 columns issued)"))
             guid["guided_step_total_us"] = prof["guidance"]["ms_per_call"] / prof["guidance"]["launches_per_call"] * 1e3
         value = world * B * S * steps / dt
         flops_per_body = {"ddpm100": 183.8e9, "c2_ddim10": 35.5e9}.get(workload)  # SURVEY 8d, hoisted, with diffuse_fuse

@@ -427,6 +427,98 @@ __global__ __launch_bounds__(kVT, 4) void skin_bwd_kernel(const float* __restric
 }
 
 // gpf[b][p] = sum_col posedirs[p][col] * gvp[b][col];  block = (joint-1: 9 basis rows) x (8 bodies)
+// The same contraction on the matrix cores in exact float32 (v_mfma_f32_32x32x2_f32): gpf[b][k] = sum_c gverts[b][c] * posedirs[k][c], a
+// [B, 3V] x [3V, 207] GEMM whose BOTH operands are k-contiguous rows - a lane (row / column = l & 31, h = l >> 5) loads 16 bytes of its row at
+// k + 4 h, MFMA i of an 8-k group contracts k + i and k + 4 + i.  A wave owns 32 bodies x ALL 224 (207) columns (7 accumulator tiles: the
+// gradient rows, 106 MB at 1280 bodies, are read exactly once; the 17 MB basis once per 32 bodies, from L2) over 1 / (4 kPfSplit) of K; the four
+// waves of a block reduce through LDS, the kPfSplit partial tiles are added by posefeat_sum_kernel in a fixed order (deterministic, no
+// atomics).  11 GFLOP dense: the vector-ALU kernel below (which skips the gradient's zero columns) took 0.38 - 0.58 ms at 1280 bodies.
+constexpr int kPfSplit = 8, kPfTiles = 7;
+__global__ __launch_bounds__(256, 2) void posefeat_bwd_mfma_kernel(const float* __restrict__ gv, const float* __restrict__ posedirs,
+                                                                float* __restrict__ part, int B, int V3) {
+  __shared__ float red[3][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mi = lane & 31, h = lane >> 5;
+  const int m0 = 32 * blockIdx.x, sp = blockIdx.y;
+  const int G = (V3 + 7) / 8, Gfull = V3 / 8, c = sp * 4 + wave;
+  const int g0 = (int)((long long)c * G / (4 * kPfSplit)), g1 = (int)((long long)(c + 1) * G / (4 * kPfSplit));
+  const int row = m0 + mi;
+  const bool row_ok = row < B;
+  const float* xa = gv + (size_t)(row_ok ? row : 0) * V3 + 4 * h;
+  const float* wb[kPfTiles];
+  bool col_ok[kPfTiles];
+#pragma unroll
+  for (int t = 0; t < kPfTiles; ++t) {
+    col_ok[t] = 32 * t + mi < kPoseBasis;
+    wb[t] = posedirs + (size_t)(col_ok[t] ? 32 * t + mi : 0) * V3 + 4 * h;
+  }
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  f32x16_t acc[kPfTiles];
+#pragma unroll
+  for (int t = 0; t < kPfTiles; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  const int ge = g1 < Gfull ? g1 : Gfull;
+#pragma unroll 2
+  for (int g = g0; g < ge; ++g) {
+    f32x4_t a = *(const f32x4_t*)(xa + 8 * g);                       // (rows start at 4-byte multiples only: unaligned 16-byte loads)
+    if (!row_ok) a = zero;
+#pragma unroll
+    for (int t = 0; t < kPfTiles; ++t) {
+      f32x4_t b = *(const f32x4_t*)(wb[t] + 8 * g);
+      if (!col_ok[t]) b = zero;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[t], 0, 0, 0);
+    }
+  }
+  if (g1 > Gfull) {                                                    // the last, partial 8-k group (3V % 8 != 0)
+    f32x4_t a = zero;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 8 * Gfull + 4 * h + i;
+      if (k < V3 && row_ok) a[i] = gv[(size_t)row * V3 + k];
+    }
+#pragma unroll
+    for (int t = 0; t < kPfTiles; ++t) {
+      f32x4_t b = zero;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 8 * Gfull + 4 * h + i;
+        if (k < V3 && col_ok[t]) b[i] = posedirs[(size_t)(32 * t + mi) * V3 + k];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[t], 0, 0, 0);
+    }
+  }
+  // accumulator layout: column = mi, row = (r & 3) + 8 (r >> 2) + 4 h; one 32 x 32 tile at a time through the LDS reduction
+#pragma unroll
+  for (int t = 0; t < kPfTiles; ++t) {
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][(r & 3) + 8 * (r >> 2) + 4 * h][mi] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0 && 32 * t + mi < 208) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m0 + rr < B) part[((size_t)sp * B + m0 + rr) * 208 + 32 * t + mi] = ((acc[t][r] + red[0][rr][mi]) + red[1][rr][mi]) + red[2][rr][mi];
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ void posefeat_sum_kernel(const float* __restrict__ part, float* __restrict__ gpf, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = part[i];
+#pragma unroll
+  for (int q = 1; q < kPfSplit; ++q) s += part[(size_t)q * n + i];
+  gpf[i] = s;
+}
+
 __global__ __launch_bounds__(256) void posefeat_bwd_kernel(const float* __restrict__ gvp, SmplDev S, float* __restrict__ gpf, int B) {
   const int jr = blockIdx.x, b0 = blockIdx.y * kBG, nb = min(kBG, B - b0), tid = threadIdx.x;
   const int V3 = S.V * 3;
@@ -641,6 +733,7 @@ struct Scratch {
   int* idx;      // [B][N]
   float* gA;     // [B][24][12]
   float* gpf;    // [B][208]
+  float* gpf_part;   // [kPfSplit][B][208] partial sums of posefeat_bwd_mfma_kernel
 };
 
 Scratch carve_scratch(void* base, int B, int N) {
@@ -650,7 +743,8 @@ Scratch carve_scratch(void* base, int B, int N) {
   s.count = (int*)p;   p += round_up((int64_t)B * 4, 256);
   s.idx = (int*)p;     p += round_up((int64_t)B * N * 4, 256);
   s.gA = (float*)p;    p += round_up((int64_t)B * kJ * 12 * 4, 256);
-  s.gpf = (float*)p;
+  s.gpf = (float*)p;   p += round_up((int64_t)B * 208 * 4, 256);
+  s.gpf_part = (float*)p;
   return s;
 }
 
@@ -718,7 +812,13 @@ int backward_impl(ehm_smpl* h, const float* betas, const float* x, const float* 
   }
   {
     EhmProfScope ps(EHM_PROF_G_POSEFEAT_BWD, st);
-    hipLaunchKernelGGL(posefeat_bwd_kernel, dim3(kJ - 1, (unsigned)b_groups), dim3(256), 0, st, gverts, d, s.gpf, B);
+    static const bool valu = [] { const char* e = getenv("EHM_POSEFEAT_VALU"); return e && e[0] == '1'; }();
+    if (valu) {
+      hipLaunchKernelGGL(posefeat_bwd_kernel, dim3(kJ - 1, (unsigned)b_groups), dim3(256), 0, st, gverts, d, s.gpf, B);
+    } else {
+      hipLaunchKernelGGL(posefeat_bwd_mfma_kernel, dim3((unsigned)ceil_div(B, 32), kPfSplit), dim3(256), 0, st, gverts, d.posedirs, s.gpf_part, B, d.V * 3);
+      hipLaunchKernelGGL(posefeat_sum_kernel, dim3((unsigned)ceil_div((int64_t)B * 208, 256)), dim3(256), 0, st, s.gpf_part, s.gpf, B * 208);
+    }
   }
   hipLaunchKernelGGL(chain_bwd_kernel, dim3(B), dim3(64), 0, st, betas, x, mean, std_, d, s.gA, s.gpf, gpose);
   EHM_LAUNCH_CHECK();
@@ -729,7 +829,7 @@ int backward_impl(ehm_smpl* h, const float* betas, const float* x, const float* 
 
 int64_t ehm_guidance_scratch_bytes(int B, int N) {
   return round_up((int64_t)B * 6 * 4, 256) + round_up((int64_t)B * 4, 256) + round_up((int64_t)B * N * 4, 256) +
-         round_up((int64_t)B * kJ * 12 * 4, 256) + round_up((int64_t)B * 208 * 4, 256);
+         round_up((int64_t)B * kJ * 12 * 4, 256) + round_up((int64_t)B * 208 * 4, 256) + round_up((int64_t)kPfSplit * B * 208 * 4, 256);
 }
 
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,

@@ -430,13 +430,18 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
 // 256 x 256 macro-tile for M = 256, i.e. 4 - 8 workgroups and 170 - 450 us per GEMM.  Here one block owns a 32 x 32 output tile, its
 // four waves split K and reduce through LDS (deterministic, no atomics): 512 - 2048 blocks, a few microseconds.
 // A fragment: lane (row = l & 31, h = l >> 5) loads X[row][k + 4 h .. + 3]; MFMA i of an 8-k group contracts k + i and k + 4 + i.
-__global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                                              float* __restrict__ Y, int M, int K, int N, int relu) {
-  __shared__ float red[3][32][33];
+// NW waves split K (in units of 8-k groups); NW = 16 for long K: a wave's whole K range is in flight at once, 32 waves per CU hide the latency
+// of the (strided, first-touch) weight loads - with 4 waves the 2048-deep projections of FusedSampler.prepare took 120 - 150 us for 15 us of
+// matrix time.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_f32_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                  float* __restrict__ Y, int M, int K, int N, int relu) {
+  __shared__ float red[NW - 1][32][33];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mi = lane & 31, h = lane >> 5;
   const int n0 = 32 * blockIdx.x, m0 = 32 * blockIdx.y;
-  const int kq = K / 4, k_begin = wave * kq;
+  const int G = K / 8;
+  const int k_begin = 8 * (int)((long long)wave * G / NW), kq = 8 * (int)((long long)(wave + 1) * G / NW) - k_begin;
   const int row = m0 + mi;
   const bool row_ok = row < M;
   const float* xa = X + (size_t)(row_ok ? row : 0) * K + k_begin + 4 * h;
@@ -465,7 +470,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-      float v = ((acc[r] + red[0][rr][mi]) + red[1][rr][mi]) + red[2][rr][mi] + add;
+      float v = acc[r];
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) v += red[w][rr][mi];          // (k order: wave 0, 1, 2, ...)
+      v += add;
       if (relu) v = fmaxf(v, 0.f);
       if (m0 + rr < M) Y[(size_t)(m0 + rr) * N + n0 + mi] = v;
     }
@@ -602,8 +610,9 @@ extern "C" int ehm_skinny_gemm_f32(const float* X, const float* W, const float* 
     ehm_set_error("ehm_skinny_gemm_f32 needs K %% 32 == 0, N %% 32 == 0 and a 16-byte aligned X (K = %d, N = %d)", K, N);
     return EHM_EINVAL;
   }
-  hipLaunchKernelGGL(skinny_gemm_f32_kernel, dim3((unsigned)(N / 32), (unsigned)ceil_div(M, 32)), dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, M,
-                     K, N, relu);
+  const dim3 grid((unsigned)(N / 32), (unsigned)ceil_div(M, 32));
+  if (K >= 1024) hipLaunchKernelGGL(skinny_gemm_f32_kernel<16>, grid, dim3(1024), 0, (hipStream_t)stream, X, W, bias, Y, M, K, N, relu);
+  else hipLaunchKernelGGL(skinny_gemm_f32_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, X, W, bias, Y, M, K, N, relu);
   EHM_LAUNCH_CHECK();
   return 0;
 }

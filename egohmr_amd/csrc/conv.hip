@@ -265,6 +265,10 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   static_assert(!(SK && DS), "the dual-source conv runs whole tiles");
   constexpr int XBN = 64 * NU, XSTG = x_stage_floats(NU);
   __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 / 64 KiB; the ONLY LDS object
+  // MODE.FP16_OVFL = 1 for the life of the wave: every f32 -> f16 conversion of the epilogue clamps to +-65504 instead of producing inf - the
+  // same results on finite values as the explicit clamps it replaces (4 of the ~8 vector-ALU instructions per output value: v_med3 + its
+  // canonicalising v_max, twice), as in the GCN tile engine (gcn_tile.hip)
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
 
   constexpr int KS = 2, NM = 9 * NU, NR = 6 + 2 * NU, NBD = 2 * NU;
   const int tid = threadIdx.x;
@@ -638,8 +642,8 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             if (relu) v[c] = fmaxf(v[c], 0.f);
-            hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
-            ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
+            hh[c] = (half_t)v[c];                              // (MODE.FP16_OVFL: the conversions saturate at +-65504, see the kernel's head)
+            ll[c] = (half_t)(v[c] - (float)hh[c]);
           }
           const unsigned int vo = (unsigned int)(8 * GP * ps + ISTEP * it3 + irow) * yrow + col_off;
           if (colw < p.Co) {

@@ -82,6 +82,10 @@ template <bool RELU_A, bool LIFT>
 __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   static_assert(!(RELU_A && LIFT), "the generated operand is already rectified");
   __shared__ __attribute__((aligned(16))) float lds[2 * LSTG];   // 80 KiB; the ONLY LDS object
+  // MODE.FP16_OVFL = 1 for the life of the wave: every f32 -> f16 conversion of the epilogue clamps to +-65504 instead of producing inf - the
+  // same results on finite values as the explicit clamps it replaces (4 of the ~8 vector-ALU instructions per output value: v_med3 + its
+  // canonicalising v_max, twice), as in the GCN tile engine (gcn_tile.hip)
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
 
   constexpr int KS = 2, NM = 18, NR = 10;
   const int tid = threadIdx.x;
@@ -176,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = fmaxf(fmaf(wk[e][2], pz[j], fmaf(wk[e][1], py[j], fmaf(wk[e][0], px[j], wk[e][3]))), 0.f);
-        hi[e] = (half_t)fminf(v, 65504.f);
-        lo[e] = (half_t)fminf(fmaxf(v - (float)hi[e], -65504.f), 65504.f);
+        hi[e] = (half_t)v;                                   // (MODE.FP16_OVFL: saturating conversions)
+        lo[e] = (half_t)(v - (float)hi[e]);
       }
       float* dst = lds + buf * LSTG + row * RK;
       *(half8*)(dst + ((wave ^ key) << 2)) = hi;                  // logical chunk 2 s + g = wave: k = 8 wave .. + 7
@@ -385,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
           half8 hh, ll;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            hh[c] = (half_t)fminf(fmaxf(v[c], -65504.f), 65504.f);
-            ll[c] = (half_t)fminf(fmaxf(v[c] - (float)hh[c], -65504.f), 65504.f);
+            hh[c] = (half_t)v[c];                              // (MODE.FP16_OVFL: the conversions saturate at +-65504, see the kernel's head)
+            ll[c] = (half_t)(v[c] - (float)hh[c]);
           }
           const unsigned int vo = (unsigned int)(8 * Gq + rr) * yrow + col_off;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);

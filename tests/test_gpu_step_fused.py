@@ -92,7 +92,10 @@ def test_fused_step_launch_without_per_step_skinning_and_unfused_passes(dev, smp
 
 
 def test_fused_step_launch_under_collision_guidance(dev, smpl_asset):
-    """guided steps: the gradient of step t enters the fused launch's update (gaussian_diffusion.py:378-385)"""
+    """guided steps: the gradient of step t enters the fused launch's update (gaussian_diffusion.py:378-385).  The collision gradient itself is
+    scattered with float atomics (csrc/guidance.hip: the order of the additions into a vertex varies from run to run), so two runs of the SAME
+    route already differ in the last bits now and then: equal within that noise here (as tests/test_gpu_api.py does for run_samples), and the
+    two routes must agree no worse than a route agrees with itself."""
     from egohmr_amd.diffusion import create_gaussian_diffusion
     from egohmr_amd.factory import batch_to_device
     model = _model(dev, smpl_asset, diffuse_fuse=True)
@@ -101,4 +104,8 @@ def test_fused_step_launch_under_collision_guidance(dev, smpl_asset):
     batch = batch_to_device(syn.make_batch(B, 1024, seed=9), dev)
     noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=9)).to(dev)
     kw = dict(ddim=False, guided=True, cond_grad_weight=0.3)
-    _same(_run(model, d, batch, noise, True, **kw), _run(model, d, batch, noise, False, **kw))
+    a, b, a2 = _run(model, d, batch, noise, True, **kw), _run(model, d, batch, noise, False, **kw), _run(model, d, batch, noise, True, **kw)
+    assert float((a["sample"] - _run(model, d, batch, noise, True, ddim=False)["sample"]).abs().max()) > 1e-4      # the guidance is live
+    for k in a:
+        assert float((a[k] - b[k]).abs().max()) <= 2e-5, (k, float((a[k] - b[k]).abs().max()))
+        assert float((a[k] - a2[k]).abs().max()) <= 2e-5, k

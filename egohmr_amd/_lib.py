@@ -28,22 +28,53 @@ class EgoHMRHipError(RuntimeError):
     pass
 
 
+HEADERS = ["common.h", "smpl_dev.h", "gcn_dev.h", "step_dev.h", "internal.h", "gcn_loop_dev.h", "gcn_loop_host.inc"]
+
+
 def build(verbose: bool = False, force: bool = False) -> str:
-    """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "smpl_dev.h"), os.path.join(CSRC, "gcn_dev.h"), os.path.join(CSRC, "step_dev.h"), os.path.join(CSRC, "internal.h"), os.path.join(INCLUDE, "egohmr_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU): one object per source, the sources in parallel, objects
+    kept under egohmr_amd/build/ and reused while neither their source, a header nor the flags changed."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS for the in-kernel time stamps (tools/stamp_tiles.py, tools/stamp_skin.py)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}", *extra,
-           *srcs, "-o", LIB_PATH]
+    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS (tools/stamp_*.py), -DEHM_WITH_LOOP_ENGINE (the one-launch loop experiment)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *extra]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "egohmr_hip.h")]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    tag = hashlib.sha1(" ".join([hipcc] + flags).encode()).hexdigest()[:10]
+    objdir = os.path.join(_HERE, "build", os.path.basename(LIB_PATH) + "." + tag)
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append((src, obj))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def compile_one(job):
+        cmd = [hipcc, *flags, "-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        return subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("EHM_BUILD_JOBS", min(len(jobs) or 1, os.cpu_count() or 1)))) as ex:
+        for (src, _), r in zip(jobs, ex.map(compile_one, jobs)):
+            if r.returncode != 0:
+                raise EgoHMRHipError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise EgoHMRHipError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        raise EgoHMRHipError(f"hipcc (link) failed:\n{r.stdout}\n{r.stderr}")
     return LIB_PATH
+
+
+def build_features() -> set:
+    """Optional parts the loaded library was built with (ehm_build_features): 'loop_engine', 'stamps'."""
+    return set(lib().ehm_build_features().decode().split())
 
 
 class GConvParams(C.Structure):
@@ -114,7 +145,7 @@ class NonlocalParams(C.Structure):
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int), ("loop_engine", C.c_int)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int), ("loop_engine", C.c_int), ("per_step_launches", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -123,6 +154,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PROTOTYPES = {
     "ehm_last_error": (C.c_char_p, []),
     "ehm_target_arch": (C.c_char_p, []),
+    "ehm_build_features": (C.c_char_p, []),
     "ehm_rot6d_to_rotmat": (_I, [_P, _P, _L, _I, _P]),
     "ehm_rot6d_to_rotmat_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
     "ehm_smpl_create": (_I, [C.POINTER(_P), _P, _P, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P]),

@@ -559,13 +559,24 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
           __hip_atomic_fetch_add(p.sk_flags + pc.tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       } else if (last_blk > owner) {
+        int gave_up = 0;
         if (tid == 0) {
           int spins = 0;
           while (__hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(last_blk - owner) && ++spins < (1 << 24))
             __builtin_amdgcn_s_sleep(2);
+          gave_up = spins >= (1 << 24);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        __syncthreads();
+        // never hang the device - but never hand out a sum with a missing K range either: a tile whose partners did not arrive in ~1 s (a
+        // preempted / shared GPU) comes out as NaN, which the callers' finite checks and every downstream consumer make loud
+        if (__syncthreads_or(gave_up)) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[t][u][r] = __builtin_nanf("");
+        }
         for (int q = 0; q < last_blk - owner; ++q) {
           const float* theirs = part + (size_t)q * NACC * 256 + tid;
 #pragma unroll
@@ -707,7 +718,7 @@ SkPlan sk_plan(const ehm_conv_x2_desc* d, int Ho, int Wo) {
   const int64_t rounds = ceil_div(s.tiles, slots);
   const double eff = (double)s.tiles / (double)(rounds * slots);
   // (K loops shorter than 64 K tiles: measured slower - the 96 KiB partial-sum hand-off of a cut tile costs more than the idle slots)
-  if (d->x2 != nullptr || KT % 2 != 0 || KT < 64 || eff >= 0.875 || s.tiles < slots / 2 || getenv("EHM_CONV_NO_STREAMK")) return s;
+  if (d->x2 != nullptr || KT % 2 != 0 || KT < 64 || eff >= 0.875 || s.tiles < slots / 2) return s;
   const int P2 = KT / 2;
   const int64_t U2 = s.tiles * P2;
   s.per = (int)ceil_div(U2, slots);

@@ -89,37 +89,6 @@ struct ChainArgs {
   unsigned int* sticky;     // never cleared by a launch: accumulates err over a whole sampling loop (ehm_gcn_stack_status)
   unsigned int* finished;   // blocks that ran out of tickets; the last one audits done[nl-1][*]
   int nq;                   // queues = XCDs
-  int slab_groups;          // 1: a queue's tickets run (layer, row tile, channel tile); g > 1 (measurement, EHM_CHAIN_SLAB_GROUPS): (layer, channel-tile
-                            // group, row tile, channel tile in the group) - a group's 1/g of the layer's weight slab is shared by all row tiles in flight
-};
-
-// The one-launch sampling loop (MODE 2 of run_tiles): `nsteps` consecutive unguided denoising steps of ONE precision in a single persistent
-// launch.  Work items per step and 8-body group G (row tiles m = pass * ngroups + G): INPUT (hoisted input conv of the group's rows, `ny` items
-// per row tile) -> hidden convs (the chain's tiles) -> OUT (output-conv responses of a row tile) -> BODY (the group's 8 bodies: output mix,
-// sampler update, pose chain, blend fragments) -> INPUT of the next step.  All of a group's items live in queue G % nq (one XCD: one L2);
-// the groups of a queue alternate between two classes whose steps are offset by half a step in the ticket order, so that while one class
-// walks the short OUT -> BODY -> INPUT chain the blocks of the XCD have a full slot of the other class's conv tiles to run.
-// What only the items that are not conv tiles need lives in DEVICE memory (ehm_gcn::loop_extra) and is read where it is used: as kernel
-// arguments these ~1 KiB were kept in SGPRs across the conv tiles' K loop (848 spilled SGPRs, scratch traffic inside the K loop).
-struct LoopExtra {
-  GcnInputArgs in;           // tvec = the segment's first step; Y = buf[0]; x = the loop state x_t [B,144]
-  float* hs;                 // [m_tiles * 192, 12]
-  StepBodyArgs sb;           // per-step fields (c, noise, x_next, do_pose, Aws, pf, trace) are filled per item
-  const ehm_step_coefs* coefs;   // device [nsteps]
-  SmplDev S;
-  float* A_steps; sk_half8* pf_steps;      // [nsteps][B,24,12], [nsteps][ceil(B/32),14,2,64]
-  long long A_stride, pf_stride, tvec_stride, noise_stride;   // elements per step
-  float* trace;              // [nsteps,B,144] or nullptr
-  float* x_final;            // where the segment's LAST step writes x_{t-1} (the state buffer itself unless it is the loop's last step)
-  int lbs_every_step, last_is_final;
-};
-struct LoopArgs {
-  ChainArgs c;               // layers, buf, nl, m_tiles (= passes * ngroups), n_tiles, tickets, done [nl][m_tiles], err, sticky, finished, nq
-  int nsteps, passes, ngroups, ny;
-  unsigned int *in_done, *out_done, *body_done;   // [m_tiles], [m_tiles], [ngroups]: monotone counts of completed INPUT / OUT / BODY items
-  unsigned int *item_tickets, *alive, *item_finished;   // [8], [8] item blocks resident per queue, [1]
-  const LoopExtra* ex;       // device
-  int n_items;               // the first n_items blocks of the grid run the items that are not conv tiles
 };
 
 struct OneArgs {
@@ -141,183 +110,20 @@ __device__ __forceinline__ const float* layer_weights(const LayerDev& L) {
 // channels - the activation tile is staged once for both channel halves, 56 KiB instead of 80 KiB of operands per K tile and CU; with
 // one MFMA per product the K loop is bound by LDS bandwidth (writes + fragment reads), see DESIGN.md 3.2.
 
-#ifdef EHM_LOOPSTAT
-// per-block time accounting of the one-launch loop (tools/loop_stats.py): [blocks][16] cycles / counts
-__device__ unsigned long long* g_lstat = nullptr;
-#define LSTAT_DECL unsigned long long ls_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ls_t0 = __builtin_amdgcn_s_memtime()
-#define LSTAT_T() __builtin_amdgcn_s_memtime()
-#define LSTAT_ADD(i, v) ls_[i] += (v)
-#define LSTAT_FLUSH() do { ls_[0] = __builtin_amdgcn_s_memtime() - ls_t0; if (g_lstat && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_lstat[(size_t)blockIdx.x * 16 + i_] = ls_[i_]; } while (0)
-__device__ unsigned long long g_lwait = 0;   // (scratch for the per-lane wait accounting below)
+#ifdef EHM_WITH_LOOP_ENGINE
+#include "gcn_loop_dev.h"
 #else
+// MODE 2 of run_tiles (the one-launch sampling loop) is an experiment that the default build leaves out (gcn_loop_dev.h): the engine's
+// `if constexpr (LOOP)` branches only need these names to parse
+struct LoopArgs;
+template <bool TILES> __device__ unsigned long long loop_decode(unsigned int, unsigned int, unsigned int, const LoopArgs*);
+template <bool TILES> __device__ unsigned int loop_period_items(const LoopArgs*, unsigned int);
+template <int P, int NW> __device__ void loop_item_input(float*, const LoopArgs*, int, int, int, unsigned long long* = nullptr);
 #define LSTAT_DECL do { } while (0)
 #define LSTAT_T() 0ull
 #define LSTAT_ADD(i, v) do { } while (0)
 #define LSTAT_FLUSH() do { } while (0)
 #endif
-
-// ------------------------------------------------------------------------------------------------ one-launch loop: items that are not conv tiles
-// They run in their OWN kernel (gcn_loop_items_kernel, a few blocks per XCD, launched beside the tile kernel): inlined into the tile kernel
-// they kept ~700 more scalars alive across the conv tiles' K loop and it reloaded spilled registers between the operand DMA and the MFMAs
-// that were supposed to cover it (1.5 ms per step instead of 1.05); as real calls they cost a stack frame per wave.
-//
-// ticket -> (step, stage, class, group, item) by arithmetic.  A period = one step's worth of a queue's items; stage s of class-0 groups sits
-// at slot s of the period, stage s of class-1 groups half a period later (their late stages belong to the previous period's step).
-// Stages: 0 INPUT, 1..nl hidden conv, nl + 1 OUT, nl + 2 BODY.  Packed result: kind | layer << 3 | n_tile << 8 | m_tile << 20 | step << 40.
-template <bool TILES>   // TILES: the conv tiles' sequence (stages 1..nl); else the sequence of the other items (INPUT, OUT, BODY)
-__device__ __forceinline__ int loop_stage_items(const LoopArgs* a, int stage) {
-  // the tile blocks also run the INPUT items (VALU work for the whole chip: 16 item blocks cannot carry it), the item blocks OUT and BODY
-  if (TILES) return stage == 0 ? a->passes * a->ny : ((stage >= 1 && stage <= a->c.nl) ? a->passes * a->c.n_tiles : 0);
-  if (stage == a->c.nl + 1) return a->passes;
-  if (stage == a->c.nl + 2) return 2;              // a group's 8 bodies as two items of 4 (one wave per body)
-  return 0;
-}
-__device__ __forceinline__ int loop_queue_groups(const LoopArgs* a, unsigned int q) {
-  return (int)q < a->ngroups ? (a->ngroups - (int)q + a->c.nq - 1) / a->c.nq : 0;     // groups q, q + nq, ...
-}
-template <bool TILES>
-__device__ __forceinline__ unsigned int loop_period_items(const LoopArgs* a, unsigned int q) {
-  int per_group = 0;
-  for (int st = 0; st < a->c.nl + 3; ++st) per_group += loop_stage_items<TILES>(a, st);
-  return (unsigned int)(loop_queue_groups(a, q) * per_group);
-}
-template <bool TILES>
-__device__ __forceinline__ unsigned long long loop_decode(unsigned int t, unsigned int q, unsigned int period_items, const LoopArgs* a) {
-  const int ngq = loop_queue_groups(a, q);
-  const int ns = a->c.nl + 3, nsp = ns + (ns & 1);
-  const int period = (int)(t / period_items);
-  int r = (int)(t % period_items);
-  for (int vt = 0; vt < nsp; ++vt)
-    for (int cls = 0; cls < 2; ++cls) {
-      int stage = vt - cls * (nsp / 2), soff = 0;
-      if (stage < 0) { stage += nsp; soff = -1; }
-      const int pc = loop_stage_items<TILES>(a, stage), ng = cls ? ngq / 2 : (ngq + 1) / 2, c = pc * ng;
-      if (r >= c) { r -= c; continue; }
-      const int gi = r / pc, ri = r % pc;
-      const int G = (int)q + a->c.nq * (2 * gi + cls);
-      const int step = period + soff;
-      if (step < 0 || step >= a->nsteps) return (unsigned long long)K_SKIP;      // the pipeline's lead-in / drain
-      int kind, layer = 0, m = G, n = 0;
-      if (stage == 0) { kind = K_INPUT; m = (ri / a->ny) * a->ngroups + G; n = ri % a->ny; }
-      else if (stage <= a->c.nl) { kind = K_HIDDEN; layer = stage - 1; m = (ri / a->c.n_tiles) * a->ngroups + G; n = ri % a->c.n_tiles; }
-      else if (stage == a->c.nl + 1) { kind = K_OUT; m = ri * a->ngroups + G; }
-      else { kind = K_BODY; n = ri; }
-      return (unsigned long long)kind | ((unsigned long long)layer << 3) | ((unsigned long long)n << 8) | ((unsigned long long)m << 20) |
-             ((unsigned long long)step << 40);
-    }
-  return (unsigned long long)K_SKIP;
-}
-__device__ __forceinline__ void loop_wait(const unsigned int* f, unsigned int target, const ChainArgs& c, unsigned int code, unsigned long long* waited = nullptr) {   // one lane; never hangs the device
-  [[maybe_unused]] const unsigned long long w0 = LSTAT_T();
-  int spins = 0;
-  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(4);
-    ++spins;
-    if (spins > (1 << 22) || ((spins & 255) == 0 && __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-      if (spins > (1 << 22)) __hip_atomic_fetch_or(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (who gave up first: EHM_LOOP_DEBUG prints the word)
-      __hip_atomic_fetch_or(c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(c.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-  }
-  if (waited) *waited += LSTAT_T() - w0;
-}
-// The items exchange data with other blocks of the launch through plain stores and loads bracketed by agent-scope fences: publish = every
-// wave drains its stores, barrier, ONE lane releases (write-back) and bumps the item's counter; consume = one lane waits for its counters and
-// acquires (drops this CU's stale L1 lines), barrier, plain vector loads.
-__device__ __forceinline__ void loop_publish(unsigned int* counter, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-__device__ __forceinline__ void loop_acquire(int tid) {
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-}
-// LoopExtra sits in constant-like device memory: scalar loads
-__device__ __forceinline__ const LoopExtra* loop_extra(const LoopArgs* a) {
-  // an OPAQUE copy of the pointer per item: the block's (loop-invariant, constant-address-space) fields cannot be hoisted out of the item -
-  // hoisted in front of the tile blocks' outer loop they stayed live across the conv tiles' K loop
-  unsigned long long v = (unsigned long long)(uintptr_t)a->ex;
-  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
-  asm volatile("" : "+s"(lo), "+s"(hi));
-  typedef const LoopExtra __attribute__((address_space(4))) CLoopExtra;
-  return (const LoopExtra*)(CLoopExtra*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-}
-// hoisted input conv of row tile m_tile, channel block n_tile (gcn_dev.h: gcn_input_body)
-template <int P, int NW>
-__device__ __forceinline__ void loop_item_input(float* lds, const LoopArgs* a, int step, int m_tile, int n_tile, unsigned long long* waited = nullptr) {
-  const int tid = threadIdx.x;
-  const LoopExtra& e = *loop_extra(a);
-  const int G = m_tile % a->ngroups;
-  if (tid == 0 && step > 0) loop_wait(a->body_done + G, 2u * (unsigned int)step, a->c, 0x10u, waited);
-  loop_acquire(tid);
-#ifndef EHM_ABL_NOITEMS
-  float* T = lds;                                  // 24 x 256 floats per 256 threads
-  float* xs = lds + (NW / 4) * kJ * 256;           // the group's x_t: 8 x 144 floats (another block of this launch wrote them)
-  for (int i = tid; i < 8 * kPoseDim; i += 64 * NW) xs[i] = e.in.x[(size_t)8 * G * kPoseDim + i];
-  __syncthreads();
-  GcnInputArgs g = e.in;
-  g.tvec = e.in.tvec + (size_t)step * e.tvec_stride;
-  static_assert(P == 3 && NW == 4, "the loop's input item is built for the split-f16 mode, 256 threads");
-  gcn_input_rows8<1>(T, tid, 8 * m_tile, n_tile, g, xs);
-#else
-  (void)e; (void)n_tile;
-#endif
-  loop_publish(a->in_done + m_tile, tid);
-}
-// output-conv responses of row tile m_tile (gcn_dev.h: gcn_out_dot_rows16)
-template <int P, int NW>
-__device__ __forceinline__ void loop_item_out(float* lds, const LoopArgs* a, int step, int m_tile, unsigned long long* waited = nullptr) {
-  const int tid = threadIdx.x;
-  const LoopExtra& e = *loop_extra(a);
-  const ChainArgs& c = a->c;
-  if (tid == 0) loop_wait(c.done + (size_t)(c.nl - 1) * c.m_tiles + m_tile, (unsigned int)(step + 1) * (unsigned int)c.n_tiles, c, 0x20u, waited);
-  __syncthreads();
-#ifndef EHM_ABL_NOITEMS
-  const float* X = (const float*)c.buf[((c.nl / 2 - 1) & 1) ? 0 : 2];    // where the last hidden conv writes (io_of)
-  const int64_t rows = (int64_t)c.m_tiles * 192;
-  (void)lds;
-  for (int sub = tid >> 6; sub < 12; sub += NW)      // a wave owns row groups sub, sub + 4, sub + 8: no LDS, no barrier, bit-equal to gcn_out_dot_kernel
-    gcn_out_dot_rows16_wave<P == 1, kLoadAux>(X, e.sb.O, e.hs, (int64_t)m_tile * 192 + 16 * sub, rows, tid & 63);
-#else
-  (void)e;
-#endif
-  loop_publish(a->out_done + m_tile, tid);
-}
-// the 8 bodies of group G: one wave per body (step_dev.h: step_body_one)
-template <int NW>
-__device__ __forceinline__ void loop_item_body(float* lds, const LoopArgs* a, int step, int G, int half, unsigned long long* waited = nullptr) {
-  const int tid = threadIdx.x;
-  if (tid == 0)
-    for (int p = 0; p < a->passes; ++p) loop_wait(a->out_done + p * a->ngroups + G, (unsigned int)(step + 1), a->c, 0x40u, waited);
-  loop_acquire(tid);
-#ifndef EHM_ABL_NOITEMS
-  const LoopExtra& e = *loop_extra(a);
-  StepBodyArgs sb = e.sb;
-  const bool last = step == a->nsteps - 1;
-  sb.c = e.coefs[step];
-  sb.noise = e.sb.noise + (size_t)step * e.noise_stride;
-  sb.x_next = last ? e.x_final : e.sb.x_next;
-  sb.do_pose = (e.lbs_every_step || (last && e.last_is_final)) ? 1 : 0;
-  sb.Aws = e.A_steps + (size_t)step * e.A_stride;
-  sb.pf = e.pf_steps + (size_t)step * e.pf_stride;
-  sb.trace = e.trace ? e.trace + (size_t)step * e.noise_stride : nullptr;
-  StepBodyLds* L = (StepBodyLds*)lds + (tid >> 6);
-  auto wsync = [] {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  static_assert(NW == 4, "one wave per body, four bodies per item");
-  step_body_one(8 * G + 4 * half + (tid >> 6), tid & 63, sb, e.S, *L, wsync);
-#endif
-  loop_publish(a->body_done + G, tid);
-}
 
 template <class A>
 __device__ __forceinline__ const ChainArgs& chain_view(const A& a) {
@@ -560,14 +366,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       o.step = (int)(v >> 40);
     } else if constexpr (CHAIN) {
       const int layer = (int)(t / ipl), r = (int)(t % ipl);
-      if (a.slab_groups > 1) {
-        const int per = (int)ipl / a.slab_groups, nt = a.n_tiles / a.slab_groups, grp = r / per, rr = r % per;
-        o.m_tile = (int)q + a.nq * (rr / nt);
-        o.n_tile = grp * nt + rr % nt;
-      } else {
-        o.m_tile = (int)q + a.nq * (r / a.n_tiles);
-        o.n_tile = r % a.n_tiles;
-      }
+      o.m_tile = (int)q + a.nq * (r / a.n_tiles);
+      o.n_tile = r % a.n_tiles;
       o.layer = layer;
       o.kind = K_HIDDEN; o.step = 0;
     }
@@ -1117,70 +917,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gcn_hidden_chain_ker
   run_tiles<P, 1, NW>(lds, a);
 }
 
-// The items of the one-launch loop that are not conv tiles, `item_blocks` per XCD: same queue (XCC id), same staggered order as the tile
-// kernel's blocks, their own ticket counter.
-template <int P>
-__device__ __forceinline__ void loop_items_main(float* lds, const LoopArgs& a) {
-  static_assert(kJ * 256 + 8 * kPoseDim + 64 <= 2 * stage_floats(4) && 4 * sizeof(StepBodyLds) <= 2 * stage_floats(4) * 4, "item scratch fits the block's LDS");
-  volatile unsigned int& slot = *(volatile unsigned int*)(lds + 2 * stage_floats(4) - 4);
-  const int tid = threadIdx.x;
-  const unsigned int q = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (unsigned int)a.c.nq;
-  if (tid == 0) __hip_atomic_fetch_add(&a.alive[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned int period = loop_period_items<false>(&a, q);
-  const unsigned int total = period * (unsigned int)(a.nsteps + 1);
-  LSTAT_DECL;
-  [[maybe_unused]] unsigned long long waited = 0;
-  while (period) {
-    __syncthreads();
-    if (tid == 0) slot = __hip_atomic_fetch_add(&a.item_tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned int t = __builtin_amdgcn_readfirstlane(slot);
-    if (t >= total) break;
-    const unsigned long long v = loop_decode<false>(t, q, period, &a);
-    const int kind = (int)(v & 7u), n_tile = (int)((v >> 8) & 0xfffu), m_tile = (int)((v >> 20) & 0xfffffu), step = (int)(v >> 40);
-    [[maybe_unused]] const unsigned long long lt1 = LSTAT_T();
-    [[maybe_unused]] const unsigned long long wz = waited;
-    if (kind == K_OUT) loop_item_out<P, 4>(lds, &a, step, m_tile, &waited);
-    else if (kind == K_BODY) loop_item_body<4>(lds, &a, step, m_tile, n_tile, &waited);
-    if (kind != K_SKIP) { LSTAT_ADD(2 * kind, LSTAT_T() - lt1 - (waited - wz)); LSTAT_ADD(2 * kind + 1, 1); }   // INPUT 2,3  OUT 4,5  BODY 6,7 (waiting excluded)
-    else LSTAT_ADD(9, 1);
-  }
-  LSTAT_ADD(13, waited);
-  LSTAT_ADD(14, 1);                                  // marks an item block
-  LSTAT_FLUSH();
-  // audit: the last item block to finish checks that every group went through all its steps (a queue whose XCD received no block would
-  // otherwise go unnoticed).  The host zeroes the sync words in front of every launch.
-  __syncthreads();
-  if (tid == 0) slot = __hip_atomic_fetch_add(a.item_finished, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)a.n_items - 1u ? 1u : 0u;
-  __syncthreads();
-  if (slot) {
-    bool ok = true;
-    for (int g = tid; g < a.ngroups; g += 256)
-      ok = ok && __hip_atomic_load(&a.body_done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u * (unsigned int)a.nsteps;
-    if (!ok) {
-      __hip_atomic_fetch_or(a.c.err, 0x81u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.c.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// host data -> device memory through the kernel-argument block (stream-ordered, no pinned staging to manage, no lifetime question)
-template <class T>
-__global__ void upload_words_kernel(T v, unsigned int* __restrict__ dst) {
-  const unsigned int* src = (const unsigned int*)&v;
-  for (int i = threadIdx.x; i < (int)(sizeof(T) / 4); i += blockDim.x) dst[i] = src[i];
-}
-struct CoefChunk { ehm_step_coefs c[64]; };
-
-// The one-launch sampling loop: the same tile engine, tickets over (step, stage, group) - see LoopArgs.
-template <int P, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gcn_loop_kernel(LoopArgs a) {
-  static_assert(P == 3 && NW == 4, "the one-launch loop is built for the split-f16 (parity) path");
-  __shared__ __attribute__((aligned(16))) float lds[2 * stage_floats(NW) + (NW == 8 ? 24 * 256 : 0)];
-  if ((int)blockIdx.x < a.n_items) loop_items_main<P>(lds, a);
-  else run_tiles<P, 2, NW>(lds, a);
-}
-
 // float32 [rows, K] <-> plain f16 [rows, K]
 __global__ void pack_half_kernel(const float* __restrict__ X, half_t* __restrict__ Y, size_t n, float scale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1216,9 +952,6 @@ bool shape_ok(const ehm_gcn* h, int64_t rows_pad) {
 
 }  // namespace
 
-#ifdef EHM_LOOPSTAT
-extern "C" int ehm_dbg_set_loopstat(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lstat), &q, sizeof(q)); }
-#endif
 #ifdef EHM_STAMPS
 extern "C" int ehm_dbg_set(void* p) { unsigned long long* q = (unsigned long long*)p; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tdbg), &q, sizeof(q)); }
 #endif
@@ -1296,11 +1029,6 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   a.nq = ehm_num_cus() / 32;
   if (a.nq < 1) a.nq = 1;
   if (a.nq > 8) a.nq = 8;
-  a.slab_groups = 1;
-  if (const char* e = getenv("EHM_CHAIN_SLAB_GROUPS")) {      // measurement switch (DESIGN 3.2 "slab order"): results are the same bits either way
-    const int g = atoi(e);
-    if (g > 1 && n_tiles % g == 0) a.slab_groups = g;
-  }
   if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL((gcn_hidden_chain_kernel<3, 4>), dim3(blocks), dim3(256), 0, st, a);
   else if (wide) hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 8>), dim3(blocks), dim3(512), 0, st, a);
   else hipLaunchKernelGGL((gcn_hidden_chain_kernel<1, 4>), dim3(blocks), dim3(256), 0, st, a);
@@ -1308,115 +1036,9 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   return 0;
 }
 
-// `nsteps` consecutive unguided steps in ONE launch (see LoopArgs).  Needs B % 8 == 0, no pass pruning map on the handle (every item runs
-// both passes), a chainable precision; the caller (sampler.hip) checks eligibility and runs the skinning of the steps afterwards.
-int ehm_upload_step_coefs(const ehm_step_coefs* host, ehm_step_coefs* dev, int n, hipStream_t st) {
-  for (int i = 0; i < n; i += 64) {
-    CoefChunk ch{};
-    const int m = n - i < 64 ? n - i : 64;
-    memcpy(ch.c, host + i, (size_t)m * sizeof(ehm_step_coefs));
-    hipLaunchKernelGGL(upload_words_kernel<CoefChunk>, dim3(1), dim3(256), 0, st, ch, (unsigned int*)(dev + i));
-    EHM_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-int ehm_gcn_tile_loop_impl(ehm_gcn* h, const ehm_loop_launch* L, hipStream_t st) {
-  const int nl = h->num_hidden;
-  const int ngroups = L->B / 8, m_tiles = L->passes * ngroups;
-  const int64_t rows_pad = (int64_t)m_tiles * 192;
-  if (L->B % 8 != 0 || nl < 2 || (nl & 1) || h->num_masked >= 0 || h->precision != EHM_PREC_F16X3 || L->nsteps < 1 || !shape_ok(h, rows_pad) ||
-      !h->loop_extra) {
-    ehm_set_error("ehm_gcn_tile_loop_impl: not eligible (B = %d, hidden convs = %d, pass map = %d, precision = %d)", L->B, nl, h->num_masked, h->precision);
-    return EHM_EINVAL;
-  }
-  const bool wide = h->precision != EHM_PREC_F16X3 && h->hid % 128 == 0;
-  const int n_tiles = h->hid / (wide ? 128 : 64);
-  if (h->reserved_rows < rows_pad) {
-    const int rc = ehm_gcn_reserve_rows(h, rows_pad);
-    if (rc != 0) return rc;
-  }
-  EHM_HIP(hipMemsetAsync(h->chain_sync, 0, h->chain_sync_words * sizeof(unsigned int), st));
-  h->chain_sync_clean = 0;                       // (the next per-step chained launch clears the words again)
-  LoopArgs a{};
-  a.c.layers = h->hidden_dev;
-  for (int i = 0; i < 3; ++i) a.c.buf[i] = L->bufs[i];
-  a.c.nl = nl; a.c.m_tiles = m_tiles; a.c.n_tiles = n_tiles;
-  a.c.tickets = h->chain_sync;
-  a.c.done = h->chain_sync + 8;
-  a.in_done = a.c.done + (size_t)nl * m_tiles;
-  a.out_done = a.in_done + m_tiles;
-  a.body_done = a.out_done + m_tiles;
-  h->chain_err_off = 8 + (size_t)(nl + 3) * m_tiles;
-  a.c.err = h->chain_sync + h->chain_err_off;
-  a.c.finished = a.c.err + 1;
-  a.item_finished = a.c.err + 2;
-  a.item_tickets = a.c.err + 8;
-  a.alive = a.c.err + 16;
-  a.c.sticky = h->chain_sticky;
-  a.c.nq = ehm_num_cus() / 32;
-  if (a.c.nq < 1) a.c.nq = 1;
-  if (a.c.nq > 8) a.c.nq = 8;
-  a.c.slab_groups = 1;
-  a.nsteps = L->nsteps; a.passes = L->passes; a.ngroups = ngroups; a.ny = (int)ceil_div(h->hid, 256);
-  LoopExtra e{};
-  e.in = *L->in;
-  e.hs = h->hs;
-  e.sb = *(const StepBodyArgs*)L->step_body;
-  e.sb.hs = h->hs;
-  e.sb.O = h->out;
-  e.coefs = L->coefs;
-  memcpy(&e.S, L->smpl_dev, sizeof(SmplDev));
-  e.A_steps = L->A_steps; e.pf_steps = (sk_half8*)L->pf_steps;
-  e.A_stride = (long long)L->B * kJ * 12;
-  e.pf_stride = (long long)(L->pf_bytes_per_step / 16);
-  e.tvec_stride = 2LL * h->hid;
-  e.noise_stride = (long long)L->B * kPoseDim;
-  e.trace = L->trace;
-  e.x_final = L->x_final;
-  e.lbs_every_step = L->lbs_every_step; e.last_is_final = L->last_is_final;
-  static_assert(sizeof(LoopExtra) <= EHM_LOOP_EXTRA_BYTES && sizeof(LoopExtra) % 4 == 0 && sizeof(LoopExtra) <= 3072, "ehm_gcn::loop_extra / kernel-argument size");
-  // (as a KERNEL ARGUMENT: captured at launch.  hipMemcpyAsync from this stack frame read it after the function had returned.)
-  hipLaunchKernelGGL(upload_words_kernel<LoopExtra>, dim3(1), dim3(256), 0, st, e, (unsigned int*)h->loop_extra);
-  EHM_LAUNCH_CHECK();
-  a.ex = (const LoopExtra*)h->loop_extra;
-  // ONE grid of 2 x CUs co-resident blocks (80 KiB of LDS each): the first `items` of them run the items that are not conv tiles (block
-  // specialisation: two kernels on two streams did not reliably start together - the tile blocks then waited for item blocks that were
-  // queued behind them), the others the conv tiles.
-  static int per_xcd = getenv("EHM_LOOP_ITEM_BLOCKS") ? atoi(getenv("EHM_LOOP_ITEM_BLOCKS")) : 2;
-  const int items = (per_xcd < 1 ? 1 : per_xcd) * a.c.nq;
-  a.n_items = items;
-  const int blocks = 2 * ehm_num_cus();
-  hipEvent_t dbg0 = nullptr, dbg1 = nullptr;
-  if (getenv("EHM_LOOP_DEBUG")) { (void)hipEventCreate(&dbg0); (void)hipEventCreate(&dbg1); (void)hipEventRecord(dbg0, st); }
-  hipLaunchKernelGGL((gcn_loop_kernel<3, 4>), dim3(blocks), dim3(256), 0, st, a);
-  EHM_LAUNCH_CHECK();
-  if (getenv("EHM_LOOP_DEBUG")) {          // debugging aid: wait for the two kernels and print the counters they left behind
-    (void)hipEventRecord(dbg1, st);
-    (void)hipStreamSynchronize(st);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, dbg0, dbg1);
-    fprintf(stderr, "loop: %.3f ms  ", ms);
-    (void)hipEventDestroy(dbg0); (void)hipEventDestroy(dbg1);
-    std::vector<unsigned int> w(h->chain_sync_words);
-    (void)hipMemcpy(w.data(), h->chain_sync, w.size() * sizeof(unsigned int), hipMemcpyDeviceToHost);
-    const size_t e0 = h->chain_err_off;
-    fprintf(stderr, "loop: nsteps %d m_tiles %d ngroups %d n_tiles %d ny %d items %d | err %u finished %u item_finished %u\n  tile tickets:", a.nsteps, m_tiles, ngroups,
-            n_tiles, a.ny, items, w[e0], w[e0 + 1], w[e0 + 2]);
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", w[i]);
-    fprintf(stderr, "\n  first timeout: word %u (done starts at 8, in at %d) target %u seen %u block %u queue %u", w[e0 + 3], 8 + nl * m_tiles, w[e0 + 4], w[e0 + 5], w[e0 + 6], w[e0 + 7]);
-    fprintf(stderr, "\n  item tickets:");
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", w[e0 + 8 + i]);
-    fprintf(stderr, "\n  alive:");
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", w[e0 + 16 + i]);
-    for (int l = 0; l < nl + 3; ++l) {
-      fprintf(stderr, "\n  %s", l < nl ? "done" : l == nl ? "in  " : l == nl + 1 ? "out " : "body");
-      for (int m = 0; m < m_tiles; ++m) fprintf(stderr, " %u", w[8 + (size_t)l * m_tiles + m]);
-    }
-    fprintf(stderr, "\n");
-  }
-  return 0;
-}
+#ifdef EHM_WITH_LOOP_ENGINE
+#include "gcn_loop_host.inc"
+#endif
 
 extern "C" int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, int group, void* stream) {
   EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0 && (group == 0 || group == 32));

@@ -9,7 +9,7 @@
 //   nearest_kernel       build-defined proxy: nearest body vertex of every selected point from an LDS-resident copy of
 //                        the body (SoA, broadcast reads), hinge relu(tau - d)^2, scatter of d loss / d vertex
 //   skin_bwd_kernel      VJP of the skinning + pose-corrective blend w.r.t. posed rest vertices and the 24 transforms
-//   posefeat_bwd_kernel  VJP of the 207-basis pose blend (a [B,20670] x [20670,207] contraction)
+//   posefeat_bwd_mfma_kernel  VJP of the 207-basis pose blend (a [B,20670] x [20670,207] contraction, exact-f32 MFMA)
 //   chain_bwd_kernel     one wave per body, lane = joint: reverse kinematic chain through LDS (children -> parent in
 //                        fixed order, deterministic), then the Gram-Schmidt (rot6d) VJP
 //   finish_kernel        -1/denom scaling, x2 for joints 3..23, zeroing of the upper-body joints (egohmr.py:562-567)
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void posefeat_bwd_mfma_kernel(const float* 
   }
   typedef float f32x16_t __attribute__((ext_vector_type(16)));
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef f32x4_t f32x4_u __attribute__((aligned(4)));   // rows of 3 V floats and a caller-owned basis: only dword-aligned (global dwordx4 loads accept that; the TYPE must say so)
   f32x16_t acc[kPfTiles];
 #pragma unroll
   for (int t = 0; t < kPfTiles; ++t)
@@ -463,11 +464,11 @@ __global__ __launch_bounds__(256, 2) void posefeat_bwd_mfma_kernel(const float* 
   const int ge = g1 < Gfull ? g1 : Gfull;
 #pragma unroll 2
   for (int g = g0; g < ge; ++g) {
-    f32x4_t a = *(const f32x4_t*)(xa + 8 * g);                       // (rows start at 4-byte multiples only: unaligned 16-byte loads)
+    f32x4_t a = *(const f32x4_u*)(xa + 8 * g);                       // (rows start at 4-byte multiples only: unaligned 16-byte loads)
     if (!row_ok) a = zero;
 #pragma unroll
     for (int t = 0; t < kPfTiles; ++t) {
-      f32x4_t b = *(const f32x4_t*)(wb[t] + 8 * g);
+      f32x4_t b = *(const f32x4_u*)(wb[t] + 8 * g);
       if (!col_ok[t]) b = zero;
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[t], 0, 0, 0);
@@ -519,45 +520,6 @@ __global__ void posefeat_sum_kernel(const float* __restrict__ part, float* __res
   gpf[i] = s;
 }
 
-__global__ __launch_bounds__(256) void posefeat_bwd_kernel(const float* __restrict__ gvp, SmplDev S, float* __restrict__ gpf, int B) {
-  const int jr = blockIdx.x, b0 = blockIdx.y * kBG, nb = min(kBG, B - b0), tid = threadIdx.x;
-  const int V3 = S.V * 3;
-  float acc[kBG][9];
-#pragma unroll
-  for (int bb = 0; bb < kBG; ++bb)
-#pragma unroll
-    for (int r = 0; r < 9; ++r) acc[bb][r] = 0.f;
-  for (int col = tid; col < V3; col += 256) {
-    float g[kBG];
-    bool nz = false;
-#pragma unroll
-    for (int bb = 0; bb < kBG; ++bb) {
-      g[bb] = bb < nb ? gvp[(size_t)(b0 + bb) * V3 + col] : 0.f;
-      nz |= g[bb] != 0.f;
-    }
-    if (!nz) continue;
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const float pd = S.posedirs[(size_t)(jr * 9 + r) * V3 + col];
-#pragma unroll
-      for (int bb = 0; bb < kBG; ++bb) acc[bb][r] = fmaf(pd, g[bb], acc[bb][r]);
-    }
-  }
-  __shared__ float red[4][kBG * 9];
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int bb = 0; bb < kBG; ++bb)
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const float s = wave_sum(acc[bb][r]);
-      if (lane == 0) red[wave][bb * 9 + r] = s;
-    }
-  __syncthreads();
-  if (tid < nb * 9) {
-    const int bb = tid / 9, r = tid % 9;
-    gpf[(size_t)(b0 + bb) * 208 + jr * 9 + r] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-  }
-}
 
 // VJP of R = rot6d_to_rotmat(a1, a2) (utils/geometry.py:59-66): gR [9] row-major -> (ga1, ga2)
 __device__ __forceinline__ void rot6d_bwd(float a1x, float a1y, float a1z, float a2x, float a2y, float a2z, const float (&gR)[9],
@@ -812,13 +774,8 @@ int backward_impl(ehm_smpl* h, const float* betas, const float* x, const float* 
   }
   {
     EhmProfScope ps(EHM_PROF_G_POSEFEAT_BWD, st);
-    static const bool valu = [] { const char* e = getenv("EHM_POSEFEAT_VALU"); return e && e[0] == '1'; }();
-    if (valu) {
-      hipLaunchKernelGGL(posefeat_bwd_kernel, dim3(kJ - 1, (unsigned)b_groups), dim3(256), 0, st, gverts, d, s.gpf, B);
-    } else {
-      hipLaunchKernelGGL(posefeat_bwd_mfma_kernel, dim3((unsigned)ceil_div(B, 32), kPfSplit), dim3(256), 0, st, gverts, d.posedirs, s.gpf_part, B, d.V * 3);
-      hipLaunchKernelGGL(posefeat_sum_kernel, dim3((unsigned)ceil_div((int64_t)B * 208, 256)), dim3(256), 0, st, s.gpf_part, s.gpf, B * 208);
-    }
+    hipLaunchKernelGGL(posefeat_bwd_mfma_kernel, dim3((unsigned)ceil_div(B, 32), kPfSplit), dim3(256), 0, st, gverts, d.posedirs, s.gpf_part, B, d.V * 3);
+    hipLaunchKernelGGL(posefeat_sum_kernel, dim3((unsigned)ceil_div((int64_t)B * 208, 256)), dim3(256), 0, st, s.gpf_part, s.gpf, B * 208);
   }
   hipLaunchKernelGGL(chain_bwd_kernel, dim3(B), dim3(64), 0, st, betas, x, mean, std_, d, s.gA, s.gpf, gpose);
   EHM_LAUNCH_CHECK();

@@ -26,6 +26,7 @@ int ehm_pose_steps_impl(ehm_smpl* smpl, const float* x0_steps, int nsteps, int f
                         const float* std_, float* A_steps, void* pf_steps, float* R, float* joints, float* pose6d, float* x0_final,
                         float* scratch_joints, hipStream_t st);
 int ehm_skin_min_bodies();
+int ehm_smpl_has_mfma_skin(const ehm_smpl* h);   // 0: a body model with more than four skinning weights per vertex (no MFMA fragments): VALU skinning inside every step
 int64_t ehm_skin_pf_bytes_per_step(int B);
 void ehm_smpl_dev(const ehm_smpl* h, void* out);   // copies the handle's SmplDev (smpl_dev.h) into *out
 size_t ehm_smpl_dev_size();
@@ -51,7 +52,8 @@ int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
                             hipStream_t st);
 int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
-// the one-launch sampling loop (gcn_tile.hip): launch description filled by sampler.hip
+#ifdef EHM_WITH_LOOP_ENGINE
+// the one-launch sampling loop (gcn_loop_host.inc, experiment): launch description filled by sampler.hip
 struct ehm_loop_launch {
   void* bufs[3];                 // activation ping-pong [passes * B * 24, hid]
   int B, passes, nsteps;
@@ -66,6 +68,7 @@ struct ehm_loop_launch {
 };
 int ehm_gcn_tile_loop_impl(ehm_gcn* h, const ehm_loop_launch* L, hipStream_t st);
 int ehm_upload_step_coefs(const ehm_step_coefs* host, ehm_step_coefs* dev, int n, hipStream_t st);
+#endif
 void ehm_pack_half(const float* X, void* Y, size_t n, float scale, hipStream_t st);
 // gcn.hip
 int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad);   // sync words + output-conv scratch for up to rows_pad rows (allocates: not inside a capture)

@@ -26,6 +26,16 @@ void ehm_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ehm_last_error(void) { return g_err; }
 extern "C" const char* ehm_target_arch(void) { return "gfx950"; }
+extern "C" const char* ehm_build_features(void) {
+  return ""
+#ifdef EHM_WITH_LOOP_ENGINE
+         "loop_engine "
+#endif
+#ifdef EHM_STAMPS
+         "stamps "
+#endif
+      ;
+}
 
 int ehm_num_cus() {   // of the CURRENT device (cached per ordinal)
   static int n[16] = {};
@@ -226,6 +236,12 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   EHM_CHECK_ARG(d->passes == 1 || ehm_gcn_virtual_bodies(gcn, d->B, 2) == d->B + (d->num_masked >= 0 ? d->num_masked : d->B));   // desc and ehm_gcn_set_pass_map agree
   const int hid = ehm_gcn_hid(gcn), nh = ehm_gcn_num_hidden(gcn), V = ehm_smpl_num_verts(smpl);
   EHM_CHECK_ARG(nh % 2 == 0);
+#ifndef EHM_WITH_LOOP_ENGINE
+  if (d->loop_engine) {
+    ehm_set_error("ehm_sample_desc.loop_engine = 1, but this library was built without -DEHM_WITH_LOOP_ENGINE (the one-launch loop is an experiment, DESIGN.md 3.7)");
+    return EHM_EINVAL;
+  }
+#endif
   bool any_guided = false;
   for (int k = 0; k < d->num_steps; ++k) any_guided |= steps[k].grad_scale != 0.f;
   EHM_CHECK_ARG(!any_guided || (scene && d->num_scene_points > 0 && !d->ddim));
@@ -258,8 +274,9 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   // step while others finish this one) + ONE skinning launch for the run.  Guided steps and ineligible shapes take the per-step launches below.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
+#ifdef EHM_WITH_LOOP_ENGINE
   const bool engine_ok = w.loop_seg > 0 && cap == hipStreamCaptureStatusNone && base_prec != 0 && nlp->Ci == 0 && nh >= 2 &&
-                         ehm_gcn_mask_slot(gcn, d->passes) == nullptr && ehm_gcn_chain_enabled(gcn);
+                         ehm_gcn_mask_slot(gcn, d->passes) == nullptr && ehm_gcn_chain_enabled(gcn) && ehm_smpl_has_mfma_skin(smpl);
   auto run_segment = [&](int k0, int k1) -> int {
     const int ns = k1 - k0;
     const bool final_seg = k1 == d->num_steps;
@@ -299,17 +316,20 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
                               w.loop_verts, w.loop_joints, st);
     return r;
   };
+#else
+  (void)cap;
+#endif
   // ---- deferred skinning of the per-step launches (see carve): slots filled since the last skinning launch
-  const bool defer_skin = w.skin_seg > 0 && d->lbs_every_step;
+  // (a body model with dense skinning weights has no MFMA fragments: its steps keep the VALU skinning launch of ehm_step_body_impl - the workspace
+  //  was sized without looking at the handle, the slots simply stay unused)
+  const bool defer_skin = w.skin_seg > 0 && d->lbs_every_step && ehm_smpl_has_mfma_skin(smpl);
   const int64_t pf_bytes_step = ehm_skin_pf_bytes_per_step(B);
   int pending = 0;
   bool pending_poses = false;       // the pending slots hold x0 only (fused step launches): their poses are still to be computed
   // ---- fused step launches (step.hip): output responses + per-body update + the next step's input conv as ONE launch per step.  Needs the
   //      step's pose off the per-step path: deferred skinning (poses computed per flush), or no per-step skinning at all (then the last step
   //      takes the per-step launches below, which end in the pose and the skinning launch).
-  const char* fused_e = getenv("EHM_STEP_FUSED");                 // "0": the per-step launches (A/B runs, the bit-equality tests)
-  const bool fused_env = !(fused_e && fused_e[0] == '0');
-  const bool fused_steps = fused_env && hid % 64 == 0 && (defer_skin || !d->lbs_every_step);
+  const bool fused_steps = !d->per_step_launches && hid % 64 == 0 && (defer_skin || !d->lbs_every_step);   // (per_step_launches: A/B runs, the bit-equality tests)
   if (defer_skin && B % 32 != 0) EHM_HIP(hipMemsetAsync(w.loop_pf, 0, (size_t)w.skin_seg * pf_bytes_step, st));   // padding bodies of every slot's last 32-body tile
   auto flush_skin = [&](bool final_step_inside) -> int {
     if (pending == 0) return 0;
@@ -326,6 +346,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   bool input_done = false;          // step k's input conv already ran inside step k-1's skinning launch
   for (int k = 0; k < d->num_steps && rc == 0; ++k) {
     const ehm_step_coefs& c = steps[k];
+#ifdef EHM_WITH_LOOP_ENGINE
     if (engine_ok && !input_done && c.grad_scale == 0.f && prec_of(k) == 1) {      // (the loop kernels are built for the split-f16 mode)
       int e = k;
       while (e < d->num_steps && e - k < w.loop_seg && steps[e].grad_scale == 0.f && prec_of(e) == prec_of(k)) ++e;
@@ -336,6 +357,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
         continue;
       }
     }
+#endif
     if (lowprec > 0) ehm_gcn_set_precision(gcn, prec_of(k));   // host-side kernel choice only; same X2 buffers
     const bool last = k == d->num_steps - 1;
     if (trace) EHM_HIP(hipMemcpyAsync(trace + (int64_t)k * n, w.x_cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -692,6 +692,7 @@ int ehm_skin_steps_impl(ehm_smpl* h, const float* A_steps, const void* pf_steps,
   return 0;
 }
 int ehm_skin_min_bodies() { return kSkinMfmaMinBodies; }
+int ehm_smpl_has_mfma_skin(const ehm_smpl* h) { return h->d.PDf != nullptr ? 1 : 0; }
 int64_t ehm_skin_pf_bytes_per_step(int B) { return (int64_t)ceil_div(B, 32) * kBlendSteps * 2 * 64 * 16; }
 void ehm_smpl_dev(const ehm_smpl* h, void* out) { memcpy(out, &h->d, sizeof(SmplDev)); }
 size_t ehm_smpl_dev_size() { return sizeof(SmplDev); }

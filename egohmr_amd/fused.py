@@ -144,7 +144,10 @@ class FusedSampler:
                batch["box_center"], batch["box_size"], batch["smpl_params"]["transl"]]
         if ins[0].shape[0] == 0:
             raise ValueError("empty batch (the reference fails on it too: egohmr.py:233 reshapes x_t [0, 144] to [0, 24, -1])")
-        key = tuple((id(t), t._version, t.data_ptr()) for t in ins) + self._param_key() + self._cond_param_key()
+        # ... and of the model switches that ehm_item_prep bakes into the cached state (the pass map's grouping, the camera-feature columns, the
+        # scene frame, which OpenPose joints feed the visibility mask)
+        switches = (int(getattr(m, "pass_group", 1)), bool(m.with_bbox_info), bool(m.with_cam_center), bool(m.scene_cano), tuple(m.openpose_to_smpl))
+        key = tuple((id(t), t._version, t.data_ptr()) for t in ins) + self._param_key() + self._cond_param_key() + (switches,)
         if self._prep is not None and self._prep_key == key:
             return self._prep
         self.gcn()
@@ -173,6 +176,9 @@ class FusedSampler:
         n_scene, n_tr = m.scene_enc.fc_c.out_features, te[2].out_features
         n_other = n_scene + n_tr + 1 + (3 if m.with_bbox_info else 0) + (2 if m.with_cam_center else 0)
         jm = getattr(self, "_joint_map", None)
+        if kp.dim() != 3 or kp.shape[2] != 3 or not all(0 <= int(k) < kp.shape[1] for k in m.openpose_to_smpl):
+            # (item_prep_kernel indexes keypoints_2d[b, joint_map[t], 2]: checked here, once per batch, instead of on the device)
+            raise ValueError(f"orig_keypoints_2d must be [B, NK, 3] with NK > max(openpose_to_smpl) = {max(m.openpose_to_smpl)}; got {tuple(kp.shape)}")
         if jm is None or jm[0] != (tuple(m.openpose_to_smpl), str(dev)):
             jm = self._joint_map = ((tuple(m.openpose_to_smpl), str(dev)), torch.tensor(m.openpose_to_smpl, dtype=torch.int32, device=dev))
         oth = torch.empty(B, f.k_oth, device=dev)
@@ -310,7 +316,9 @@ class FusedSampler:
         """The T ehm_step_coefs rows of a loop (newest first = execution order), cached on the diffusion object: every row costs a handful of
         float32 CPU tensor ops (GaussianDiffusion.step_coefs keeps torch's roundings), 100 rows ~ 3 ms of host time per call."""
         cache = diffusion.__dict__.setdefault("_ehm_step_tables", {})
-        key = (bool(ddim), float(cond_grad_weight), bool(guided))
+        # (the fingerprint of the tables the rows are computed from: a diffusion object whose betas / timestep map were edited in place gets new rows)
+        fp = hash((diffusion.betas.tobytes(), tuple(getattr(diffusion, "timestep_map", ()))))
+        key = (bool(ddim), float(cond_grad_weight), bool(guided), fp)
         if key not in cache:
             T = diffusion.num_timesteps
             rows = [diffusion.step_coefs(i, ddim, 0.0, cond_grad_weight, guided) for i in range(T - 1, -1, -1)]
@@ -709,13 +717,16 @@ class FusedSampler:
         # more than it when a sizeable share of the items has every joint visible
         engine = (bool(m.loop_engine) and not nonlocal_ci and B % 8 == 0 and B >= 24 and m.gcn_precision == "f16x3"
                   and not (passes == 2 and m.prune_passes and st.num_masked < m.loop_engine_min_masked * B))
+        if m.loop_engine and "loop_engine" not in _lib.build_features():
+            raise _lib.EgoHMRHipError("EgoHMR.loop_engine = True needs a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_LOOP_ENGINE "
+                                      "(the one-launch loop is an experiment that the default build leaves out, DESIGN.md 3.7)")
         self.last_engine = bool(engine)                   # (runs of >= 2 unguided steps of this call go through the one-launch loop)
         if engine:
             _lib.check(L.ehm_gcn_set_pass_map(self.gcn(), None, None, -1), "ehm_gcn_set_pass_map")
             num_masked = -1
         else:
             _, num_masked = self._apply_pass_map(st, passes)
-        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim), loop_engine=int(engine),
+        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim), loop_engine=int(engine), per_step_launches=int(bool(m.per_step_launches)),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
                                guide_denom=self.guide_denom(denom_items or B), tau=m.collision_tau, num_masked=num_masked,
                                guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=int(lowprec), nonlocal_ci=int(nonlocal_ci))

@@ -34,6 +34,9 @@ extern "C" {
 const char* ehm_last_error(void);
 /* compile-time facts, for the loader's sanity check: returns "gfx950" */
 const char* ehm_target_arch(void);
+/* optional parts this library was built with, space separated ("" for the default build): "loop_engine" (-DEHM_WITH_LOOP_ENGINE: the
+ * one-launch sampling loop experiment, ehm_sample_desc.loop_engine), "stamps" (-DEHM_STAMPS: in-kernel time stamps for tools/stamp_*.py) */
+const char* ehm_build_features(void);
 
 /* ------------------------------------------------------------------ geometry ------------------ */
 /* utils/geometry.py:47-66 rot6d_to_rotmat(x, rot6d_mode).  x6d [n,6] -> R [n,3,3].
@@ -411,9 +414,12 @@ typedef struct {
                          (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */
   int nonlocal_ci;    /* inter_channels of the non-local block set with ehm_gcn_set_nonlocal, 0 = none (needs float32 features:
                          handle mode 0 or 1 and lowprec_steps == 0)                                                              */
-  int loop_engine;    /* 1 = runs of consecutive unguided steps execute as ONE persistent launch + one skinning launch (same arithmetic,
-                         same results) when the shape allows it: B % 8 == 0, B >= 24, no pass pruning map (num_masked = -1), an f16 /
-                         split-f16 handle mode, no non-local block; 0 = one launch sequence per step                                 */
+  int loop_engine;    /* EXPERIMENT, off in the default build: 1 = runs of consecutive unguided steps execute as ONE persistent launch (bit-equal,
+                         measured 12 % slower).  Only a library built with -DEHM_WITH_LOOP_ENGINE accepts 1; the default one
+                         returns EHM_EINVAL.  Shape limits: B % 8 == 0, B >= 24, no pass map, split-f16 mode, no non-local block                */
+  int per_step_launches; /* 0 (default) = two launches per step: chained hidden convs, then step_fused_kernel (output responses + per-body
+                         update + the next step's input conv); 1 = the separate launches of rounds 2-3 (input conv, chain, responses, per-body
+                         step) - same bits, kept for A/B runs and the bit-equality tests                                                      */
 } ehm_sample_desc;
 
 /* GaussianDiffusion.p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508, :618-718)

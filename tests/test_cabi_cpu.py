@@ -136,3 +136,32 @@ def test_oracle_is_test_infrastructure_only():
         assert oracle_imports(f) == [], f
     assert set(oracle_imports(os.path.join(repo, "bench.py"))) == {"cpu_baseline"}
     assert set(oracle_imports(os.path.join(repo, "__graft_entry__.py"))) == {"smoke"}
+
+
+def test_default_library_has_no_experiment_and_no_env_switch_on_the_launch_path():
+    """the one-launch loop (bit-equal, 12 % slower) is an experiment - the default build() must not contain its kernel, and no
+    environment variable may change which kernels a caller's process runs: the only getenv left in the product sources is EHM_F16_CHAIN, read once in
+    ehm_gcn_create (handle creation); the rest sits behind -DEHM_STAMPS / -DEHM_WITH_LOOP_ENGINE, which build() does not set."""
+    import glob
+    from egohmr_amd import _lib
+    assert not os.environ.get("EHM_HIPCC_FLAGS") and not os.environ.get("EHM_LIB_PATH"), "this test is about the DEFAULT build"
+    _lib.build()
+    assert _lib.build_features() == set()
+    with open(_lib.LIB_PATH, "rb") as f:
+        blob = f.read()
+    assert b"gcn_loop_kernel" not in blob and b"gcn_hidden_chain_kernel" in blob
+    sites = []
+    for path in sorted(glob.glob(os.path.join(REPO, "egohmr_amd", "csrc", "*"))):
+        if os.path.basename(path) == "gcn_loop_host.inc":           # compiled only under -DEHM_WITH_LOOP_ENGINE
+            continue
+        depth = []                                                  # stack of "is this #if block an instrumentation flag"
+        for ln, line in enumerate(open(path), 1):
+            st = line.strip()
+            if st.startswith("#if"):
+                depth.append(("EHM_STAMPS" in st or "EHM_WITH_LOOP_ENGINE" in st or "EHM_LOOPSTAT" in st) and not st.startswith("#ifndef"))
+            elif st.startswith("#endif") and depth:
+                depth.pop()
+            elif "getenv(" in line and not any(depth):
+                sites.append((os.path.basename(path), ln, st))
+    assert [(f, s.split('getenv("')[1].split('"')[0]) for f, _, s in sites] == [("gcn.hip", "EHM_F16_CHAIN")], sites
+    assert not os.path.exists(os.path.join(REPO, "tools", "jobs"))

@@ -137,3 +137,36 @@ def test_module_calls_are_the_hip_path(dev, model, golden_dir):
     with torch.no_grad():
         c = model.scene_enc(torch.from_numpy(p["pts"]).to(dev))
     np.testing.assert_allclose(c.cpu().numpy(), p["feat"], atol=2e-5)
+
+
+@pytest.mark.parametrize("B,lbs_every_step", [(40, True), (40, False), (8, True)])
+def test_sampler_with_a_dense_skinning_weights_body_model(dev, synth_weights, smpl_asset, B, lbs_every_step):
+    """A body model whose vertices carry more than four skinning weights has no matrix-core skinning fragments (with B >= 24 and
+    lbs_every_step the loop used to pick deferred MFMA skinning from B alone and fail with EINVAL).  The sampling loop must fall back to the
+    VALU skinning inside every step and still match the oracle (which uses the same dense weights)."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    from oracle import model as om, sampler as osamp, schedule as osched
+    asset = dict(smpl_asset)
+    g = np.random.Generator(np.random.PCG64(77))
+    w = np.array(asset["lbs_weights"], dtype=np.float64).copy()
+    for v in g.choice(w.shape[0], size=w.shape[0] // 3, replace=False):
+        js = g.choice(w.shape[1], size=6, replace=False)
+        w[v] = 0.0
+        w[v, js] = g.uniform(0.05, 1.0, size=6)
+        w[v] /= w[v].sum()
+    asset["lbs_weights"] = w.astype(np.float32)
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, state_dict=synth_weights, smpl_asset=asset)
+    m.lbs_every_step = lbs_every_step
+    N, n, rs = 512, 50, "ddim5"
+    bnp = syn.make_batch(B, N, seed=83)
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
+    noise = syn.make_noise_stack(d.num_timesteps, B, seed=83)
+    out = d.val_losses(m, batch_to_device(bnp, dev), shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False,
+                       noise_stack=torch.from_numpy(noise).to(dev))
+    mean, std = syn.make_body_rep_stats(0)
+    ref = om.EgoHMROracle(synth_weights, asset, mean, std, faithful=False)
+    tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in bnp.items()}
+    ro = osamp.val_losses(ref, tb, osched.make_tables(n, rs), torch.from_numpy(noise), rs)
+    np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), ro["pred_vertices"].numpy(), atol=1e-4)
+    np.testing.assert_allclose(out["pred_keypoints_3d"].cpu().numpy(), ro["pred_keypoints_3d"].numpy(), atol=1e-4)

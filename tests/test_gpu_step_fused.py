@@ -3,9 +3,7 @@ one block per body; the steps' poses computed per skinning flush) against the pe
 step_body_kernel, gcn_input_kernel; models/egohmr/egohmr.py:232-260 around diffusion/gaussian_diffusion.py:298-337 / :511-556).
 
 Same device functions, same operation order per output: every result of a sampling call must be BIT-equal between the two routes
-(EHM_STEP_FUSED=0 selects the per-step launches), on every kind of loop the sampler runs."""
-import os
-
+(`EgoHMR.per_step_launches` / ehm_sample_desc.per_step_launches selects the per-step launches), on every kind of loop the sampler runs."""
 import pytest
 import torch
 
@@ -28,18 +26,14 @@ def _model(dev, smpl_asset, **kw):
 
 
 def _run(model, d, batch, noise, fused, **kw):
-    old = os.environ.get("EHM_STEP_FUSED")
-    os.environ["EHM_STEP_FUSED"] = "1" if fused else "0"
+    model.per_step_launches = not fused                   # ehm_sample_desc.per_step_launches
     try:
         fs = model.fused_sampler
         fs.invalidate()
         r = fs.run(d, dict(batch), noise, trace=True, **kw)
         torch.cuda.synchronize()
     finally:
-        if old is None:
-            del os.environ["EHM_STEP_FUSED"]
-        else:
-            os.environ["EHM_STEP_FUSED"] = old
+        model.per_step_launches = False
     o = r["other_outputs"]
     return {"sample": r["sample"].clone(), "x0": r["pred_xstart"].clone(), "verts": o["pred_vertices"].clone(), "joints": o["pred_keypoints_3d"].clone(),
             "R": o["pred_smpl_params"]["body_pose"].clone(), "orient": o["pred_smpl_params"]["global_orient"].clone(), "pose6d": o["pred_pose_6d"].clone(),

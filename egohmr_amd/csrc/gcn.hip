@@ -349,6 +349,11 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
     L.Ds = cursor;   cursor += (size_t)kJ * N;
     L.M1s = cursor;  cursor += (size_t)kJ * N;
   }
+  if (!with_w) {     // the input conv reads its tables per channel too (gcn_dev.h: gcn_input_body): [N][24] copies, unscaled
+    L.Ds = cursor;   cursor += (size_t)kJ * N;
+    L.M1s = cursor;  cursor += (size_t)kJ * N;
+    L.w_scale = 1.f;
+  }
   L.D = cursor;      cursor += (size_t)kJ * N;
   L.M1 = cursor;     cursor += (size_t)kJ * N;
   L.shift = cursor;  cursor += N;
@@ -362,6 +367,7 @@ static int pack_layer(const float* adj, const ehm_gconv_params& p, LayerDev& L, 
   hipLaunchKernelGGL(pack_epilogue_kernel, dim3((unsigned)ceil_div(N, threads)), dim3(threads), 0, st, adj, p, L.D, L.M1,
                      L.shift, L.Aoff);
   hipLaunchKernelGGL(pack_aoff_half_kernel, dim3(1), dim3(64), 0, st, L.Aoff, (half8*)L.AoffH);
+  if (!with_w) hipLaunchKernelGGL(scale_epilogue_kernel, dim3((unsigned)ceil_div(kJ * N, 256)), dim3(256), 0, st, L.D, L.M1, L.Ds, L.M1s, N, 1.f);
   EHM_LAUNCH_CHECK();
   if (with_w) {
     // power-of-two weight scale that keeps |W|*scale well inside f16 and pushes the lo parts out of the subnormal range
@@ -407,7 +413,7 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
   const size_t epi = (size_t)2 * kJ * hid_dim + hid_dim + kJ * kJ + 768;
-  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (5 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) +
+  size_t floats = epi * (1 + num_hidden) + (size_t)num_hidden * (5 * (size_t)hid_dim * hid_dim + 2 * kJ * hid_dim) + 2 * (size_t)kJ * hid_dim +
                   12 * (size_t)hid_dim + kJ * 6 + kJ * kJ + 8 + 64;
   if (hipMalloc(&g->arena, floats * sizeof(float)) != hipSuccess) {
     delete g;

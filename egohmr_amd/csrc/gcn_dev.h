@@ -233,6 +233,26 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
   const uint8_t* vb_ = vis + (size_t)b * kJ;
   float h0[kJ], h1[kJ];
   const float sh = L.shift[n];
+  // the channel's 24 + 24 table values from the [N][24] copies: twelve 16-byte loads instead of 48 strided dword loads (a unit's vector-memory
+  // instructions: 1280 bodies 303 -> 254 us per fused step launch when the second pass found them in registers - measured with the tables held
+  // across both passes at the cost of 88 spilled registers; as 16-byte loads they are cheap enough to fetch per unit)
+  float dj[kJ], mj[kJ];
+  {
+    typedef unsigned int u32x4_tb __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t dsB = ehm_buffer_rsrc(L.Ds), m1B = ehm_buffer_rsrc(L.M1s);   // (buffer form: as plain pointers out of the argument struct these became flat loads)
+    const unsigned int nrow = (unsigned int)n * (unsigned int)(kJ * 4);
+#pragma unroll
+    for (int q4 = 0; q4 < kJ / 4; ++q4) {
+      const u32x4_tb d4 = __builtin_amdgcn_raw_buffer_load_b128(dsB, nrow, 16 * q4, 0);
+      const u32x4_tb m4 = __builtin_amdgcn_raw_buffer_load_b128(m1B, nrow, 16 * q4, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned int du = d4[i], mu = m4[i];       // (hipcc: __builtin_bit_cast of a vector ELEMENT expression reads element 0)
+        dj[4 * q4 + i] = __builtin_bit_cast(float, du);
+        mj[4 * q4 + i] = __builtin_bit_cast(float, mu);
+      }
+    }
+  }
   // the two branches' sums as the halves of packed FMAs (v_pk_fma_f32: the same fused operations per half, two per instruction - this
   // kernel is bound by vector-ALU issue: ~940 scalar FMAs per lane before, 4 cycles apiece for a wave)
   const f32x2 img2 = {img[0], img[1]}, base2 = {base[0], base[1]};
@@ -248,8 +268,8 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
       const float xv = xb[j * 6 + c];
       s = __builtin_elementwise_fma(f32x2{xv, xv}, wx2[c], s);
     }
-    h0[j] = fmaf(L.D[j * N + n], s[0], sh);
-    h1[j] = L.M1[j * N + n] * s[1];
+    h0[j] = fmaf(dj[j], s[0], sh);
+    h1[j] = mj[j] * s[1];
   }
   // 24x24 adjacency mix per lane (one channel), then through a float [24][256] LDS tile so that the rows leave as 16-byte stores
   // (one dword per lane and joint is store-issue bound: 30 us for 48 MiB).
@@ -321,6 +341,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
   for (int i = 0; i < 3; ++i) {
     const int u = tid + 256 * i, j = u >> 5, c8 = (u & 31) * 8;   // (joint, 8 consecutive channels)
     if (nb + c8 >= N) continue;
+
     const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     const size_t row = (size_t)vb * kJ + j;
@@ -458,28 +479,30 @@ __device__ __forceinline__ f32x4 gcn_out_dot_quarter(const float* __restrict__ X
   const int kq = K / 4;                                              // this wave's K range (hid % 64 == 0: a multiple of 16)
   // a lane owns 8 consecutive k of every 32-k group (16 bytes of f16 / 32 bytes of float32 per load: the four lanes of a row cover a
   // 64 / 128-byte segment); MFMA c of the group contracts element c of all lanes, i.e. k = c, 8 + c, 16 + c, 24 + c
-  const float* xr = X + r * K + (size_t)wave * kq + 8 * q;
-  const half_t* xh = (const half_t*)X + r * K + (size_t)wave * kq + 8 * q;
+  // Both operands in buffer form (descriptor in SGPRs, one 32-bit lane offset, the k step as an immediate): as plain pointers taken out of the
+  // kernel-argument structs the loads were FLAT instructions (address-space check per lane, both wait counters).  AUX != 0: the rows were
+  // written by other blocks of THIS launch - cache-bypassing loads.
   typedef unsigned int u32x4_od __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(X);           // AUX != 0: the rows were written by other blocks of THIS launch - cache-bypassing loads
+  typedef unsigned int u32x2_od __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(X), rsW = ehm_buffer_rsrc(O.Wt);
   const unsigned int vox = (unsigned int)((r * K + (size_t)wave * kq + 8 * q) * (HALF_IN ? 2 : 4));
-  (void)rsX; (void)vox;
-  const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 8 * q;
+  const unsigned int vow = (unsigned int)(((size_t)(row < 12 ? row : 0) * K + (size_t)wave * kq + 8 * q) * 4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: the dependent-accumulator latency (40 cyc) exceeds the issue interval
 #pragma unroll 4
   for (int k = 0; k + 32 <= kq; k += 32) {
     float xv[8];
     if (HALF_IN) {
-      const half8 hv = AUX ? __builtin_bit_cast(half8, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 2, AUX)) : *(const half8*)(xh + k);
+      const half8 hv = __builtin_bit_cast(half8, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 2, AUX));
 #pragma unroll
       for (int c = 0; c < 8; ++c) xv[c] = (float)hv[c];
     } else {
-      const f32x4 x0 = AUX ? __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4, AUX)) : *(const f32x4*)(xr + k);
-      const f32x4 x1 = AUX ? __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4 + 16, AUX)) : *(const f32x4*)(xr + k + 4);
+      const f32x4 x0 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4, AUX));
+      const f32x4 x1 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4 + 16, AUX));
 #pragma unroll
       for (int c = 0; c < 4; ++c) { xv[c] = x0[c]; xv[4 + c] = x1[c]; }
     }
-    f32x4 w0 = *(const f32x4*)(wr + k), w1 = *(const f32x4*)(wr + k + 4);
+    f32x4 w0 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsW, vow, k * 4, 0));
+    f32x4 w1 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsW, vow, k * 4 + 16, 0));
     if (row >= 12) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
 #pragma unroll
     for (int c = 0; c < 4; c += 2) {
@@ -493,16 +516,16 @@ __device__ __forceinline__ f32x4 gcn_out_dot_quarter(const float* __restrict__ X
     }
   }
   if (kq & 16) {                                                      // hid % 128 != 0: one last 16-k group, four k per lane
-    const int k = kq - 16 - 4 * q;                                    // (undo the 8 q of the pointers: this group's lane stride is 4)
+    const int k = kq - 16 - 4 * q;                                    // (undo the 8 q of the lane offsets: this group's lane stride is 4)
     f32x4 xv;
     if (HALF_IN) {
       typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-      const half4_t hv = *(const half4_t*)(xh + k);          // (hid % 128 != 0 only: not used by the one-launch loop, which needs AUX loads)
+      const half4_t hv = __builtin_bit_cast(half4_t, (u32x2_od)__builtin_amdgcn_raw_buffer_load_b64(rsX, vox + (unsigned int)(k * 2), 0, AUX));
       xv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
     } else {
-      xv = *(const f32x4*)(xr + k);
+      xv = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox + (unsigned int)(k * 4), 0, AUX));
     }
-    f32x4 wv = *(const f32x4*)(wr + k);
+    f32x4 wv = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsW, vow + (unsigned int)(k * 4), 0, 0));
     if (row >= 12) wv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; c += 2) {
@@ -520,7 +543,9 @@ __device__ __forceinline__ void gcn_out_dot_rows16(const float* __restrict__ X, 
   const int lane = tid & 63, wave = tid >> 6;
   const int row = lane & 15, q = lane >> 4;
   const int64_t r = r0 + row < rows ? r0 + row : rows - 1;          // tail block: clamp the load, drop the store
-  const f32x4 acc = gcn_out_dot_quarter<HALF_IN, AUX>(X, O, r, wave, lane);
+  // (the quarter's lane offsets are 32-bit: hand it the matrix rebased at this block's first row)
+  const float* Xb = (const float*)((const char*)X + (size_t)r0 * O.K * (HALF_IN ? 2 : 4));
+  const f32x4 acc = gcn_out_dot_quarter<HALF_IN, AUX>(Xb, O, r - r0, wave, lane);
   // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
   for (int c = 0; c < 4; ++c) part[wave][4 * q + c][row] = acc[c];

@@ -329,7 +329,8 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   // ---- fused step launches (step.hip): output responses + per-body update + the next step's input conv as ONE launch per step.  Needs the
   //      step's pose off the per-step path: deferred skinning (poses computed per flush), or no per-step skinning at all (then the last step
   //      takes the per-step launches below, which end in the pose and the skinning launch).
-  const bool fused_steps = !d->per_step_launches && hid % 64 == 0 && (defer_skin || !d->lbs_every_step);   // (per_step_launches: A/B runs, the bit-equality tests)
+  const bool fused_steps = !d->per_step_launches && hid % 64 == 0 && (defer_skin || !d->lbs_every_step) &&
+                           w.rows_pad * hid * 4 < ((int64_t)1 << 32);   // (its row loads carry 32-bit byte offsets into the activation matrix)   // (per_step_launches: A/B runs, the bit-equality tests)
   if (defer_skin && B % 32 != 0) EHM_HIP(hipMemsetAsync(w.loop_pf, 0, (size_t)w.skin_seg * pf_bytes_step, st));   // padding bodies of every slot's last 32-body tile
   auto flush_skin = [&](bool final_step_inside) -> int {
     if (pending == 0) return 0;

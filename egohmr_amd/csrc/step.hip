@@ -24,23 +24,31 @@ struct StepFusedArgs {
   int do_input;
 };
 
-constexpr int kFusedThreads = 1024;            // 16 waves: 12 (tile, K quarter) pairs of the responses; 4 groups of 256 channels of the input conv
-constexpr int kFusedT = kJ * 256;              // floats of one group's transpose tile
+constexpr int kFusedT = kJ * 256;              // floats of one 256-channel group's transpose tile
 
-// LDS: 4 transpose tiles (96 KiB; the response partials alias the first 12 KiB) + the step's scratch
-template <bool HALF_IN, int OUT>
-__global__ __launch_bounds__(kFusedThreads) void step_fused_kernel(StepFusedArgs a) {
-  __shared__ __attribute__((aligned(16))) float T[4 * kFusedT];
+// NT threads per block = NT / 256 groups of 256 channels for the input conv, NT / 64 waves for the 12 (row tile, K quarter) pairs of the responses.
+//   NT = 1024 (batches of up to one body per CU): the round-4 shape - with one body per CU its chain of phases IS the launch's duration, and four
+//             groups walk the body's 8 input-conv units in two rounds (LDS 96 KiB: one block per CU);
+//   NT = 512  (bigger batches): 48 KiB of LDS and 128 registers let TWO blocks share a CU, so that one body's global-memory round trips hide behind
+//             another's vector-ALU work (1280 bodies: 297 -> 254 us per launch).
+// (Two half-blocks per body - each with half of the input-conv units, both recomputing the responses - were built too: 62 -> 70 us at 256 bodies,
+//  and a race: the chain's result and the next input rows share one buffer, which is only safe while ONE block reads a body's rows before it
+//  overwrites them.)  The update runs on three waves (48 elements each) instead of one.
+// Per output the arithmetic is that of the per-step kernels (same device functions, same order): bit-equal.
+template <bool HALF_IN, int OUT, int NT>
+__global__ __launch_bounds__(NT, 4) void step_fused_kernel(StepFusedArgs a) {
+  constexpr int G = NT / 256, NWV = NT / 64;                        // 256-thread groups, waves
+  __shared__ __attribute__((aligned(16))) float T[G * kFusedT];     // G transpose tiles (24 KiB each); the response partials alias the first 12 KiB
   __shared__ StepBodyLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, B = a.sb.B;
   const int slot = a.sb.passes == 2 ? (a.sb.mask_slot ? a.sb.mask_slot[b] : b) : -1;   // second pass of this body: rows of virtual body B + slot (< 0: none)
   const int nrows = slot >= 0 ? 2 * kJ : kJ;
 
-  // ---- responses of the body's rows: 16-row tiles over [pass 0 rows | pass 1 rows], four waves (K quarters) per tile
+  // ---- responses of the body's rows: 16-row tiles over [pass 0 rows | pass 1 rows], four K quarters per tile: 12 tasks
   float (*part)[4][16][16] = (float (*)[4][16][16])T;
-  if (wave < 12) {
-    const int tile = wave >> 2, wq = wave & 3;
+  for (int task = wave; task < 12; task += NWV) {
+    const int tile = task >> 2, wq = task & 3;
     if (16 * tile < nrows) {
       int rr = 16 * tile + (lane & 15);
       if (rr >= nrows) rr = nrows - 1;                                   // rows past the body's: recompute its last row, never stored
@@ -50,35 +58,29 @@ __global__ __launch_bounds__(kFusedThreads) void step_fused_kernel(StepFusedArgs
       for (int c = 0; c < 4; ++c) part[tile][wq][4 * (lane >> 4) + c][lane & 15] = acc[c];
     }
   }
-  if (wave == 12) step_stage_tables<true>(b, lane, a.sb, L);   // the update's tables arrive while the responses are computed
+  if (wave == NWV - 1) step_stage_tables<true>(b, lane, a.sb, L);   // the update's tables arrive while the responses are computed (the last wave has at most one task)
   __syncthreads();
-  if (tid < 2 * kJ * 12) {
-    const int rr = tid / 12, cc = tid % 12, tile = rr >> 4, tr = rr & 15;
-    (&L.sh[0][0][0])[tid] = rr < nrows ? (part[tile][0][tr][cc] + part[tile][1][tr][cc]) + (part[tile][2][tr][cc] + part[tile][3][tr][cc]) : 0.f;
+  for (int i = tid; i < 2 * kJ * 12; i += NT) {
+    const int rr = i / 12, cc12 = i % 12, tile = rr >> 4, tr = rr & 15;
+    (&L.sh[0][0][0])[i] = rr < nrows ? (part[tile][0][tr][cc12] + part[tile][1][tr][cc12]) + (part[tile][2][tr][cc12] + part[tile][3][tr][cc12]) : 0.f;
   }
   __syncthreads();
-  // ---- x0 and x_{t-1} of the body (one wave; the step's pose is left to pose_steps_kernel)
-  if (wave == 12) {
-    auto wsync = [] {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
+  // ---- x0 and x_{t-1} of the body (three waves, 48 elements each; the step's pose is left to pose_steps_kernel)
+  if (wave < 3) {
     SmplDev unused;                                                        // (WITH_POSE = false: never read)
-    step_body_one<true, false, true>(b, lane, a.sb, unused, L, wsync);
+    step_body_one<true, false, true>(b, lane, a.sb, unused, L, [] {}, wave, 3);
   }
   if (!a.do_input) return;
-  __syncthreads();
+  __syncthreads();                                                         // L.xn is complete
   // ---- the next step's input conv of the body: units (pass, 256-channel block), one per 256-thread group and round
-  const int ny = a.in.ny, units = (slot >= 0 ? 2 : 1) * ny, grp = tid >> 8;
-  for (int u0 = 0; u0 < units; u0 += 4) {
-    const int u = u0 + grp;
-    if (u < units) {
-      const int p = u / ny;
-      gcn_input_body<OUT>(T + grp * kFusedT, tid & 255, p ? B + slot : b, u - p * ny, a.in, L.xn);   // (one __syncthreads inside)
-    } else {
-      __syncthreads();
-    }
+  //      (one flat loop with one call site: as two nested loops hipcc kept both passes' tables live and spilled 90 registers)
+  //      a group keeps its channel block for both passes (the second pass finds the block's tables in the caches)
+  const int ny = a.in.ny, np = slot >= 0 ? 2 : 1, grp = tid >> 8;
+  const int rounds = np * ((ny + G - 1) / G);                             // block-uniform: every thread meets every barrier
+  for (int k = 0; k < rounds; ++k) {
+    const int cb = grp + G * (k / np), p = k % np;
+    if (cb < ny) gcn_input_body<OUT>(T + grp * kFusedT, tid & 255, p ? B + slot : b, cb, a.in, L.xn);   // (one __syncthreads inside)
+    else __syncthreads();
     __syncthreads();                                                      // the tile is read back after that barrier: keep the next round's writes behind it
   }
 }
@@ -113,11 +115,17 @@ __global__ __launch_bounds__(64) void pose_steps_kernel(PoseStepsArgs p, SmplDev
   step_pose_part(b, lane, a, S, L, [] { __syncthreads(); }, L.x0s);
 }
 
+template <bool HALF_IN, int NT>
+void launch_fused2(int next_prec, int B, hipStream_t st, const StepFusedArgs& a) {
+  const dim3 grid((unsigned)B), blk(NT);
+  if (next_prec == EHM_PREC_F32) hipLaunchKernelGGL((step_fused_kernel<HALF_IN, 0, NT>), grid, blk, 0, st, a);
+  else if (next_prec == EHM_PREC_F16X3) hipLaunchKernelGGL((step_fused_kernel<HALF_IN, 1, NT>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((step_fused_kernel<HALF_IN, 2, NT>), grid, blk, 0, st, a);
+}
 template <bool HALF_IN>
 void launch_fused(int next_prec, int B, hipStream_t st, const StepFusedArgs& a) {
-  if (next_prec == EHM_PREC_F32) hipLaunchKernelGGL((step_fused_kernel<HALF_IN, 0>), dim3(B), dim3(kFusedThreads), 0, st, a);
-  else if (next_prec == EHM_PREC_F16X3) hipLaunchKernelGGL((step_fused_kernel<HALF_IN, 1>), dim3(B), dim3(kFusedThreads), 0, st, a);
-  else hipLaunchKernelGGL((step_fused_kernel<HALF_IN, 2>), dim3(B), dim3(kFusedThreads), 0, st, a);
+  if (B <= ehm_num_cus()) launch_fused2<HALF_IN, 1024>(next_prec, B, st, a);     // one body per CU: the wide block
+  else launch_fused2<HALF_IN, 512>(next_prec, B, st, a);                          // two blocks per CU
 }
 
 }  // namespace

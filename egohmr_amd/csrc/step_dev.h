@@ -178,15 +178,17 @@ __device__ __forceinline__ void step_stage_tables(int b, int lane, const StepBod
 
 // WITH_POSE = false: the pose part is not even compiled in (the caller leaves it to pose_steps_kernel, step.hip).  STAGED: the caller has run
 // step_stage_tables itself (and ordered it).
+// (wi, nw): the body's 144 elements are dealt out to `nw` cooperating waves, this one being number `wi` (the arithmetic per element does not
+// depend on who computes it; a caller with nw > 1 orders the waves' LDS results itself and must not ask for the pose).
 template <bool HS_LDS = false, bool WITH_POSE = true, bool STAGED = false, class Sync>
-__device__ __forceinline__ void step_body_one(int b, int lane, const StepBodyArgs& a, const SmplDev& S, StepBodyLds& L, Sync sync) {
+__device__ __forceinline__ void step_body_one(int b, int lane, const StepBodyArgs& a, const SmplDev& S, StepBodyLds& L, Sync sync, int wi = 0, int nw = 1) {
   float (&sh)[2][kJ][12] = L.sh;
   float (&x0s)[kPoseDim] = L.x0s;
   float (&sAo)[kJ * kJ] = L.sAo;
   float (&sMo)[kJ * 6] = L.sMo;
   if constexpr (!STAGED) step_stage_tables<HS_LDS>(b, lane, a, L);
   sync();
-  for (int e = lane; e < kPoseDim; e += 64) {
+  for (int e = lane + 64 * wi; e < kPoseDim; e += 64 * nw) {
     const int j = e / 6, c = e % 6;
     const int p = (a.passes == 2 && !a.vis[(size_t)b * kJ + j]) ? 1 : 0;          // egohmr.py:249-254
     const float s = sAo[j * kJ + j] * (sMo[j * 6 + c] * sh[p][j][c]);

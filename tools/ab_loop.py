@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Timing-only runs of the sampling loop for same-box A/B of library builds (EHM_LIB_PATH), ablation builds included (no finite checks, no
+calibration: every step split-f16):  python tools/ab_loop.py [ddpm100|c2_ddim10|c3_guided] [calls]
+prints ms per call and the per-launch-class averages of one profiled call (ehm_profile_begin / _end)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from egohmr_amd import _lib, synthetic as syn  # noqa: E402
+from egohmr_amd.diffusion import create_gaussian_diffusion  # noqa: E402
+from egohmr_amd.factory import batch_to_device, build_synthetic_model  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "ddpm100"
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+rs = {"ddpm100": "", "c2_ddim10": "ddim10", "c3_guided": ""}[wl]
+B, S, guided = (128, 10, True) if wl == "c3_guided" else (256, 1, False)
+dev = torch.device("cuda:0")
+model = build_synthetic_model(dev, 0, sensitive=dict(num_diffusion_timesteps=100))
+model.f16x3_last_steps = None
+d = create_gaussian_diffusion(num_diffusion_timesteps=100, timestep_respacing=rs)
+T = d.num_timesteps
+b = batch_to_device(syn.make_batch(B, 4096, seed=100), dev)
+if guided:
+    b["scene_pcd_verts_full"][:, : 4096 // 3, 1] = b["smpl_params"]["transl"][:, None, 1] - 0.6
+noises = [torch.from_numpy(syn.make_noise_stack(T, B, seed=100 + 1000 * k)).to(dev) for k in range(S)]
+fs = model.fused_sampler
+
+
+def call():
+    fs.invalidate()
+    fs.run_samples(d, b, noises, ddim=bool(rs), guided=guided, cond_grad_weight=2.0 if guided else 1.0, defer_status=True)
+
+
+for _ in range(2):
+    call()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(calls):
+    call()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / calls * 1e3
+L = _lib.lib()
+L.ehm_profile_begin()
+call()
+torch.cuda.synchronize()
+n = len(_lib.PROF_CLASSES)
+ms_arr, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+L.ehm_profile_end(ms_arr, cnt, n)
+prof = {c: (round(ms_arr[i] / cnt[i] * 1e3, 1), int(cnt[i])) for i, c in enumerate(_lib.PROF_CLASSES) if cnt[i]}
+print(f"{os.path.basename(os.environ.get('EHM_LIB_PATH', 'base'))} {wl}: {ms:.2f} ms/call = {B * S / ms * 1e3:.0f} bodies/s  {prof}")

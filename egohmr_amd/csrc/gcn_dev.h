@@ -207,7 +207,7 @@ struct GcnInputArgs {
 // One block of the input conv: virtual body `bx`, channels 256 * by .. + 255.  T = 24 * 256 floats of LDS.  `tid` = 0..255 (the calling
 // 256 threads; a 512-thread block runs two of these side by side on two T regions), `xb_in` = the body's 144 x_t values when the caller has
 // staged them itself (the one-launch loop reads them with agent-scope loads: another block of the SAME launch wrote them), else nullptr.
-template <int OUT>   // 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows
+template <int OUT, bool X_LDS = false>   // OUT: 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows; X_LDS: xb_in is an LDS pointer (the caller staged x itself)
 __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by, const GcnInputArgs& a, const float* xb_in) {
   const float* __restrict__ h_img = a.h_img; const float* __restrict__ h_oth = a.h_oth; const uint8_t* __restrict__ vis = a.vis;
   const float* __restrict__ x = a.x; const float* __restrict__ Wx = a.Wx; const float* __restrict__ tvec = a.tvec;
@@ -229,7 +229,19 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
 #pragma unroll
     for (int c = 0; c < 6; ++c) wx[k][c] = Wx[(k * 6 + c) * N + n];
   }
-  const float* xb = xb_in ? xb_in : x + (size_t)b * kPoseDim;   // wave-uniform -> scalar loads (standalone launches)
+  // x_t of the body: wave-uniform.  Standalone launches: scalar loads from the global row.  X_LDS: 36 sixteen-byte LDS reads through an explicit
+  // LDS pointer (as `xb_in ? xb_in : global row` the pointer was generic and the reads FLAT loads: aperture check per access, both wait counters)
+  const float* xb = xb_in ? xb_in : x + (size_t)b * kPoseDim;
+  float xr[X_LDS ? kPoseDim : 1];
+  if constexpr (X_LDS) {
+    typedef const f32x4 __attribute__((address_space(3))) lf32x4;
+    lf32x4* xl = (lf32x4*)xb_in;
+#pragma unroll
+    for (int i = 0; i < kPoseDim / 4; ++i) {
+      const f32x4 v = xl[i];
+      xr[4 * i] = v[0]; xr[4 * i + 1] = v[1]; xr[4 * i + 2] = v[2]; xr[4 * i + 3] = v[3];
+    }
+  }
   const uint8_t* vb_ = vis + (size_t)b * kJ;
   float h0[kJ], h1[kJ];
   const float sh = L.shift[n];
@@ -265,7 +277,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
     f32x2 s = __builtin_elementwise_fma(f32x2{v, v}, img2, base2);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const float xv = xb[j * 6 + c];
+      const float xv = X_LDS ? xr[X_LDS ? j * 6 + c : 0] : xb[j * 6 + c];
       s = __builtin_elementwise_fma(f32x2{xv, xv}, wx2[c], s);
     }
     h0[j] = fmaf(dj[j], s[0], sh);

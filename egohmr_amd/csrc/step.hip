@@ -39,7 +39,7 @@ template <bool HALF_IN, int OUT, int NT>
 __global__ __launch_bounds__(NT, 4) void step_fused_kernel(StepFusedArgs a) {
   constexpr int G = NT / 256, NWV = NT / 64;                        // 256-thread groups, waves
   __shared__ __attribute__((aligned(16))) float T[G * kFusedT];     // G transpose tiles (24 KiB each); the response partials alias the first 12 KiB
-  __shared__ StepBodyLds L;
+  __shared__ __attribute__((aligned(16))) StepBodyLds L;          // (L.xn is read back as 16-byte vectors)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, B = a.sb.B;
   const int slot = a.sb.passes == 2 ? (a.sb.mask_slot ? a.sb.mask_slot[b] : b) : -1;   // second pass of this body: rows of virtual body B + slot (< 0: none)
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NT, 4) void step_fused_kernel(StepFusedArgs a) {
   const int rounds = np * ((ny + G - 1) / G);                             // block-uniform: every thread meets every barrier
   for (int k = 0; k < rounds; ++k) {
     const int cb = grp + G * (k / np), p = k % np;
-    if (cb < ny) gcn_input_body<OUT>(T + grp * kFusedT, tid & 255, p ? B + slot : b, cb, a.in, L.xn);   // (one __syncthreads inside)
+    if (cb < ny) gcn_input_body<OUT, true>(T + grp * kFusedT, tid & 255, p ? B + slot : b, cb, a.in, L.xn);   // (one __syncthreads inside)
     else __syncthreads();
     __syncthreads();                                                      // the tile is read back after that barrier: keep the next round's writes behind it
   }

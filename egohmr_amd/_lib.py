@@ -45,11 +45,12 @@ def build(verbose: bool = False, force: bool = False) -> str:
     objdir = os.path.join(_HERE, "build", os.path.basename(LIB_PATH) + "." + tag)
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for s in SOURCES:
+    sources = SOURCES + (["gcn_wide.hip"] if "-DEHM_WITH_WIDE_TILE" in extra else [])     # experiment: the 96 x 64 (x 2) wave tile
+    for s in sources:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
             jobs.append((src, obj))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in sources]
     if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
 
@@ -73,7 +74,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
 
 
 def build_features() -> set:
-    """Optional parts the loaded library was built with (ehm_build_features): 'loop_engine', 'stamps'."""
+    """Optional parts the loaded library was built with (ehm_build_features): 'loop_engine', 'stamps', 'wide_tile'."""
     return set(lib().ehm_build_features().decode().split())
 
 

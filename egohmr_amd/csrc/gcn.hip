@@ -409,6 +409,9 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   for (int i = 0; i < num_hidden; ++i) EHM_CHECK_ARG(hidden[i].in_dim == hid_dim && hidden[i].out_dim == hid_dim && hidden[i].W);
   hipStream_t st = (hipStream_t)stream;
   auto* g = new ehm_gcn();
+#ifdef EHM_WITH_WIDE_TILE
+  if (const char* e = getenv("EHM_GCN_WIDE")) g->wide = atoi(e);   // (experiment build: gcn_wide.hip for the per-conv launches)
+#endif
   if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);   // 0: one launch per hidden conv (debugging aid; bit-identical results)
   g->hid = hid_dim;
   g->num_hidden = num_hidden;

@@ -59,6 +59,7 @@ struct ehm_gcn {
   int chain_sync_clean = 0;              // 1: the last chained launch zeroed tickets / done / finished itself (its last block does)
   int64_t chain_sync_shape = 0;          // nl * m_tiles the words were last used with (err sits right behind done[])
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
+  int wide = 0;                          // -DEHM_WITH_WIDE_TILE builds only (experiment): EHM_GCN_WIDE=1 at create -> per-conv launches of the split-f16 mode run gcn_wide.hip
   int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (f16 modes), 0 = one launch per conv (EHM_F16_CHAIN=0)
   OutDev out{};
   float* arena = nullptr;

@@ -964,6 +964,9 @@ void ehm_pack_half(const float* X, void* Y, size_t n, float scale, hipStream_t s
 int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
                             hipStream_t st) {
   if (!shape_ok(h, rows_pad)) return EHM_EINVAL;
+#ifdef EHM_WITH_WIDE_TILE
+  if (h->wide && h->precision == EHM_PREC_F16X3 && h->hid % 128 == 0) return ehm_gcn_wide_layer_impl(h, layer, X, residual, out, rows_pad, out_f32, st);
+#endif
   OneArgs a;
   a.L = h->hidden[layer];
   a.X = X;

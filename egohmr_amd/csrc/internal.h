@@ -51,6 +51,10 @@ int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 // gcn_tile.hip (f16 matrix-core hidden convs: 'f16x3' split operands and plain 'f16')
 int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
                             hipStream_t st);
+#ifdef EHM_WITH_WIDE_TILE
+int ehm_gcn_wide_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
+                            hipStream_t st);   // gcn_wide.hip (experiment)
+#endif
 int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
 #ifdef EHM_WITH_LOOP_ENGINE
 // the one-launch sampling loop (gcn_loop_host.inc, experiment): launch description filled by sampler.hip

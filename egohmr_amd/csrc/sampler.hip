@@ -34,6 +34,9 @@ extern "C" const char* ehm_build_features(void) {
 #ifdef EHM_STAMPS
          "stamps "
 #endif
+#ifdef EHM_WITH_WIDE_TILE
+         "wide_tile "
+#endif
       ;
 }
 

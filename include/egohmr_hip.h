@@ -35,7 +35,8 @@ const char* ehm_last_error(void);
 /* compile-time facts, for the loader's sanity check: returns "gfx950" */
 const char* ehm_target_arch(void);
 /* optional parts this library was built with, space separated ("" for the default build): "loop_engine" (-DEHM_WITH_LOOP_ENGINE: the
- * one-launch sampling loop experiment, ehm_sample_desc.loop_engine), "stamps" (-DEHM_STAMPS: in-kernel time stamps for tools/stamp_*.py) */
+ * one-launch sampling loop experiment, ehm_sample_desc.loop_engine), "stamps" (-DEHM_STAMPS: in-kernel time stamps for tools/stamp_*.py),
+ * "wide_tile" (-DEHM_WITH_WIDE_TILE: the 96 x 64 wave-tile experiment of csrc/gcn_wide.hip, selected per handle with EHM_GCN_WIDE=1 at ehm_gcn_create) */
 const char* ehm_build_features(void);
 
 /* ------------------------------------------------------------------ geometry ------------------ */

@@ -149,16 +149,16 @@ def test_default_library_has_no_experiment_and_no_env_switch_on_the_launch_path(
     assert _lib.build_features() == set()
     with open(_lib.LIB_PATH, "rb") as f:
         blob = f.read()
-    assert b"gcn_loop_kernel" not in blob and b"gcn_hidden_chain_kernel" in blob
+    assert b"gcn_loop_kernel" not in blob and b"gcn_hidden_wide_kernel" not in blob and b"gcn_hidden_chain_kernel" in blob
     sites = []
     for path in sorted(glob.glob(os.path.join(REPO, "egohmr_amd", "csrc", "*"))):
-        if os.path.basename(path) == "gcn_loop_host.inc":           # compiled only under -DEHM_WITH_LOOP_ENGINE
+        if os.path.basename(path) in ("gcn_loop_host.inc", "gcn_wide.hip"):           # compiled only under -DEHM_WITH_LOOP_ENGINE / -DEHM_WITH_WIDE_TILE
             continue
         depth = []                                                  # stack of "is this #if block an instrumentation flag"
         for ln, line in enumerate(open(path), 1):
             st = line.strip()
             if st.startswith("#if"):
-                depth.append(("EHM_STAMPS" in st or "EHM_WITH_LOOP_ENGINE" in st or "EHM_LOOPSTAT" in st) and not st.startswith("#ifndef"))
+                depth.append(("EHM_STAMPS" in st or "EHM_WITH_LOOP_ENGINE" in st or "EHM_LOOPSTAT" in st or "EHM_WITH_WIDE_TILE" in st) and not st.startswith("#ifndef"))
             elif st.startswith("#endif") and depth:
                 depth.pop()
             elif "getenv(" in line and not any(depth):

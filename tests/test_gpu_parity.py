@@ -218,6 +218,22 @@ def test_gcn_hidden_layer_vs_oracle(L, dev, hid, bodies, prec):
 def test_hidden_stack_chain_tile_shapes(L, dev, hid, bodies, prec):
     """The chained launch picks its tile by width: hid % 128 == 0 in f16 mode runs the 8-wave 192 x 128 tile, everything else the
     4-wave 192 x 64 tile (ehm_gcn_tile_chain_impl).  Both must reproduce the per-conv launches (always 192 x 64) bit for bit."""
+    _chain_vs_per_conv_launches(L, dev, hid, bodies, prec)
+
+
+@pytest.mark.parametrize("hid,bodies", [(256, 33), (1024, 40)])
+def test_wide_wave_tile_experiment_is_bit_equal(L, dev, hid, bodies, monkeypatch):
+    """csrc/gcn_wide.hip (96 x 64 (x 2) wave tile, 16-k K tiles: 14 fragment reads and 7 operand pieces per 36 MFMAs instead of 20 and 10) is an
+    EXPERIMENT - measured equal to the shipped tile, DESIGN.md 3.2 - that only a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_WIDE_TILE contains;
+    there, a handle created under EHM_GCN_WIDE=1 runs it for the per-conv launches, which must reproduce the chained launch bit for bit."""
+    from egohmr_amd import _lib
+    if "wide_tile" not in _lib.build_features():
+        pytest.skip("library built without -DEHM_WITH_WIDE_TILE (default)")
+    monkeypatch.setenv("EHM_GCN_WIDE", "1")                 # read once, at ehm_gcn_create
+    _chain_vs_per_conv_launches(L, dev, hid, bodies, "f16x3")
+
+
+def _chain_vs_per_conv_launches(L, dev, hid, bodies, prec):
     import ctypes as C
     from egohmr_amd import _lib
     from egohmr_amd.model import PRECISIONS

@@ -19,7 +19,16 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rs = {"ddpm100": "", "c2_ddim10": "ddim10", "c3_guided": ""}[wl]
 B, S, guided = (128, 10, True) if wl == "c3_guided" else (256, 1, False)
 dev = torch.device("cuda:0")
-model = build_synthetic_model(dev, 0, sensitive=dict(num_diffusion_timesteps=100))
+asset = None
+if os.environ.get("EHM_SORT_VERTS"):        # experiment: the synthetic body with its vertices in bone order (real SMPL's vertex numbering is spatially coherent;
+    import numpy as np                      # the synthetic asset hangs vertex i on a RANDOM bone, so a wave's 32 vertices gather 32 unrelated transforms)
+    asset = syn.make_smpl_asset(0)
+    perm = np.argsort(asset["lbs_weights"].argmax(1), kind="stable")
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    asset = dict(asset, v_template=asset["v_template"][perm], shapedirs=asset["shapedirs"][perm],
+                 posedirs=asset["posedirs"].reshape(207, -1, 3)[:, perm].reshape(207, -1).copy(), J_regressor=asset["J_regressor"][:, perm].copy(),
+                 lbs_weights=asset["lbs_weights"][perm], faces=inv[asset["faces"]], extra_joints_idxs=inv[asset["extra_joints_idxs"]])
+model = build_synthetic_model(dev, 0, sensitive=dict(num_diffusion_timesteps=100), smpl_asset=asset)
 model.f16x3_last_steps = None
 d = create_gaussian_diffusion(num_diffusion_timesteps=100, timestep_respacing=rs)
 T = d.num_timesteps

@@ -178,15 +178,12 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
   const int cnt = count[b];
   if (cnt <= 1024 * slice) return;                       // block-uniform: nothing for this slice (cnt == 0 included)
   const int Vp = (V + 3) & ~3;
-  float* sx = sv;
-  float* sy = sv + Vp;
-  float* sz = sv + 2 * Vp;
-  int* cstart = (int*)(sv + 3 * Vp);                     // [kMaxCells + 1] exclusive offsets
+  f32x4* sp = (f32x4*)sv;                                // [Vp] slot i = (x, y, z, vertex id as bits) of the i-th vertex in CELL order
+  int* cstart = (int*)(sv + 4 * Vp);                     // [kMaxCells + 1] exclusive offsets
   int* cursor = cstart + kMaxCells + 1;                  // [kMaxCells]
-  unsigned short* order = (unsigned short*)(cursor + kMaxCells);   // [Vp] vertex id of sorted slot i
-  // sx / sy / sz hold the vertices SORTED BY CELL (slot i = vertex order[i]): the search streams a cell's slots with independent loads;
-  // with the positions in vertex order every candidate cost two dependent LDS round trips (order[i] -> sx[order[i]]) and the per-point
-  // search was 93 % of the kernel (in-kernel stamps)
+  // The vertices sit SORTED BY CELL, one 16-byte slot each: a candidate costs ONE ds_read_b128.  (Round 2: positions in vertex order = two
+  // dependent LDS round trips per candidate; rounds 3-4: three SoA arrays + an id array = three to four 4-byte reads per candidate at addresses
+  // that differ from lane to lane - the search, 93 % of the kernel by in-kernel stamps, was bound by LDS bank conflicts.)
   __shared__ int part[1024];
   __shared__ float wred[16];
   __shared__ int hred[16];
@@ -253,8 +250,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
   for (int i = 0; i < kVPT; ++i)                         // scatter (order inside a cell is arbitrary; the search below does not care)
     if (vc[i] >= 0) {
       const int slot = atomicAdd(&cursor[vc[i]], 1);
-      order[slot] = (unsigned short)(tid + 1024 * i);
-      sx[slot] = vx[i]; sy[slot] = vy[i]; sz[slot] = vz[i];
+      sp[slot] = f32x4{vx[i], vy[i], vz[i], __builtin_bit_cast(float, tid + 1024 * i)};
     }
   __syncthreads();
 
@@ -271,12 +267,23 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
       for (int dy = max(cy - 1, 0); dy <= min(cy + 1, ny - 1); ++dy) {
         // the (up to three) cells of one x-run are adjacent in the sorted order: one contiguous slot range
         const int c0 = max(cx - 1, 0) + nx * (dy + ny * dz), c1 = min(cx + 1, nx - 1) + nx * (dy + ny * dz);
-        for (int i = cstart[c0]; i < cstart[c1 + 1]; ++i) {
-          const float ex = px - sx[i], ey = py - sy[i], ez = pz - sz[i];
-          const float d2 = ex * ex + ey * ey + ez * ez;
-          if (d2 <= best) {                               // (rare path) first minimum by vertex index, like torch.min
-            const int v = order[i];
-            if (d2 < best || v < bi) { best = d2; bi = v; bslot = i; }
+        // four candidates per trip, their slots requested together: one candidate per trip is a chain of LDS round trips (read -> compare ->
+        // next read, ~120 cycles each; a point near a limb has several hundred candidates).  The last trip re-reads the range's last slot:
+        // a repeated candidate changes nothing (same distance, same vertex)
+        const int e = cstart[c1 + 1];
+        for (int i = cstart[c0]; i < e; i += 4) {
+          f32x4 q[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) q[u] = sp[min(i + u, e - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float ex = px - q[u][0], ey = py - q[u][1], ez = pz - q[u][2];
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 <= best) {                             // (rare path) first minimum by vertex index, like torch.min
+              const float qw = q[u][3];                   // (hipcc: __builtin_bit_cast of a vector ELEMENT expression reads element 0 - go through a scalar)
+              const int v = __builtin_bit_cast(int, qw);
+              if (d2 < best || v < bi) { best = d2; bi = v; bslot = min(i + u, e - 1); }
+            }
           }
         }
       }
@@ -289,9 +296,10 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
         if (gverts) {
           const float s = 2.f * hh / d;                   // d(h^2)/dv = 2h (p - v)/d
           float* g = gverts + ((size_t)b * V + bi) * 3;
-          atomicAdd(g + 0, s * (px - sx[bslot]));
-          atomicAdd(g + 1, s * (py - sy[bslot]));
-          atomicAdd(g + 2, s * (pz - sz[bslot]));
+          const f32x4 q = sp[bslot];
+          atomicAdd(g + 0, s * (px - q[0]));
+          atomicAdd(g + 1, s * (py - q[1]));
+          atomicAdd(g + 2, s * (pz - q[2]));
         }
       }
     }
@@ -314,9 +322,13 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------ LBS backward
 // thread = vertex, 8 bodies per block (same tiling as the forward skin_kernel).  In: d loss/d verts (gv, overwritten
 // in place by d loss/d posed-rest-vertex).  Out: gA[b][24][12] += sum_v w[v,j] [gv (x) vp | gv]  (LDS, then global atomics)
+// `vposed` (may be nullptr): the blended rest vertices [B,V,3] as the forward's matrix-core skinning left them - then they are READ (24 bytes per
+// vertex and body with a gradient) instead of recomputed from the 217-row blend basis per 8 bodies (2.6 KB of basis per vertex: 2.9 GB of L2
+// reads per guided step at 1280 bodies, the kernel's 0.75 ms).
 __global__ __launch_bounds__(kVT, 4) void skin_bwd_kernel(const float* __restrict__ betas, const float* __restrict__ Rws,
                                                           const float* __restrict__ A, SmplDev S, float* __restrict__ gv_io,
-                                                          float* __restrict__ gA, int B, int v_tiles, int b_groups) {
+                                                          float* __restrict__ gA, int B, int v_tiles, int b_groups,
+                                                          const float* __restrict__ vposed) {
   __shared__ __attribute__((aligned(16))) float sA[kBG][kJ][12];
   __shared__ float sG[kBG][kJ][12];
   __shared__ float sPF[kBG][kPoseBasis + 1];
@@ -351,18 +363,27 @@ __global__ __launch_bounds__(kVT, 4) void skin_bwd_kernel(const float* __restric
     (&sA[0][0][0])[i] = (i / (kJ * 12)) < nb ? A[(size_t)b0 * kJ * 12 + i] : 0.f;
     (&sG[0][0][0])[i] = 0.f;
   }
-  for (int i = tid; i < kBG * kPoseBasis; i += kVT) {
-    const int bb = i / kPoseBasis, p = i % kPoseBasis, e = p % 9;
-    sPF[bb][p] = bb < nb ? Rws[((size_t)(b0 + bb) * kJ + 1) * 9 + p] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f) : 0.f;
+  if (!vposed) {
+    for (int i = tid; i < kBG * kPoseBasis; i += kVT) {
+      const int bb = i / kPoseBasis, p = i % kPoseBasis, e = p % 9;
+      sPF[bb][p] = bb < nb ? Rws[((size_t)(b0 + bb) * kJ + 1) * 9 + p] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f) : 0.f;
+    }
+    if (tid < kBG * 10) sBeta[tid / 10][tid % 10] = (tid / 10) < nb ? betas[(size_t)b0 * 10 + tid] : 0.f;
   }
-  if (tid < kBG * 10) sBeta[tid / 10][tid % 10] = (tid / 10) < nb ? betas[(size_t)b0 * 10 + tid] : 0.f;
   __syncthreads();
 
   if (mine) {
     const int V3 = S.V * 3;
-    // recompute the posed rest vertex (forward skin_kernel) only for bodies with gradient
+    // the blended rest vertex of the bodies with gradient: read (the forward left it), or recomputed (forward skin_kernel)
     float vp[kBG][3];
-    {
+    if (vposed) {
+#pragma unroll
+      for (int bb = 0; bb < kBG; ++bb) {
+        const bool live = bb < nb && (gv[bb][0] != 0.f || gv[bb][1] != 0.f || gv[bb][2] != 0.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vp[bb][c] = live ? vposed[((size_t)(b0 + bb) * S.V + v) * 3 + c] : 0.f;
+      }
+    } else {
       const float t0 = S.v_template[v * 3 + 0], t1 = S.v_template[v * 3 + 1], t2 = S.v_template[v * 3 + 2];
 #pragma unroll
       for (int bb = 0; bb < kBG; ++bb) { vp[bb][0] = 0.f; vp[bb][1] = 0.f; vp[bb][2] = 0.f; }
@@ -746,7 +767,7 @@ int collision_impl(const float* verts, const float* scene, float* loss, float* g
     ehm_set_error("collision proxy: %d vertices do not fit the 160 KiB LDS", V);
     return EHM_EINVAL;
   }
-  const size_t lds_grid = lds + (size_t)(2 * kMaxCells + 1) * sizeof(int) + (size_t)Vp * sizeof(unsigned short) + 16;
+  const size_t lds_grid = (size_t)4 * Vp * sizeof(float) + (size_t)(2 * kMaxCells + 1) * sizeof(int) + 16;   // 16-byte slots (x, y, z, id) + the cell offsets
   if (V <= 8192 && lds_grid <= 160 * 1024 - 4608) {          // (the grid kernel keeps 8 vertices per thread in registers)
     EHM_HIP(hipFuncSetAttribute((const void*)nearest_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4608));
     int slices = ehm_num_cus() / (B > 0 ? B : 1);         // one block per CU (the vertex arrays take half of its LDS)
@@ -763,14 +784,14 @@ int collision_impl(const float* verts, const float* scene, float* loss, float* g
 }
 
 int backward_impl(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_, const float* Rws,
-                  const float* Aws, float* gverts, float* gpose, int B, const Scratch& s, hipStream_t st) {
+                  const float* Aws, float* gverts, float* gpose, int B, const Scratch& s, hipStream_t st, const float* vposed = nullptr) {
   const SmplDev& d = h->d;
   EHM_HIP(hipMemsetAsync(s.gA, 0, (size_t)B * kJ * 12 * sizeof(float), st));
   const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBG);
   {
     EhmProfScope ps(EHM_PROF_G_SKIN_BWD, st);
     hipLaunchKernelGGL(skin_bwd_kernel, dim3((unsigned)(round_up(v_tiles, 8) * b_groups)), dim3(kVT), 0, st, betas, Rws, Aws, d, gverts,
-                       s.gA, B, v_tiles, b_groups);
+                       s.gA, B, v_tiles, b_groups, vposed);
   }
   {
     EhmProfScope ps(EHM_PROF_G_POSEFEAT_BWD, st);
@@ -791,15 +812,16 @@ int64_t ehm_guidance_scratch_bytes(int B, int N) {
 
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
                       const float* scene, int B, int N, float tau, float denom, float margin, float* verts_ws, float* joints_ws, float* R_ws,
-                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st) {
+                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st, float* vposed_ws) {
   const int V = smpl->d.V;
   const Scratch s = carve_scratch(scratch, B, N);
-  int rc = ehm_smpl_forward_impl(smpl, betas, x, true, mean, std_, verts_ws, joints_ws, R_ws, A_ws, nullptr, B, st);   // egohmr.py:528-537
+  if (vposed_ws && !ehm_smpl_writes_vposed(smpl, B)) vposed_ws = nullptr;       // (small batches / dense skinning weights: the VALU forward does not leave them)
+  int rc = ehm_smpl_forward_impl(smpl, betas, x, true, mean, std_, verts_ws, joints_ws, R_ws, A_ws, nullptr, B, st, vposed_ws);   // egohmr.py:528-537
   if (rc == 0) {
     EhmProfScope ps(EHM_PROF_G_NEAREST, st);      // memsets + bbox + select + nearest_grid_kernel (the search dominates)
     rc = collision_impl(verts_ws, scene, loss, gverts, nullptr, B, V, N, tau, margin, s, st);
   }
-  if (rc == 0) rc = backward_impl(smpl, betas, x, mean, std_, R_ws, A_ws, gverts, gpose, B, s, st);
+  if (rc == 0) rc = backward_impl(smpl, betas, x, mean, std_, R_ws, A_ws, gverts, gpose, B, s, st, vposed_ws);
   if (rc == 0) {
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)ceil_div((int64_t)B * kPoseDim, 256)), dim3(256), 0, st, gpose, grad, B, denom);
     EHM_LAUNCH_CHECK();

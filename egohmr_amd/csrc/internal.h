@@ -6,7 +6,8 @@
 // smpl.hip
 int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x, bool from_rot6d, const float* mean,
                           const float* std_, float* verts, float* joints, float* Rws, float* Aws, float* pose6d_out, int B,
-                          hipStream_t st);
+                          hipStream_t st, float* vposed = nullptr);   // vposed [B,V,3]: the blended rest vertices, written by the matrix-core skinning only:
+int ehm_smpl_writes_vposed(const ehm_smpl* h, int B);             //   1 when a forward of B bodies takes that path
 // rot6d -> R, joint regression, kinematic chain only (no skinning): R [B,24,9], A [B,24,12], joints24 into jws [B,(24+n_extra),3]
 int ehm_smpl_pose_impl(ehm_smpl* h, const float* betas, const float* x, const float* mean, const float* std_, float* Rws, float* Aws,
                        float* jws, int B, hipStream_t st);
@@ -80,7 +81,8 @@ int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad);   // sync words + output
 int64_t ehm_guidance_scratch_bytes(int B, int N);
 int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const float* mean, const float* std_,
                       const float* scene, int B, int N, float tau, float denom, float margin, float* verts_ws, float* joints_ws, float* R_ws,
-                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st);
+                      float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st,
+                      float* vposed_ws = nullptr);   // [B,V,3] scratch or nullptr: the forward's blended rest vertices for the skinning VJP (else recomputed there)
 // sampler.hip: launch-class timing for bench.py (ehm_profile_begin / ehm_profile_end); a no-op unless a profile is open
 struct EhmProfScope {
   int cls;

@@ -156,6 +156,7 @@ struct Workspace {
   float* g_R;          //                                            [B,24,9]
   float* g_A;          //                                            [B,24,12]
   float* g_gverts;     // d loss / d verts                           [B,V,3]
+  float* g_vposed;     // blended rest vertices of the guided bodies  [B,V,3]  (left by the forward for the skinning VJP)
   float* g_loss;       // [B]
   float* g_gpose;      // [B,144]
   float* g_grad;       // [B,144]
@@ -194,6 +195,7 @@ Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* ba
     w.g_R = take((int64_t)d->B * kJ * 9);
     w.g_A = take((int64_t)d->B * kJ * 12);
     w.g_gverts = take((int64_t)d->B * V * 3);
+    w.g_vposed = take((int64_t)d->B * V * 3);
     w.g_loss = take(d->B);
     w.g_gpose = take((int64_t)d->B * kPoseDim);
     w.g_grad = take((int64_t)d->B * kPoseDim);
@@ -370,7 +372,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     if (c.grad_scale != 0.f) {
       EhmProfScope ps(EHM_PROF_GUIDANCE, st);
       rc = ehm_guidance_impl(smpl, betas, w.x_cur, mean, std_, scene, B, d->num_scene_points, d->tau, d->guide_denom, d->guide_all_points ? d->tau : 0.f,
-                             w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, w.g_scratch, st);
+                             w.g_verts_in, w.g_joints, w.g_R, w.g_A, w.g_gverts, w.g_loss, w.g_gpose, w.g_grad, w.g_scratch, st, w.g_vposed);
       grad = w.g_grad;
     }
     // ---- denoiser: EgoHMR.forward's per-step part (egohmr.py:232-257): input conv, chained hidden convs, output conv responses ----

@@ -272,6 +272,8 @@ struct SkinArgs {
   // writes verts / joints, the others scratch_verts / scratch_joints (same arithmetic, results of the intermediate steps are not consumed)
   int nsteps = 1, final_step = 0;
   float* scratch_verts = nullptr; float* scratch_joints = nullptr;
+  float* vposed = nullptr;     // [B, V, 3] or nullptr: the blended REST vertex (shape + pose-corrective blend, before skinning) - what the skinning VJP
+                               // of the collision guidance needs per vertex and body (guidance.hip: skin_bwd_kernel), which otherwise recomputes it
 };
 
 // One block (256 threads) of the matrix-core skinning; sA = 32 * 24 * 12 floats (36 KiB) of LDS: the skinning transforms of the block's
@@ -378,6 +380,7 @@ __device__ __forceinline__ void skin_mfma_body(float (*sA)[kJ][12], int bid, con
                   oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
       typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
       *(f32x3u*)o = f32x3u{ox, oy, oz};                          // one 12-byte store per lane: a half-wave covers 384 contiguous bytes
+      if (a.vposed) *(f32x3u*)(a.vposed + ((size_t)(b0 + bb) * S.V + v) * 3) = f32x3u{px, py, pz};
       for (unsigned long long m = slots; m; m &= m - 1) {
         float* q = joints + ((size_t)(b0 + bb) * (kJ + S.n_extra) + kJ + __builtin_ctzll(m)) * 3;
         q[0] = ox; q[1] = oy; q[2] = oz;
@@ -559,7 +562,7 @@ extern "C" void ehm_smpl_destroy(ehm_smpl* h) {
 // internal entry shared with sampler.hip: caller provides R/A scratch (no allocation -> graph safe)
 int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x, bool from_rot6d, const float* mean,
                           const float* std_, float* verts, float* joints, float* Rws, float* Aws, float* pose6d_out, int B,
-                          hipStream_t st) {
+                          hipStream_t st, float* vposed) {
   const SmplDev& d = h->d;
   const int jstride = (kJ + d.n_extra) * 3;
   if (from_rot6d)
@@ -583,6 +586,7 @@ int ehm_smpl_forward_impl(ehm_smpl* h, const float* betas, const float* rot_or_x
     const int v_tiles = (int)ceil_div(d.V, 32), vt_groups = (int)ceil_div(v_tiles, 4);
     const int blocks = (int)round_up(vt_groups, 8) * b_tiles;
     SkinArgs sa{(const sk_half8*)h->pf, Aws, d, verts, d.n_extra ? joints : nullptr, B, v_tiles, vt_groups};
+    sa.vposed = vposed;               // (only this path writes it: ehm_smpl_writes_vposed)
     hipLaunchKernelGGL(skin_mfma_kernel, dim3(blocks), dim3(256), 0, st, sa);
   } else {
     const int v_tiles = (int)ceil_div(d.V, kVT), b_groups = (int)ceil_div(B, kBGF);
@@ -693,6 +697,7 @@ int ehm_skin_steps_impl(ehm_smpl* h, const float* A_steps, const void* pf_steps,
 }
 int ehm_skin_min_bodies() { return kSkinMfmaMinBodies; }
 int ehm_smpl_has_mfma_skin(const ehm_smpl* h) { return h->d.PDf != nullptr ? 1 : 0; }
+int ehm_smpl_writes_vposed(const ehm_smpl* h, int B) { return h->d.PDf != nullptr && B >= kSkinMfmaMinBodies ? 1 : 0; }
 int64_t ehm_skin_pf_bytes_per_step(int B) { return (int64_t)ceil_div(B, 32) * kBlendSteps * 2 * 64 * 16; }
 void ehm_smpl_dev(const ehm_smpl* h, void* out) { memcpy(out, &h->d, sizeof(SmplDev)); }
 size_t ehm_smpl_dev_size() { return sizeof(SmplDev); }

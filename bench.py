@@ -456,6 +456,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     _lib.check(L.ehm_profile_end(ms_arr, cnt_arr, ncls), "ehm_profile_end")
     prof = {c: {"ms_per_call": ms_arr[i], "launches_per_call": int(cnt_arr[i]), "avg_launch_us": (ms_arr[i] / cnt_arr[i] * 1e3) if cnt_arr[i] else None}
             for i, c in enumerate(_lib.PROF_CLASSES)}
+    nearest_evals = prof.pop("guid_nearest_evals")["launches_per_call"]      # a COUNT (EHM_PROF_G_NEAREST_EVALS): point-to-vertex distance evaluations of the profiled call
 
     # split of one call (rank 0, informative)
     torch.cuda.synchronize()
@@ -548,12 +549,20 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
                     div = 1e9 if unit == "GB/s" else 1e12
                     guid[cls] = {"bound": bound, "kernel": kernel, "achieved": work / t / div, "peak": peak, "unit": unit, "frac": work / t / div / peak,
                                  "avg_launch_us": t * 1e6, "launches_per_call": pr["launches_per_call"], "algorithmic_work_per_launch": work, "work_is": what}
-            g_entry("guid_nearest", "bbox / select / nearest_grid_kernel (proxy loss: nearest body vertex of every selected scene point, loss and d loss / d verts)",
-                    "hbm", nb * (6890 * 12 * 2 + N * 12 + N * 4), PEAK_HBM_GBS, "GB/s",
-                    "per body: vertices read + gradient written (2 x 82,680 B) + scene points and their selection list (N x 16 B); the search itself is vector-ALU work over an LDS-resident cell grid")
+            # the search: counted IN the kernel (one evaluation = 3 subtractions + 3 multiply-adds + the comparison: 8 flop) against the float32
+            # vector-ALU peak - the bytes it moves (vertices in, gradient out, 0.2 GB per step at 1280 bodies) are not what bounds it
+            n_g = prof["guid_nearest"]["launches_per_call"]
+            g_entry("guid_nearest", "bbox / select / nearest_grid_kernel (proxy loss: nearest body vertex of every selected scene point over a 27-cell neighbourhood "
+                    "of an LDS-resident cell grid, loss and d loss / d verts)",
+                    "valu_f32", 8.0 * nearest_evals / max(n_g, 1), PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
+                    f"8 flop x {nearest_evals / max(n_g, 1) / max(nb, 1):.0f} distance evaluations per body and guided step (counted in the kernel); peak = the f32 vector rate "
+                    "(157.3 TFLOP/s).  A lane walks its point's candidates alone: the fraction mostly says how uneven the candidate counts of a wave's 64 points are")
+            if "guid_nearest" in guid:
+                guid["guid_nearest"]["distance_evaluations_per_launch"] = nearest_evals / max(n_g, 1)
             g_entry("guid_skin_bwd", "skin_bwd_kernel (VJP of the skinning: d loss / d transforms, d loss / d blended rest pose)",
-                    "hbm", nb * (6890 * 12 * 2 + 24 * 12 * 4) + 19.3e6, PEAK_HBM_GBS, "GB/s",
-                    "per body: vertex gradient read + rest-pose gradient written (2 x 82,680 B) + transform gradient; SMPL constants 19.3 MB once per launch")
+                    "hbm", nb * (6890 * 12 * 3 + 24 * 12 * 4), PEAK_HBM_GBS, "GB/s",
+                    "per body: vertex gradient read + rest-pose gradient written + the forward's blended rest vertices read (3 x 82,680 B) + transform gradient "
+                    "(upper bound: blocks whose vertices carry no gradient stop after the first read)")
             g_entry("guid_posefeat_bwd", "posefeat_bwd_mfma_kernel + posefeat_sum_kernel ([bodies, 20670] x [20670, 207] contraction with the pose-corrective basis)",
                     "mfma", nb * 2.0 * 20670 * 207, PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                     "2 x bodies x 20670 x 207 flop, exact-f32 MFMA (v_mfma_f32_32x32x2_f32; 224 of 207 columns issued)")

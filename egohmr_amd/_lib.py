@@ -207,7 +207,7 @@ PROTOTYPES = {
     "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }
 PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "loop_f16x3", "loop_f16",
-                "guid_nearest", "guid_skin_bwd", "guid_posefeat_bwd", "step_fused")   # EHM_PROF_* of the header
+                "guid_nearest", "guid_skin_bwd", "guid_posefeat_bwd", "step_fused", "guid_nearest_evals")   # EHM_PROF_* of the header (the last one is a COUNT in `launches`)
 
 _lib = None
 

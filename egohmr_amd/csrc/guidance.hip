@@ -168,7 +168,8 @@ constexpr int kMaxCells = 4096;
 __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restrict__ verts, const float* __restrict__ scene,
                                                             const int* __restrict__ idx, const int* __restrict__ count,
                                                             const float* __restrict__ bbox, float* __restrict__ loss,
-                                                            float* __restrict__ gverts, int* __restrict__ hits, int V, int N, float tau) {
+                                                            float* __restrict__ gverts, int* __restrict__ hits, int V, int N, float tau,
+                                                            unsigned long long* __restrict__ evals) {
   // grid = (bodies, slices): the selected points of a body are dealt out in runs of 1024 to gridDim.y blocks, each of which builds the
   // body's (cheap) cell grid for itself - the per-point search is 93 % of the kernel (in-kernel stamps) and one block per body left
   // half of the chip idle at B = 128
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
 
   float contrib = 0.f;
   int nhit = 0;
+  unsigned int nev = 0;                                  // distance evaluations of this thread (bench.py's roofline of the search; counted per range)
   for (int k = tid + 1024 * slice; k < cnt; k += 1024 * slices) {
     const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + k]) * 3;
     const float px = p[0], py = p[1], pz = p[2];
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
         // next read, ~120 cycles each; a point near a limb has several hundred candidates).  The last trip re-reads the range's last slot:
         // a repeated candidate changes nothing (same distance, same vertex)
         const int e = cstart[c1 + 1];
+        nev += (unsigned int)(e - cstart[c0]);
         for (int i = cstart[c0]; i < e; i += 4) {
           f32x4 q[4];
 #pragma unroll
@@ -303,6 +306,12 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
         }
       }
     }
+  }
+  if (evals) {                                           // (a profile is open: one atomic per wave)
+    unsigned int ne = nev;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ne += __shfl_xor(ne, o);
+    if ((tid & 63) == 0 && ne) atomicAdd(evals, (unsigned long long)ne);
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { contrib += __shfl_xor(contrib, o); nhit += __shfl_xor(nhit, o); }
@@ -774,7 +783,7 @@ int collision_impl(const float* verts, const float* scene, float* loss, float* g
     slices = slices < 1 ? 1 : (slices > 4 ? 4 : slices);
     if (slices > (N + 1023) / 1024) slices = (N + 1023) / 1024;
     hipLaunchKernelGGL(nearest_grid_kernel, dim3(B, slices), dim3(1024), lds_grid, st, verts, scene, s.idx, s.count, s.bbox, loss, gverts, hits, V,
-                       N, tau);
+                       N, tau, ehm_prof_evals_ptr());
   } else {   // bodies too large for the in-LDS grid: brute force over an LDS-resident copy of the vertices
     hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)ceil_div(N, 1024), B), dim3(1024), lds, st, verts, scene, s.idx, s.count, loss,
                        gverts, hits, V, N, tau);

@@ -84,6 +84,7 @@ int ehm_guidance_impl(ehm_smpl* smpl, const float* betas, const float* x, const 
                       float* A_ws, float* gverts, float* loss, float* gpose, float* grad, void* scratch, hipStream_t st,
                       float* vposed_ws = nullptr);   // [B,V,3] scratch or nullptr: the forward's blended rest vertices for the skinning VJP (else recomputed there)
 // sampler.hip: launch-class timing for bench.py (ehm_profile_begin / ehm_profile_end); a no-op unless a profile is open
+unsigned long long* ehm_prof_evals_ptr();   // device counter of the collision search's distance evaluations, or nullptr when no profile is open
 struct EhmProfScope {
   int cls;
   hipStream_t st;

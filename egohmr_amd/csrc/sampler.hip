@@ -57,7 +57,9 @@ namespace {
 struct ProfRec { int cls; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec*> g_prof;
+unsigned long long* g_prof_evals = nullptr;     // device word: distance evaluations of the collision proxy's search while a profile is open
 }  // namespace
+unsigned long long* ehm_prof_evals_ptr() { return g_prof_on ? g_prof_evals : nullptr; }
 EhmProfScope::EhmProfScope(int cls_, hipStream_t st_) : cls(cls_), st(st_), rec(nullptr) {
   if (!g_prof_on) return;
   ProfRec* r = new ProfRec{cls, nullptr, nullptr};
@@ -76,6 +78,8 @@ EhmProfScope::~EhmProfScope() {
 extern "C" int ehm_profile_begin(void) {
   for (ProfRec* r : g_prof) { (void)hipEventDestroy(r->a); (void)hipEventDestroy(r->b); delete r; }
   g_prof.clear();
+  if (!g_prof_evals && hipMalloc(&g_prof_evals, sizeof(unsigned long long)) != hipSuccess) g_prof_evals = nullptr;
+  if (g_prof_evals) (void)hipMemset(g_prof_evals, 0, sizeof(unsigned long long));
   g_prof_on = true;
   return 0;
 }
@@ -93,6 +97,10 @@ extern "C" int ehm_profile_end(double* ms, int64_t* launches, int n) {
     delete r;
   }
   g_prof.clear();
+  if (n > EHM_PROF_G_NEAREST_EVALS && g_prof_evals) {      // a COUNT, not a launch class: distance evaluations of nearest_grid_kernel during the profile
+    unsigned long long ev = 0;
+    if (hipMemcpy(&ev, g_prof_evals, sizeof(ev), hipMemcpyDeviceToHost) == hipSuccess) launches[EHM_PROF_G_NEAREST_EVALS] = (int64_t)ev;
+  }
   if (rc) ehm_set_error("ehm_profile_end: an event of the profile could not be read");
   return rc;
 }

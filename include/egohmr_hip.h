@@ -458,7 +458,8 @@ enum {
   EHM_PROF_G_SKIN_BWD = 11,  /* inside EHM_PROF_GUIDANCE: skin_bwd_kernel (VJP of the skinning)                          */
   EHM_PROF_G_POSEFEAT_BWD = 12, /* inside EHM_PROF_GUIDANCE: posefeat_bwd_kernel ([B, 20670] x [20670, 207] contraction) */
   EHM_PROF_STEP_FUSED = 13,  /* step_fused_kernel: a step's output responses + per-body update + the NEXT step's input conv, one block per body */
-  EHM_PROF_N = 14
+  EHM_PROF_G_NEAREST_EVALS = 14, /* not a launch class: launches[14] = point-to-vertex distance evaluations of nearest_grid_kernel while the profile was open (ms[14] = 0) */
+  EHM_PROF_N = 15
 };
 int ehm_profile_begin(void);
 int ehm_profile_end(double* ms, int64_t* launches, int n);

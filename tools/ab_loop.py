@@ -59,5 +59,5 @@ torch.cuda.synchronize()
 n = len(_lib.PROF_CLASSES)
 ms_arr, cnt = (C.c_double * n)(), (C.c_int64 * n)()
 L.ehm_profile_end(ms_arr, cnt, n)
-prof = {c: (round(ms_arr[i] / cnt[i] * 1e3, 1), int(cnt[i])) for i, c in enumerate(_lib.PROF_CLASSES) if cnt[i]}
+prof = {c: (round(ms_arr[i] / cnt[i] * 1e3, 1), int(cnt[i])) for i, c in enumerate(_lib.PROF_CLASSES) if cnt[i] and ms_arr[i] > 0}
 print(f"{os.path.basename(os.environ.get('EHM_LIB_PATH', 'base'))} {wl}: {ms:.2f} ms/call = {B * S / ms * 1e3:.0f} bodies/s  {prof}")

@@ -556,7 +556,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
                     "of an LDS-resident cell grid, loss and d loss / d verts)",
                     "valu_f32", 8.0 * nearest_evals / max(n_g, 1), PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                     f"8 flop x {nearest_evals / max(n_g, 1) / max(nb, 1):.0f} distance evaluations per body and guided step (counted in the kernel); peak = the f32 vector rate "
-                    "(157.3 TFLOP/s).  A lane walks its point's candidates alone: the fraction mostly says how uneven the candidate counts of a wave's 64 points are")
+                    "(157.3 TFLOP/s).  One wave per point: the fraction says how little arithmetic a point is (tens of candidates) next to what it takes to find them")
             if "guid_nearest" in guid:
                 guid["guid_nearest"]["distance_evaluations_per_launch"] = nearest_evals / max(n_g, 1)
             g_entry("guid_skin_bwd", "skin_bwd_kernel (VJP of the skinning: d loss / d transforms, d loss / d blended rest pose)",

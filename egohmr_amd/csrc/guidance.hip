@@ -170,14 +170,15 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
                                                             const float* __restrict__ bbox, float* __restrict__ loss,
                                                             float* __restrict__ gverts, int* __restrict__ hits, int V, int N, float tau,
                                                             unsigned long long* __restrict__ evals) {
-  // grid = (bodies, slices): the selected points of a body are dealt out in runs of 1024 to gridDim.y blocks, each of which builds the
-  // body's (cheap) cell grid for itself - the per-point search is 93 % of the kernel (in-kernel stamps) and one block per body left
-  // half of the chip idle at B = 128
+  // grid = (bodies, slices): the selected points of a body are dealt out to gridDim.y blocks (wave w of slice s takes points w + 16 s,
+  // w + 16 s + 16 slices, ...), each of which builds the body's (cheap: ~11 us) cell grid for itself - one block per body left half of the chip
+  // idle at B = 128
   extern __shared__ __attribute__((aligned(16))) float sv[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int slice = blockIdx.y, slices = gridDim.y;
   const int cnt = count[b];
-  if (cnt <= 1024 * slice) return;                       // block-uniform: nothing for this slice (cnt == 0 included)
+  if (cnt <= 16 * slice) return;                         // block-uniform: nothing for this slice (cnt == 0 included)
+
   const int Vp = (V + 3) & ~3;
   f32x4* sp = (f32x4*)sv;                                // [Vp] slot i = (x, y, z, vertex id as bits) of the i-th vertex in CELL order
   int* cstart = (int*)(sv + 4 * Vp);                     // [kMaxCells + 1] exclusive offsets
@@ -255,42 +256,74 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
     }
   __syncthreads();
 
+  // ---- the search: one WAVE per point.  (Rounds 2-4: one LANE per point - a body's ~1000 selected points have 20 candidates on average, but
+  //      a point next to a dense part of the body has a thousand or more, and the block waited for those few lanes: 0.9 ms per guided step at
+  //      1280 bodies for 24 M distance evaluations, 0.13 % of the vector rate.)  The (up to) nine x-runs of the point's 27 cells are nine slot
+  //      ranges; lanes 0-8 fetch their bounds, a 9-step prefix turns them into ONE candidate list that the 64 lanes stride through; the wave
+  //      minimum breaks ties by the lower vertex index like torch.min.
   float contrib = 0.f;
   int nhit = 0;
-  unsigned int nev = 0;                                  // distance evaluations of this thread (bench.py's roofline of the search; counted per range)
-  for (int k = tid + 1024 * slice; k < cnt; k += 1024 * slices) {
-    const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + k]) * 3;
-    const float px = p[0], py = p[1], pz = p[2];
+  unsigned int nev = 0;                                  // distance evaluations (bench.py's roofline of the search)
+  const int lane = tid & 63, wave = tid >> 6;
+  // a wave's points arrive 64 at a time, one per lane (two dependent global loads - index, then position - per 64 points instead of per point:
+  // as a per-point load they were 1.3 us of each point's 1.4), and are handed round with v_readlane
+  for (int k0 = wave + 16 * slice; k0 < cnt; k0 += 64 * 16 * slices) {
+    const int kl = k0 + lane * 16 * slices;
+    float lx = 0.f, ly = 0.f, lz = 0.f;
+    if (kl < cnt) {
+      const float* p = scene + ((size_t)b * N + idx[(size_t)b * N + kl]) * 3;
+      lx = p[0]; ly = p[1]; lz = p[2];
+    }
+    const int npts = min(64, (cnt - k0 + 16 * slices - 1) / (16 * slices));
+  for (int pi = 0; pi < npts; ++pi) {
+    const float px = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lx), pi));
+    const float py = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ly), pi));
+    const float pz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lz), pi));
     int cx, cy, cz;
     cell_of(px, py, pz, cx, cy, cz);
+    int rs = 0, rl = 0;                                  // my range (lanes 0-8): first slot, length
+    if (lane < 9) {
+      const int dz = cz - 1 + lane / 3, dy = cy - 1 + lane % 3;
+      if (dz >= 0 && dz < nz && dy >= 0 && dy < ny) {
+        const int c0 = max(cx - 1, 0) + nx * (dy + ny * dz), c1 = min(cx + 1, nx - 1) + nx * (dy + ny * dz);
+        rs = cstart[c0];
+        rl = cstart[c1 + 1] - rs;
+      }
+    }
+    int start[9], pref[10];                              // wave-uniform copies (scalar registers)
+    pref[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      start[r] = __builtin_amdgcn_readlane(rs, r);
+      pref[r + 1] = pref[r] + __builtin_amdgcn_readlane(rl, r);
+    }
+    const int total = pref[9];
+    if (total == 0) continue;                            // (wave-uniform) no body vertex within reach of this point: most points of a bounding box
+    nev += lane == 0 ? (unsigned int)total : 0u;
     float best = 3.4e38f;
     int bi = 0x7fffffff, bslot = 0;
-    for (int dz = max(cz - 1, 0); dz <= min(cz + 1, nz - 1); ++dz)
-      for (int dy = max(cy - 1, 0); dy <= min(cy + 1, ny - 1); ++dy) {
-        // the (up to three) cells of one x-run are adjacent in the sorted order: one contiguous slot range
-        const int c0 = max(cx - 1, 0) + nx * (dy + ny * dz), c1 = min(cx + 1, nx - 1) + nx * (dy + ny * dz);
-        // four candidates per trip, their slots requested together: one candidate per trip is a chain of LDS round trips (read -> compare ->
-        // next read, ~120 cycles each; a point near a limb has several hundred candidates).  The last trip re-reads the range's last slot:
-        // a repeated candidate changes nothing (same distance, same vertex)
-        const int e = cstart[c1 + 1];
-        nev += (unsigned int)(e - cstart[c0]);
-        for (int i = cstart[c0]; i < e; i += 4) {
-          f32x4 q[4];
+    for (int i = lane; i < total; i += 64) {
+      int slot = start[0] + i;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) q[u] = sp[min(i + u, e - 1)];
+      for (int r = 1; r < 9; ++r) slot = i >= pref[r] ? start[r] + (i - pref[r]) : slot;
+      const f32x4 q = sp[slot];
+      const float ex = px - q[0], ey = py - q[1], ez = pz - q[2];
+      const float d2 = ex * ex + ey * ey + ez * ez;
+      const float qw = q[3];                             // (hipcc: __builtin_bit_cast of a vector ELEMENT expression reads element 0 - go through a scalar)
+      const int v = __builtin_bit_cast(int, qw);
+      if (d2 < best || (d2 == best && v < bi)) { best = d2; bi = v; bslot = slot; }
+    }
+    // wave minimum of (distance, vertex index): four DPP steps inside the 16-lane rows (__shfl_xor is ds_bpermute, an LDS round trip per value and
+    // step: 18 of them were ~900 of a point's ~2300 cycles), then the four row results through v_readlane
+    auto take = [&](float ob, int oi, int os) { if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; bslot = os; } };
+#define EHM_DPP_MIN(CTRL) take(dpp_move<CTRL>(best), __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, bslot, CTRL, 0xF, 0xF, true))
+    EHM_DPP_MIN(0xB1); EHM_DPP_MIN(0x4E); EHM_DPP_MIN(0x141); EHM_DPP_MIN(0x140);
+#undef EHM_DPP_MIN
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float ex = px - q[u][0], ey = py - q[u][1], ez = pz - q[u][2];
-            const float d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 <= best) {                             // (rare path) first minimum by vertex index, like torch.min
-              const float qw = q[u][3];                   // (hipcc: __builtin_bit_cast of a vector ELEMENT expression reads element 0 - go through a scalar)
-              const int v = __builtin_bit_cast(int, qw);
-              if (d2 < best || v < bi) { best = d2; bi = v; bslot = min(i + u, e - 1); }
-            }
-          }
-        }
-      }
-    if (bi != 0x7fffffff) {
+    for (int rrow = 16; rrow < 64; rrow += 16)
+      take(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best), rrow)), __builtin_amdgcn_readlane(bi, rrow),
+           __builtin_amdgcn_readlane(bslot, rrow));    // (lane 0 ends with the wave's minimum; the other lanes' values are not used)
+    if (lane == 0 && bi != 0x7fffffff) {
       const float d = sqrtf(best + 1e-12f);
       const float hh = tau - d;
       if (hh > 0.f) {
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(1024) void nearest_grid_kernel(const float* __restr
         }
       }
     }
+  }
   }
   if (evals) {                                           // (a profile is open: one atomic per wave)
     unsigned int ne = nev;

@@ -45,7 +45,8 @@ WORKLOADS = {
     # convs of every step; encoders, input / output convs, sampler update, LBS in f32-grade arithmetic).  NOT a parity tier: MPJPE to the f32-grade run reported
     "c5_volsmpl_ddpm1000": (1000, "", "BASELINE config 5 per-GPU shard: B128 S1 DDPM-1000, VolSMPL-style collision guidance (all scene points, sum reduction), fp16 denoiser + fp32 LBS"),
 }
-WORKLOAD_PRECISION = {"c5_volsmpl_ddpm1000": "f16"}       # the precision a workload NAMES (overrides --precision's default only)
+WORKLOAD_PRECISION = {"c5_volsmpl_ddpm1000": "f16"}       # the precision a workload NAMES (overrides --precision's default only); its encoders run the
+                                                          # plain-f16 tier too (EgoHMR.encoder_precision = 'f16': "for THIS tier only")
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (~2.5 PFLOP/s)
 
@@ -138,7 +139,7 @@ def compact_line(d):
     if subs:
         out["configs"] = subs
     legs = {}
-    for name in ("all_steps_f16x3", "f32_mfma_path", "f16_denoiser_path", "schedule_at_contract_tol"):
+    for name in ("all_steps_f16x3", "f32_mfma_path", "f16_denoiser_path", "fp16_tier", "schedule_at_contract_tol"):
         if d.get(name):
             legs[name] = {"value": _num(d[name]["value"]), "mpjpe_mm": _num((d[name].get("vs_default_path") or {}).get("mpjpe_mm"), 3)}
     if legs:
@@ -285,6 +286,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     model = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=sens, volsmpl=volsmpl)
     model.lbs_every_step = not args.no_lbs_every_step
     model.gcn_precision = args.precision
+    if args.precision_given is None and workload in WORKLOAD_PRECISION:
+        model.encoder_precision = "f16"
     if args.f16x3_last_steps is not None:
         model.f16x3_last_steps = int(args.f16x3_last_steps)
     diffusion = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing=rs)
@@ -360,9 +363,9 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
         ref_v = res["other_outputs"]["pred_vertices"].float().clone()
         ref_j = res["other_outputs"]["pred_keypoints_3d"].float().clone()
 
-        def leg(prec, last_steps, m=model, compare=True):
-            old = (m.gcn_precision, m.f16x3_last_steps)
-            m.gcn_precision, m.f16x3_last_steps = prec, last_steps
+        def leg(prec, last_steps, m=model, compare=True, enc="f16x3"):
+            old = (m.gcn_precision, m.f16x3_last_steps, m.encoder_precision)
+            m.gcn_precision, m.f16x3_last_steps, m.encoder_precision = prec, last_steps, enc
             try:
                 one_step(m)
                 torch.cuda.synchronize()
@@ -372,7 +375,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
                 m.fused_sampler.check_status()
                 d = time.perf_counter() - t1
             finally:
-                m.gcn_precision, m.f16x3_last_steps = old
+                m.gcn_precision, m.f16x3_last_steps, m.encoder_precision = old
             out = {"value": B * S / d, "unit": "bodies/s", "ms_per_step": d * 1e3}
             if compare:
                 v = r["other_outputs"]["pred_vertices"].float()
@@ -388,6 +391,10 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
         legs["f16_denoiser_path"] = leg("f16", None)
         legs["f16_denoiser_path"]["note"] = ("plain f16 operands and f16 activations in the hidden convs of EVERY step (f32 accumulate, everything "
                                              "else f32): BASELINE config 5's fp16 denoiser, not a parity path on its own")
+        legs["fp16_tier"] = leg("f16", None, enc="f16")
+        legs["fp16_tier"]["note"] = ("BASELINE config 5's fp16 tier as a whole: plain-f16 denoiser AND plain-f16 encoders (hi halves only: one MFMA per product, half the "
+                                     "bytes), float32 LBS / sampler update.  NOT a parity path (reference-golden bound: tests/test_gpu_schedule.py::"
+                                     "test_fp16_tier_mpjpe_bound_vs_reference_golden)")
         if workload == "ddpm100" and model.f16x3_last_steps == "auto":
             # the same job with the schedule calibrated to the north-star's OWN bar (1e-4 m -> criterion 5e-5 m) instead of the default 1e-5 m
             old_tol = model.schedule_tol
@@ -424,8 +431,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
         # the fp16-denoiser tier against the f32-grade run of the SAME job (same noise): what the tier costs in accuracy, next to what it buys
         j16 = res["other_outputs"]["pred_keypoints_3d"].float().clone()
         v16 = res["other_outputs"]["pred_vertices"].float().clone()
-        old_p = (model.gcn_precision, model.f16x3_last_steps)
-        model.gcn_precision, model.f16x3_last_steps = "f16x3", None
+        old_p = (model.gcn_precision, model.f16x3_last_steps, model.encoder_precision)
+        model.gcn_precision, model.f16x3_last_steps, model.encoder_precision = "f16x3", None, "f16x3"
         try:
             one_step()
             torch.cuda.synchronize()
@@ -435,7 +442,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
             fs.check_status()
             d32 = time.perf_counter() - t1
         finally:
-            model.gcn_precision, model.f16x3_last_steps = old_p
+            model.gcn_precision, model.f16x3_last_steps, model.encoder_precision = old_p
         j32 = r32["other_outputs"]["pred_keypoints_3d"].float()
         legs["f32_grade_path_of_this_job"] = {
             "value": B * S / d32, "unit": "bodies/s", "ms_per_step": d32 * 1e3,
@@ -596,7 +603,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
             "data": "synthetic",
             "config": {"workload": desc, "name": workload, "items_per_gpu": B, "samples_per_item": S, "samples_in_one_loop": bool(S > 1), "collision_guided": guided, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
-                       "gcn_precision": args.precision, "f16x3_last_steps": k_last if args.precision == "f16x3" else None,
+                       "gcn_precision": args.precision, "encoder_precision": model.encoder_precision, "f16x3_last_steps": k_last if args.precision == "f16x3" else None,
                        "f16x3_last_steps_policy": str(model.f16x3_last_steps),
                        "pass_pruning": {"items_without_second_pass": int(B - st.num_masked) if model.prune_passes else 0, "of": B,
                                         "note": "exact (egohmr.py:249-254): all-visible items skip the image-masked pass; the synthetic "

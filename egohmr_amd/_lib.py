@@ -90,7 +90,7 @@ class LinearDesc(C.Structure):
     _fields_ = [("A0", C.c_void_p), ("A1", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("group_bias", C.c_void_p),
                 ("Y", C.c_void_p), ("colmax", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K0", C.c_int), ("K1", C.c_int),
                 ("rows_per_group", C.c_int), ("valid_rows_per_group", C.c_int), ("relu_in0", C.c_int), ("relu_out", C.c_int),
-                ("w_scale", C.c_float), ("lift_points", C.c_void_p), ("lift_W4", C.c_void_p)]
+                ("w_scale", C.c_float), ("lift_points", C.c_void_p), ("lift_W4", C.c_void_p), ("hi_only", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -107,7 +107,7 @@ class ConvX2Desc(C.Structure):
                 ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
                 ("w_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("x2", C.c_void_p), ("x2_rows", C.c_int64), ("H2", C.c_int), ("W2", C.c_int), ("Ci2", C.c_int), ("stride2", C.c_int)]
+                ("x2", C.c_void_p), ("x2_rows", C.c_int64), ("H2", C.c_int), ("W2", C.c_int), ("Ci2", C.c_int), ("stride2", C.c_int), ("hi_only", C.c_int)]
 
 
 class ItemPrepDesc(C.Structure):
@@ -188,7 +188,7 @@ PROTOTYPES = {
     "ehm_conv_x2_rows": (C.c_int64, [C.c_int64]),
     "ehm_conv_x2": (_I, [C.POINTER(ConvX2Desc), _P]),
     "ehm_conv_x2_workspace_bytes": (C.c_int64, [C.POINTER(ConvX2Desc)]),
-    "ehm_x2_group_mean": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ehm_x2_group_mean": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
     "ehm_nonlocal_attention": (_I, [_P, _P, _L, _I, _P]),
     "ehm_pointnet_lift": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -260,7 +260,10 @@ struct XFrags {
 
 // NU = 2: 192 x 128 tiles (96 x 64 per wave); NU = 1: 192 x 64 tiles (96 x 32 per wave) for Co = 64 layers (no padding columns through
 // the matrix cores).
-template <int NU, bool SK, bool DS = false>
+// HO ("hi only", ehm_conv_x2_desc.hi_only): the plain-f16 tier of the encoders (BASELINE config 5's fp16 tier; NOT parity grade: 0.4 - 1.4 mm of final
+// vertex) on the SAME buffers - only the hi halves of activations and weights are fetched (half of every 128-byte chunk: the lanes
+// of an operand piece that carry lo chunks are masked off), multiplied (one MFMA per product instead of three), and written; lo halves are don't-care.
+template <int NU, bool SK, bool DS = false, bool HO = false>
 __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   static_assert(!(SK && DS), "the dual-source conv runs whole tiles");
   constexpr int XBN = 64 * NU, XSTG = x_stage_floats(NU);
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   const int m_tiles = (int)((p.M + XBM - 1) / XBM);
 
   int lane, wave, wm, wn, mi, g, r0, swz;
+  bool hi_lane;                                   // my 16-byte chunk of an operand piece holds hi halves (logical chunks 0-3 of the 128-byte K tile)
   int oA[KS][2], oB[KS][2];
   auto thread_consts = [&]() {
     int t = tid;
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     mi = lane & 31; g = lane >> 5;
     r0 = 8 * wave + (lane >> 3);
     swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2;
+    hi_lane = swz < 16;
     const int rA = 96 * wm + mi, rB = 32 * NU * wn + mi;
     const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
 #pragma unroll
@@ -352,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     voB = (r0 * K + swz) * 4;
   };
   auto dma_a = [&](int buf, int kt, int i) {
+    if (HO && !hi_lane) return;                   // (half of the lanes of every piece: the instruction is still issued, the wait counts stand)
     if constexpr (DS) {
       if (kt >= KT1) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (AS3 void*)(lds + buf * XSTG + (wave + 4 * i) * 256), 16, (int)pbase2[i], (kt - KT1) * XRK * 4, 0, 0);
@@ -365,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (AS3 void*)(lds + buf * XSTG + (wave + 4 * i) * 256), 16, (int)off, 0, 0, 0);
   };
   auto dma_b = [&](int buf, int kt, int i) {
+    if (HO && !hi_lane) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (AS3 void*)(lds + buf * XSTG + XA_T + (wave + 4 * i) * 256), 16, voB, (i * brow32 + kt * XRK) * 4, 0, 0);
   };
   auto stage = [&](int buf, int kt) {
@@ -378,12 +385,12 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       f.ah[t] = *(const half8*)(S + oA[s][0] + 32 * t * XRK);
-      f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * XRK);
+      if constexpr (!HO) f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * XRK);
     }
  #pragma unroll
     for (int u = 0; u < NU; ++u) {
       f.bh[u] = *(const half8*)(S + oB[s][0] + 32 * u * XRK);
-      f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * XRK);
+      if constexpr (!HO) f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * XRK);
     }
   };
   f32x16 acc[3][NU];
@@ -392,12 +399,15 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int u = 0; u < NU; ++u) {                             // small cross terms first, leading term last
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
+        if constexpr (!HO) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
+        }
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[u], acc[t][u], 0, 0, 0);
       }
   };
   auto pin_reads = [&]() {
+    if constexpr (HO) return;                     // (the hi-only instruction mix is left to the scheduler)
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -406,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
   };
   auto pin_reads_dma = [&]() {
+    if constexpr (HO) return;
     if constexpr (NU == 2) {                                      // 18 MFMAs, 10 reads, 10 DMAs
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
@@ -622,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
           for (int it3 = 0; it3 < 3; ++it3) {
             const unsigned int vo = (unsigned int)(8 * GP * ps + ISTEP * it3 + irow) * yrow + col_off;
             rq[it3][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, 0, 0);
-            rq[it3][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo + 64u, 0, 0);
+            if constexpr (!HO) rq[it3][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo + 64u, 0, 0);
           }
         }
 #pragma unroll
@@ -645,9 +656,15 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
         for (int it3 = 0; it3 < 3; ++it3) {
           float v[8] = {tq[it3][0][0], tq[it3][0][1], tq[it3][0][2], tq[it3][0][3], tq[it3][1][0], tq[it3][1][1], tq[it3][1][2], tq[it3][1][3]};
           if (has_res) {
-            const half8 rh = __builtin_bit_cast(half8, rq[it3][0]), rl = __builtin_bit_cast(half8, rq[it3][1]);
+            const half8 rh = __builtin_bit_cast(half8, rq[it3][0]);
+            if constexpr (HO) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] += (float)rh[c] + (float)rl[c];
+              for (int c = 0; c < 8; ++c) v[c] += (float)rh[c];
+            } else {
+              const half8 rl = __builtin_bit_cast(half8, rq[it3][1]);
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[c] += (float)rh[c] + (float)rl[c];
+            }
           }
           half8 hh, ll;
 #pragma unroll
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
           const unsigned int vo = (unsigned int)(8 * GP * ps + ISTEP * it3 + irow) * yrow + col_off;
           if (colw < p.Co) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
+            if constexpr (!HO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
           }
         }
       }
@@ -672,10 +689,13 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 }
 
 // X2 [rows, C] -> float32 mean over groups of `hw` consecutive rows: the global average pool behind the last bottleneck
-__global__ void x2_group_mean_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int hw, int C) {
+__global__ void x2_group_mean_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int hw, int C, int hi_only) {
   const int img = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;        // thread = channel: a wave reads 64 consecutive halves per row
   if (c >= C) return;
   float s = 0.f;
+  if (hi_only) {
+    for (int r = 0; r < hw; ++r) s += (float)X[split_off<32>((size_t)img * hw + r, c, C)];
+  } else
   for (int r = 0; r < hw; ++r) s += split_load<32>(X, (size_t)img * hw + r, c, C);
   Y[(size_t)img * C + c] = s / (float)hw;
 }
@@ -785,22 +805,30 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
     a.sk_per = sk.per;
     EHM_HIP(hipMemsetAsync(a.sk_flags, 0, (size_t)sk.flag_bytes, (hipStream_t)stream));
     const int64_t blocks = ceil_div(tiles * (d->KH * d->KW * (d->Ci / XRK) / 2), (int64_t)sk.per);
-    if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (d->hi_only) {
+      if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     EHM_LAUNCH_CHECK();
     return 0;
   }
   const int64_t blocks = tiles < slots ? tiles : slots;
-  if (dual) hipLaunchKernelGGL((conv_x2_tile_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->hi_only) {
+    if (dual) hipLaunchKernelGGL((conv_x2_tile_kernel<2, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_x2_tile_kernel<2, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (dual) hipLaunchKernelGGL((conv_x2_tile_kernel<2, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((conv_x2_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, void* stream) {
+extern "C" int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, int hi_only, void* stream) {
   EHM_CHECK_ARG(X && Y && groups > 0 && rows_per_group > 0 && C > 0 && C % 32 == 0);
-  hipLaunchKernelGGL(x2_group_mean_kernel, dim3((unsigned)groups, (unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X, Y, rows_per_group, C);
+  hipLaunchKernelGGL(x2_group_mean_kernel, dim3((unsigned)groups, (unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X, Y, rows_per_group, C,
+                     hi_only);
   EHM_LAUNCH_CHECK();
   return 0;
 }

@@ -78,7 +78,8 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 // tile's 192 rows (three per lane, their points stay in nine registers for the whole tile), splits the values exactly like
 // split_store and writes the hi / lo chunks at the loader's swizzled positions.  Stage 1 is written behind the head barrier of the
 // tile (its rows are other waves' epilogue scratch until then); its values are visible after the first K tile's barrier.
-template <bool RELU_A, bool LIFT>
+// HO ("hi only", ehm_linear_desc.hi_only): the plain-f16 tier (NOT parity grade, see conv.hip): only hi halves are fetched, multiplied and written.
+template <bool RELU_A, bool LIFT, bool HO = false>
 __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   static_assert(!(RELU_A && LIFT), "the generated operand is already rectified");
   __shared__ __attribute__((aligned(16))) float lds[2 * LSTG];   // 80 KiB; the ONLY LDS object
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   const int n_tiles = p.N / LBN, m_tiles = p.M / LBM;
 
   int lane, wave, wm, wn, mi, g, r0, swz;
+  bool hi_lane;                                                // my 16-byte chunk of an operand piece holds hi halves
   int oA[KS][2], oB[KS][2];
   auto thread_consts = [&]() {                                 // re-derived per tile: nothing of this stays live across the epilogue
     int t = tid;
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     mi = lane & 31; g = lane >> 5;
     r0 = 8 * wave + (lane >> 3);                               // DMA: one wave instruction = 8 rows x 128 B, rows r0 + 32 i share a key
     swz = ((lane & 7) ^ ((r0 >> 1) & 7)) << 2;
+    hi_lane = swz < 16;
     const int rA = 96 * wm + mi, rB = 64 * wn + mi;            // (+ 32 t / + 32 u leave the swizzle key alone)
     const int keyA = (rA >> 1) & 7, keyB = (rB >> 1) & 7;
 #pragma unroll
@@ -147,11 +150,13 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     voB = (r0 * K + swz) * 4;
   };
   auto dma_a = [&](int buf, int kt, int i) {
+    if (HO && !hi_lane) return;                                // (half of the lanes of every piece; the instruction is still issued: wait counts stand)
     AS3 void* dst = (AS3 void*)(lds + buf * LSTG + (wave + 4 * i) * 256);
     if (kt < KT0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, dst, 16, voA0, (i * a0row32 + kt * RK) * 4, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, dst, 16, voA1, (i * a1row32 + (kt - KT0) * RK) * 4, 0, 0);
   };
   auto dma_b = [&](int buf, int kt, int i) {
+    if (HO && !hi_lane) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (AS3 void*)(lds + buf * LSTG + LA_T + (wave + 4 * i) * 256), 16, voB, (i * brow32 + kt * RK) * 4, 0, 0);
   };
   float px[3], py[3], pz[3];                                    // LIFT: the points of rows lane + 64 j of the current tile
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       }
       float* dst = lds + buf * LSTG + row * RK;
       *(half8*)(dst + ((wave ^ key) << 2)) = hi;                  // logical chunk 2 s + g = wave: k = 8 wave .. + 7
-      *(half8*)(dst + (((wave + 4) ^ key) << 2)) = lo;
+      if constexpr (!HO) *(half8*)(dst + (((wave + 4) ^ key) << 2)) = lo;
     }
   };
   auto stage = [&](int buf, int kt) {
@@ -204,16 +209,31 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       f.ah[t] = *(const half8*)(S + oA[s][0] + 32 * t * RK);
-      f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * RK);
+      if constexpr (!HO) f.al[t] = *(const half8*)(S + oA[s][1] + 32 * t * RK);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f.bh[u] = *(const half8*)(S + oB[s][0] + 32 * u * RK);
-      f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * RK);
+      if constexpr (!HO) f.bl[u] = *(const half8*)(S + oB[s][1] + 32 * u * RK);
     }
     if constexpr (RELU_A) {                                       // (the ReLU'd operand is the only K segment: K1 == 0, checked by the host)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) relu_split(f.ah[t], f.al[t]);
+      for (int t = 0; t < 3; ++t) {
+        if constexpr (HO) {
+          typedef _Float16 half2_r __attribute__((ext_vector_type(2)));
+          typedef unsigned int u32x4_r __attribute__((ext_vector_type(4)));
+          u32x4_r h = __builtin_bit_cast(u32x4_r, f.ah[t]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned int he = h[e];
+            const half2_r m = __builtin_elementwise_max(__builtin_bit_cast(half2_r, he), half2_r{(_Float16)0.f, (_Float16)0.f});
+            h[e] = __builtin_bit_cast(unsigned int, m);
+          }
+          f.ah[t] = __builtin_bit_cast(half8, h);
+        } else {
+          relu_split(f.ah[t], f.al[t]);
+        }
+      }
     }
   };
   f32x16 acc[3][2];
@@ -222,13 +242,16 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {                             // small cross terms first, leading term last
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
+        if constexpr (!HO) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[t], f.bh[u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bl[u], acc[t][u], 0, 0, 0);
+        }
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[t], f.bh[u], acc[t][u], 0, 0, 0);
       }
   };
   // sched_group_barrier masks: 0x008 MFMA, 0x100 DS read, 0x010 VMEM
   auto pin_reads = [&]() {
+    if constexpr (HO) return;                                   // (the hi-only instruction mix is left to the scheduler)
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -237,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
   };
   auto pin_reads_dma = [&]() {                                  // 10 x (MFMA, read), then the ten DMAs behind the last 8 MFMAs
+    if constexpr (HO) return;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -394,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
           }
           const unsigned int vo = (unsigned int)(8 * Gq + rr) * yrow + col_off;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
+          if constexpr (!HO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
         }
       }
     }
@@ -601,7 +625,11 @@ extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
     ehm_set_error("ehm_linear_split: relu_in0 needs K1 == 0 (the ReLU'd operand must be the only K segment)");
     return EHM_EINVAL;
   }
-  if (lift) hipLaunchKernelGGL((linear_tile_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->hi_only) {
+    if (lift) hipLaunchKernelGGL((linear_tile_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else if (d->relu_in0) hipLaunchKernelGGL((linear_tile_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((linear_tile_kernel<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (lift) hipLaunchKernelGGL((linear_tile_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else if (d->relu_in0) hipLaunchKernelGGL((linear_tile_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((linear_tile_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();

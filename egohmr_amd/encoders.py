@@ -44,6 +44,8 @@ class _Bottleneck(nn.Module):
 class ResNet50Features(nn.Module):
     """models/resnet.py:139-150: ResNet-50 trunk, global average pool -> [B,2048]."""
 
+    hi_only = False      # True: the plain-f16 tier of the trunk (ehm_conv_x2_desc.hi_only: hi halves only, one MFMA per product) - NOT parity grade
+
     def __init__(self):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
@@ -179,6 +181,7 @@ class ResNet50Features(nn.Module):
             y = x2_buffer(N * Ho * Wo, Co, x.device)
             d = _lib.ConvX2Desc(x.data_ptr(), x.shape[0], buf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(),
                                 N, H, W, Ci, Co, KH, KW, stride, pad, 1 if relu else 0, scale, None, 0)
+            d.hi_only = int(bool(self.hi_only))                                  # the plain-f16 tier (EgoHMR.encoder_precision = 'f16'): NOT parity grade
             if shortcut is not None:
                 x_in, (_, H2, W2) = shortcut[0], shortcut[1]
                 d.x2, d.x2_rows, d.H2, d.W2, d.Ci2, d.stride2 = x_in.data_ptr(), x_in.shape[0], H2, W2, Ci2, stride2
@@ -208,7 +211,8 @@ class ResNet50Features(nn.Module):
                 else:
                     x, shp = conv_x2(y, s2, c3, res=conv_x2(x, shp, ds, relu=False)[0])
             out = torch.empty(N, x.shape[1], device=x.device)
-            _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], _lib.stream_ptr()), "ehm_x2_group_mean")
+            _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], int(bool(self.hi_only)), _lib.stream_ptr()),
+                       "ehm_x2_group_mean")
             return out
 
         def run(x):
@@ -246,6 +250,8 @@ class ResnetPointnet(nn.Module):
     Parameters keep the reference's names; the arithmetic runs on the split-f16 matrix-core kernels of
     csrc/linear.hip (f32-grade) with the per-body constant half of every block input folded
     into bias vectors, fc_1 + shortcut fused into one dual-source GEMM and the max-pool fused into its epilogue."""
+
+    hi_only = False      # True: the plain-f16 tier (ehm_linear_desc.hi_only) - NOT parity grade
 
     def __init__(self, out_dim=512, hidden_dim=256):
         super().__init__()
@@ -328,7 +334,7 @@ class ResnetPointnet(nn.Module):
                                 group_bias=gbias.data_ptr() if gbias is not None else None,
                                 Y=Y.data_ptr() if Y is not None else None, colmax=colmax.data_ptr() if colmax is not None else None,
                                 M=M, N=H, K0=K0, K1=K1, rows_per_group=Np, valid_rows_per_group=N, relu_in0=int(relu_in0),
-                                relu_out=int(relu_out), w_scale=W[1])
+                                relu_out=int(relu_out), w_scale=W[1], hi_only=int(bool(self.hi_only)))
             _lib.check(L.ehm_linear_split(d, st), "ehm_linear_split")
             if Y is not None and _x2_debug_hook is not None:
                 _x2_debug_hook(Y, H)

@@ -146,7 +146,11 @@ class FusedSampler:
             raise ValueError("empty batch (the reference fails on it too: egohmr.py:233 reshapes x_t [0, 144] to [0, 24, -1])")
         # ... and of the model switches that ehm_item_prep bakes into the cached state (the pass map's grouping, the camera-feature columns, the
         # scene frame, which OpenPose joints feed the visibility mask)
-        switches = (int(getattr(m, "pass_group", 1)), bool(m.with_bbox_info), bool(m.with_cam_center), bool(m.scene_cano), tuple(m.openpose_to_smpl))
+        if m.encoder_precision not in ("f16x3", "f16"):
+            raise ValueError(f"EgoHMR.encoder_precision must be 'f16x3' or 'f16', not {m.encoder_precision!r}")
+        m.backbone.hi_only = m.scene_enc.hi_only = m.encoder_precision == "f16"
+        switches = (int(getattr(m, "pass_group", 1)), bool(m.with_bbox_info), bool(m.with_cam_center), bool(m.scene_cano), tuple(m.openpose_to_smpl),
+                    m.encoder_precision)
         key = tuple((id(t), t._version, t.data_ptr()) for t in ins) + self._param_key() + self._cond_param_key() + (switches,)
         if self._prep is not None and self._prep_key == key:
             return self._prep

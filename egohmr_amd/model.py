@@ -218,6 +218,9 @@ class EgoHMR(nn.Module):
                                            # (17.27 vs 16.75 ms, tools/enc_split.py, three alternations: both fill the chip on their own)
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
+        # arithmetic of the two conditioning encoders: 'f16x3' (split-f16, f32 grade - the parity path) | 'f16' (plain f16 operands and activations: the
+        # encoders of BASELINE config 5's fp16 TIER, together with gcn_precision = 'f16'; NOT parity grade: 0.4 - 1.4 mm of final vertex)
+        self.encoder_precision = "f16x3"
         # precision schedule: only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'), the
         # earlier ones on plain f16 operands / f16 activations.  'auto' = the k that FusedSampler.calibrate_schedule MEASURED for the
         # loaded weights and the sampler in use (smallest k whose bodies stay within schedule_tol of the all-f16x3 loop; measured on the

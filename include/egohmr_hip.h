@@ -207,6 +207,7 @@ typedef struct {
                               the fly as relu(points . Wpos^T + bpos), K0 wide - fc_pos + the first block's actvn
                               (respointnet.py:35,:90) folded into the loader; then A0 == NULL, K1 == 0, relu_in0 == 0 */
   const float* lift_W4;    /* [K0][4] float32 rows (w_x, w_y, w_z, bias) of fc_pos                   */
+  int hi_only;             /* 1 = the plain-f16 tier (NOT parity grade): hi halves of A0 / A1 / W only, hi halves of Y only; 0 = split-f16 (f32 grade) */
 } ehm_linear_desc;
 int ehm_linear_split(const ehm_linear_desc* d, void* stream);
 /* float32 [rows,K] -> X2 [rows,K_padded] (zero padded), values multiplied by `scale` (1 for activations). */
@@ -268,6 +269,8 @@ typedef struct ehm_conv_x2_desc {
    * the SUM of the two folded biases; Co % 128 == 0. */
   const void* x2; int64_t x2_rows;
   int H2, W2, Ci2, stride2;
+  int hi_only;               /* 0 = split-f16 arithmetic (f32 grade, the parity path).  1 = the plain-f16 tier (NOT parity grade): only the hi halves of x, W,
+                                residual are read and only hi halves written - one MFMA per product, half the bytes; the lo halves of y are don't-care  */
 } ehm_conv_x2_desc;
 int64_t ehm_conv_x2_rows(int64_t pixels);
 /* Scratch of the stream-K schedule: when a conv's tile count would leave a large share of the GPU's block slots idle in its last round
@@ -277,7 +280,7 @@ int64_t ehm_conv_x2_workspace_bytes(const ehm_conv_x2_desc* d);
 int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream);
 /* Y[g, c] = mean over the rows_per_group consecutive rows of group g of the X2 matrix X [groups*rows_per_group (+ padding), C]:
  * the global average pool behind the last bottleneck (models/resnet.py:148-149). */
-int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, void* stream);
+int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, int hi_only /* 1: X was written by a hi_only call */, void* stream);
 
 /* Attention core of the optional non-local block of ModulatedGCN (nonlocal_layer=True, modulated_gcn.py:93-110;
  * nets/non_local_embedded_gaussian.py:68-79): per body, y = softmax(theta phi^T, dim=-1) g over the 24 joints.

@@ -249,3 +249,30 @@ def test_contract_tol_schedule_on_sensitive_weights_vs_reference_golden(golden_d
     dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
     print(f"[g16 @ 1e-4] calibrated k = {info['k']} of {info['T']}; max|dverts| vs reference = {dv:.3e}")
     _check_out(o, g)
+
+
+@pytest.mark.parametrize("name", ["g16_e2e_ddpm100_sensitive", "g16_e2e_ddim10_sensitive"])
+def test_fp16_tier_mpjpe_bound_vs_reference_golden(golden_dir, dev, smpl_asset, name):
+    """BASELINE config 5's fp16 TIER as a whole - plain-f16 denoiser (gcn_precision = 'f16') AND plain-f16 encoders (encoder_precision = 'f16':
+    hi halves only, ehm_conv_x2_desc.hi_only / ehm_linear_desc.hi_only), float32 LBS - is NOT a parity path; its distance to the reference's own run
+    on the trained-like weights (golden G16) is pinned as an MPJPE bound, and the encoders' features must really differ from the f32-grade ones (the
+    switch is live) while staying f16-close."""
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=100))
+    g = _load(golden_dir, name)
+    b = batch_to_device(syn.make_batch(int(g["B"]), num_scene_points=int(g["N"]), seed=int(g["batch_seed"])), dev)
+    f32 = (m.backbone(b["img"]).clone(), m.scene_enc(b["scene_pcd_verts_full"] - b["smpl_params"]["transl"][:, None]).clone())
+    m.gcn_precision, m.f16x3_last_steps, m.encoder_precision = "f16", None, "f16"
+    m.backbone.hi_only = m.scene_enc.hi_only = True
+    f16 = (m.backbone(b["img"]), m.scene_enc(b["scene_pcd_verts_full"] - b["smpl_params"]["transl"][:, None]))
+    for a, c, what in zip(f32, f16, ("image", "scene")):
+        rel = float((a - c).norm() / a.norm())
+        print(f"[fp16 tier] {what} features: relative difference to the split-f16 encoder {rel:.2e}")
+        assert 1e-6 < rel < 5e-3, (what, rel)
+    o, g, _ = _e2e_vs_golden(golden_dir, dev, m, name)
+    assert m.backbone.hi_only and m.scene_enc.hi_only
+    j, jr = o["pred_keypoints_3d"][:, :24].cpu().numpy(), g["joints"][:, :24]
+    mpjpe_mm = np.linalg.norm((j - j[:, :1]) - (jr - jr[:, :1]), axis=-1).mean() * 1000
+    dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    print(f"[fp16 tier / {name}] MPJPE vs reference = {mpjpe_mm:.4f} mm, max|dverts| = {dv * 1e3:.3f} mm")
+    assert mpjpe_mm < 1.0 and torch.isfinite(o["pred_vertices"]).all()

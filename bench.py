@@ -33,7 +33,7 @@ WORKLOADS = {
     "ddpm100": (100, "", "B256 S1 DDPM-100 N4096 ResNet50+PointNet cond, diffuse_fuse(2 GCN passes), LBS every step, unguided"),
     "c2_ddim10": (100, "ddim10", "BASELINE config 2: B256 S1 DDIM-10 N4096 ResNet50+PointNet cond, diffuse_fuse, LBS every step"),
     "c1_ddim5": (50, "ddim5", "BASELINE config 1 shape: DDIM-5 of 50"),
-    # BASELINE config 3: B128 items x 10 samples, full 100-step DDPM, collision guidance on the last 11 steps (proxy loss);
+    # BASELINE config 3: B128 items x 10 samples, full 100-step DDPM, collision guidance on the last 11 steps (proxy loss, EXPERIMENTS 3.5);
     # a "step" = one batch of items = its 10 guided samples, run as ONE fused loop over 1280 bodies on ONE conditioning pass (the reference
     # runs 10 sequential loops and re-encodes in every step of each)
     "c3_guided": (100, "", "BASELINE config 3: B128 x S10 DDPM-100, collision-guided (last 11 steps), conditioning encoded once per item"),
@@ -300,7 +300,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     fs = model.fused_sampler
     ddim = bool(rs)
     # guidance strength: C3 as in the guided goldens (2.0); the VolSMPL twin's own default (30, times B through -loss.sum()) is a chaotic regime with
-    # the build's proxy loss, so C5 is timed at the weight its tight goldens use (0.5) - the kernels' work does not depend on it
+    # the build's proxy loss (docs/EXPERIMENTS.md 3.5), so C5 is timed at the weight its tight goldens use (0.5) - the kernels' work does not depend on it
     w_guid = (0.5 if volsmpl else 2.0) if guided else 1.0
 
     def one_step(m=model):
@@ -523,7 +523,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
         n_skin = prof["skin_input"]["launches_per_call"]
         steps_per_skin = T / n_skin if n_skin else 0
         if n_skin and n_skin < T:      # deferred skinning: one launch covers steps_per_skin steps
-            hbm_entry("skin_input", f"skin_mfma_kernel (LBS skinning of {steps_per_skin:g} steps x {nb} bodies in one launch, DESIGN.md 3.7)",
+            hbm_entry("skin_input", f"skin_mfma_kernel (LBS skinning of {steps_per_skin:g} steps x {nb} bodies in one launch, docs/EXPERIMENTS.md 3.7)",
                       steps_per_skin * nb * (6890 * 3 * 4 + 21 * 3 * 4 + 24 * 12 * 4 + 2 * 224 * 2) + 19.3e6,
                       "per body-step 82,680 B vertices + extra joints + transforms + blend coefficients (SURVEY 8d) + SMPL constants 19.3 MB once per launch")
             hbm_entry("input", "gcn_input_kernel (hoisted input conv of the next step: rank-6 update + adjacency mix + BN + ReLU, split-f16 rows out)",
@@ -598,7 +598,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
                       "f16x3": "f32 results: denoiser GEMMs as 3x f16 MFMA on hi/lo-split operands (f32 accumulate) on the last "
                                f"{k_last} of {T} steps, plain f16 operands on the first {lowprec}; k = {k_last} is " +
                                ("given on the command line" if args.f16x3_last_steps is not None else "CALIBRATED on the loaded weights") +
-                               f" to a {model.schedule_tol:g} m bar (final bodies vs the all-split loop; the contract bar is 1e-4 m: leg schedule_at_contract_tol; DESIGN.md 3.6)",
+                               f" to a {model.schedule_tol:g} m bar (final bodies vs the all-split loop; the contract bar is 1e-4 m: leg schedule_at_contract_tol; docs/EXPERIMENTS.md 3.6)",
                       "f16": "f16 denoiser GEMMs and activations (f32 accumulate) + f32 everything else"}[args.precision],
             "data": "synthetic",
             "config": {"workload": desc, "name": workload, "items_per_gpu": B, "samples_per_item": S, "samples_in_one_loop": bool(S > 1), "collision_guided": guided, "denoising_steps": T,
@@ -664,7 +664,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-lbs-every-step", action="store_true")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
-                    help="arithmetic of the hidden GCN convs (DESIGN.md 3.2): f32 MFMA | split-f16 MFMA (f32-grade) | plain f16 (not parity-grade)")
+                    help="arithmetic of the hidden GCN convs (docs/EXPERIMENTS.md 3.2): f32 MFMA | split-f16 MFMA (f32-grade) | plain f16 (not parity-grade)")
     ap.add_argument("--weights", default="sensitive", choices=["sensitive", "insensitive"],
                     help="synthetic denoiser weights: 'sensitive' = trained-like (d x0 / d x_t follows the MMSE gain of a Gaussian prior, ~1 at low noise: "
                          "early rounding errors are CARRIED), 'insensitive' = the plain random network of rounds 1-2 (ignores x_t: errors are contracted)")

@@ -45,7 +45,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     objdir = os.path.join(_HERE, "build", os.path.basename(LIB_PATH) + "." + tag)
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    sources = SOURCES + (["gcn_wide.hip"] if "-DEHM_WITH_WIDE_TILE" in extra else [])     # experiment: the 96 x 64 (x 2) wave tile
+    sources = SOURCES + (["gcn_wide.hip"] if "-DEHM_WITH_WIDE_TILE" in extra else [])     # experiment: the 96 x 64 (x 2) wave tile (docs/EXPERIMENTS.md 3.2)
     for s in sources:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):

@@ -261,7 +261,7 @@ struct XFrags {
 // NU = 2: 192 x 128 tiles (96 x 64 per wave); NU = 1: 192 x 64 tiles (96 x 32 per wave) for Co = 64 layers (no padding columns through
 // the matrix cores).
 // HO ("hi only", ehm_conv_x2_desc.hi_only): the plain-f16 tier of the encoders (BASELINE config 5's fp16 tier; NOT parity grade: 0.4 - 1.4 mm of final
-// vertex) on the SAME buffers - only the hi halves of activations and weights are fetched (half of every 128-byte chunk: the lanes
+// vertex, docs/EXPERIMENTS.md 3.3) on the SAME buffers - only the hi halves of activations and weights are fetched (half of every 128-byte chunk: the lanes
 // of an operand piece that carry lo chunks are masked off), multiplied (one MFMA per product instead of three), and written; lo halves are don't-care.
 template <int NU, bool SK, bool DS = false, bool HO = false>
 __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {

@@ -1,4 +1,4 @@
-// The one-launch sampling loop (DESIGN.md 3.7 "Round 4b"): built, bit-equal to the per-step loop, measured 12 % SLOWER.  It is an experiment, not product:
+// The one-launch sampling loop (docs/EXPERIMENTS.md 3.7 "Round 4b"): built, bit-equal to the per-step loop, measured 12 % SLOWER.  It is an experiment, not product:
 // this file is compiled into gcn_tile.hip only under -DEHM_WITH_LOOP_ENGINE (EHM_HIPCC_FLAGS; the default build() does not set it), as are its host
 // half (gcn_loop_host.inc) and its test (tests/test_gpu_loop_engine.py).  Device half: structures, ticket arithmetic, the items that are not conv tiles.
 #pragma once

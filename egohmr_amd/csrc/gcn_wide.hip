@@ -2,7 +2,7 @@
 // (modulated_gcn_conv.py:39-50 + the residual of modulated_gcn.py:38-42), with half the operand traffic per matrix instruction.
 //
 // gcn_tile.hip's wave owns 96 rows x 32 channels (x 2 branches): 10 fragment reads and 10 one-KiB operand pieces per 36 MFMAs.  Its K loop is
-// bound by what it takes to FEED the matrix pipe - issuing the pieces holds the SIMD's issue for the partner wave too (the
+// bound by what it takes to FEED the matrix pipe - issuing the pieces holds the SIMD's issue for the partner wave too (docs/EXPERIMENTS.md 3.2: the
 // same schedule without an operand stream runs the pipe at 0.84 instead of 0.70).  Here a wave owns 96 rows x 64 channels (x 2 branches) =
 // 192 accumulator registers, a block (4 waves, 2 x 2) 192 rows x 128 channels, and a K tile is ONE 16-wide k-step (64 bytes per row: 16 hi
 // halves | 16 lo halves), so that two 28 KiB stages (A 12 KiB + B 16 KiB) still let two blocks share a CU:

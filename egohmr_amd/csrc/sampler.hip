@@ -251,7 +251,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   EHM_CHECK_ARG(nh % 2 == 0);
 #ifndef EHM_WITH_LOOP_ENGINE
   if (d->loop_engine) {
-    ehm_set_error("ehm_sample_desc.loop_engine = 1, but this library was built without -DEHM_WITH_LOOP_ENGINE (the one-launch loop is an experiment, DESIGN.md 3.7)");
+    ehm_set_error("ehm_sample_desc.loop_engine = 1, but this library was built without -DEHM_WITH_LOOP_ENGINE (the one-launch loop is an experiment, docs/EXPERIMENTS.md 3.7)");
     return EHM_EINVAL;
   }
 #endif

@@ -248,7 +248,7 @@ class ResnetPointnet(nn.Module):
     """models/respointnet.py:33-59: per-point MLP with three global max-pool-concat stages -> [B,out_dim].
 
     Parameters keep the reference's names; the arithmetic runs on the split-f16 matrix-core kernels of
-    csrc/linear.hip (f32-grade) with the per-body constant half of every block input folded
+    csrc/linear.hip (f32-grade, see docs/EXPERIMENTS.md 3.3) with the per-body constant half of every block input folded
     into bias vectors, fc_1 + shortcut fused into one dual-source GEMM and the max-pool fused into its epilogue."""
 
     hi_only = False      # True: the plain-f16 tier (ehm_linear_desc.hi_only) - NOT parity grade

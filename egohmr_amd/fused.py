@@ -3,7 +3,7 @@
 the per-checkpoint precision-schedule calibration (`calibrate_schedule`).
 
 Reference code this replaces on the hot path: diffusion/gaussian_diffusion.py:391-508 / :618-718 (the loops) driving
-models/egohmr/egohmr.py:173-303 (forward) and :517-570 (guide_coll); see DESIGN.md sections 1 and 3.
+models/egohmr/egohmr.py:173-303 (forward) and :517-570 (guide_coll); see DESIGN.md sections 2 and 4.
 """
 from __future__ import annotations
 
@@ -469,7 +469,7 @@ class FusedSampler:
         """How many LEADING steps of a T-step fused loop run on plain f16 operands (EgoHMR.f16x3_last_steps): None -> 0 (every step
         f32-grade), an int k -> T - k (the caller vouches for it), 'auto' -> T - k for the k that `calibrate_schedule` measured for
         `key` (= schedule_key(...)) on the LOADED weights, and 0 when there is no calibration for it.  There is no constant policy
-        any more: a k tuned on one network says nothing about another."""
+        any more: a k tuned on one network says nothing about another (docs/EXPERIMENTS.md 3.6)."""
         k = self.model.f16x3_last_steps
         if k is None or self.model.gcn_precision != "f16x3":
             return 0
@@ -717,13 +717,13 @@ class FusedSampler:
                 self.schedule_info = self._sched_cache.get(skey)
             lowprec = self.lowprec_steps(T, n_guided, ddim, key=skey)
         self.last_lowprec = int(lowprec)                  # leading steps of THIS call on plain f16 operands
-        # the one-launch loop (ehm_sample_desc.loop_engine) runs every item through both passes; exact pass pruning only pays
+        # the one-launch loop (ehm_sample_desc.loop_engine, docs/EXPERIMENTS.md 3.7) runs every item through both passes; exact pass pruning only pays
         # more than it when a sizeable share of the items has every joint visible
         engine = (bool(m.loop_engine) and not nonlocal_ci and B % 8 == 0 and B >= 24 and m.gcn_precision == "f16x3"
                   and not (passes == 2 and m.prune_passes and st.num_masked < m.loop_engine_min_masked * B))
         if m.loop_engine and "loop_engine" not in _lib.build_features():
             raise _lib.EgoHMRHipError("EgoHMR.loop_engine = True needs a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_LOOP_ENGINE "
-                                      "(the one-launch loop is an experiment that the default build leaves out, DESIGN.md 3.7)")
+                                      "(the one-launch loop is an experiment that the default build leaves out, docs/EXPERIMENTS.md 3.7)")
         self.last_engine = bool(engine)                   # (runs of >= 2 unguided steps of this call go through the one-launch loop)
         if engine:
             _lib.check(L.ehm_gcn_set_pass_map(self.gcn(), None, None, -1), "ehm_gcn_set_pass_map")

@@ -207,7 +207,7 @@ class EgoHMR(nn.Module):
         self.guide_denom_override = None       # sharded / sub-batch runs: the GLOBAL batch size of `-loss.mean()`, else None
         self.guide_all_points = False          # COAP variant: bbox-selected scene points (egohmr.py:550-552); True = all points (egohmr_volsmpl.py:609-612)
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
-        # EXPERIMENT (measured 12 % slower): runs of unguided steps as ONE persistent launch.  Only a library built with
+        # EXPERIMENT (docs/EXPERIMENTS.md 3.7, measured 12 % slower): runs of unguided steps as ONE persistent launch.  Only a library built with
         # EHM_HIPCC_FLAGS=-DEHM_WITH_LOOP_ENGINE has it; on the default build True raises (FusedSampler.run)
         self.loop_engine = False
         self.loop_engine_min_masked = 0.85
@@ -219,9 +219,9 @@ class EgoHMR(nn.Module):
         # arithmetic of the hidden GCN convs: 'f32' (f32-input MFMA), 'f16x3' (split-f16 MFMA, f32-grade), 'f16' (plain f16, not parity-grade)
         self.gcn_precision = "f16x3"
         # arithmetic of the two conditioning encoders: 'f16x3' (split-f16, f32 grade - the parity path) | 'f16' (plain f16 operands and activations: the
-        # encoders of BASELINE config 5's fp16 TIER, together with gcn_precision = 'f16'; NOT parity grade: 0.4 - 1.4 mm of final vertex)
+        # encoders of BASELINE config 5's fp16 TIER, together with gcn_precision = 'f16'; NOT parity grade: 0.4 - 1.4 mm of final vertex, docs/EXPERIMENTS.md 3.3)
         self.encoder_precision = "f16x3"
-        # precision schedule: only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'), the
+        # precision schedule (docs/EXPERIMENTS.md 3.6): only the LAST k executed steps of a fused sampling loop run in gcn_precision ('f16x3'), the
         # earlier ones on plain f16 operands / f16 activations.  'auto' = the k that FusedSampler.calibrate_schedule MEASURED for the
         # loaded weights and the sampler in use (smallest k whose bodies stay within schedule_tol of the all-f16x3 loop; measured on the
         # first call per (weights, sampler) when auto_calibrate is on, else every step stays f16x3); an int = that k, on the caller's
@@ -357,7 +357,7 @@ class EgoHMRVolsmpl(EgoHMR):
                                     selection), gradient of `-loss.sum()` (no 1/B factor); default guidance weight 30 (test_egohmr_volsmpl.py:62)
       eval_coll_volsmpl   :548-579  per item, bbox-selected points with `volume.query_fast(...) < 0` over N
       eval_coll           :519-546  the COAP metric, kept (the reference keeps COAP attached for training)
-    VolumetricSMPL is a learned SDF that cannot be obtained offline: the collision term is the build's proxy,
+    VolumetricSMPL is a learned SDF that cannot be obtained offline: the collision term is the build's proxy (docs/EXPERIMENTS.md 3.5),
     with `sdf < 0` read as `distance to the surface < tau`.  Numbers from it are NOT VolumetricSMPL numbers."""
 
     DEFAULT_COND_GRAD_WEIGHT = 30.0            # test_egohmr_volsmpl.py:62

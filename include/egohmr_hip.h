@@ -104,7 +104,7 @@ int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_params* inpu
                    int hid_dim, void* stream);
 void ehm_gcn_destroy(ehm_gcn* h);
 
-/* Arithmetic of the hidden convs.  0 = f32-input MFMA (exact f32 products; what a fresh handle is in);
+/* Arithmetic of the hidden convs (docs/EXPERIMENTS.md 3.2).  0 = f32-input MFMA (exact f32 products; what a fresh handle is in);
  * 1 = "f16x3": f16 MFMA on hi/lo-split operands, three products per term, f32 accumulate (22-bit operands,
  * f32-grade results); 2 = plain f16 operands and f16 activation storage (NOT parity-grade on its own - BASELINE config 5's
  * fp16 denoiser, and the early steps of ehm_sample_desc.lowprec_steps).
@@ -415,11 +415,11 @@ typedef struct {
   int num_masked;     /* second passes after pruning = what ehm_gcn_set_pass_map was given; -1 = no map (B)   */
   int guide_all_points; /* 1 = VolSMPL-style guidance over ALL scene points (egohmr_volsmpl.py:609-612), 0 = bbox-selected (egohmr.py:550-552) */
   int lowprec_steps;  /* precision schedule: the FIRST lowprec_steps executed steps run the hidden convs on plain f16 operands
-                         (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  DESIGN.md 3.6  */
+                         (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  docs/EXPERIMENTS.md 3.6  */
   int nonlocal_ci;    /* inter_channels of the non-local block set with ehm_gcn_set_nonlocal, 0 = none (needs float32 features:
                          handle mode 0 or 1 and lowprec_steps == 0)                                                              */
   int loop_engine;    /* EXPERIMENT, off in the default build: 1 = runs of consecutive unguided steps execute as ONE persistent launch (bit-equal,
-                         measured 12 % slower).  Only a library built with -DEHM_WITH_LOOP_ENGINE accepts 1; the default one
+                         measured 12 % slower, docs/EXPERIMENTS.md 3.7).  Only a library built with -DEHM_WITH_LOOP_ENGINE accepts 1; the default one
                          returns EHM_EINVAL.  Shape limits: B % 8 == 0, B >= 24, no pass map, split-f16 mode, no non-local block                */
   int per_step_launches; /* 0 (default) = two launches per step: chained hidden convs, then step_fused_kernel (output responses + per-body
                          update + the next step's input conv); 1 = the separate launches of rounds 2-3 (input conv, chain, responses, per-body

@@ -477,7 +477,7 @@ def g16_sensitive_denoiser(asset, mean, std):
 
 def g17_partially_sensitive_denoiser(asset, mean, std):
     """A denoiser between the two synthetic weight sets: low-noise gain d x0 / d x_t = 0.3 (make_sensitive_state_dict(gain=0.3)), for which the
-    product's calibration picks a schedule with 0 < k < T (k = 36 of 100 at a 1e-5 m bar).  The reference's own DDPM-100 loop on it
+    product's calibration picks a schedule with 0 < k < T (docs/EXPERIMENTS.md 3.6: k = 36 of 100 at a 1e-5 m bar).  The reference's own DDPM-100 loop on it
     gates a MIXED plain-f16 / split-f16 loop by the reference, not only by the product's own all-split loop."""
     from diffusion.model_util import create_gaussian_diffusion
     n, gain = 100, 0.3

@@ -224,7 +224,7 @@ def test_hidden_stack_chain_tile_shapes(L, dev, hid, bodies, prec):
 @pytest.mark.parametrize("hid,bodies", [(256, 33), (1024, 40)])
 def test_wide_wave_tile_experiment_is_bit_equal(L, dev, hid, bodies, monkeypatch):
     """csrc/gcn_wide.hip (96 x 64 (x 2) wave tile, 16-k K tiles: 14 fragment reads and 7 operand pieces per 36 MFMAs instead of 20 and 10) is an
-    EXPERIMENT - measured equal to the shipped tile, DESIGN.md 3.2 - that only a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_WIDE_TILE contains;
+    EXPERIMENT - measured equal to the shipped tile, docs/EXPERIMENTS.md 3.2 - that only a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_WIDE_TILE contains;
     there, a handle created under EHM_GCN_WIDE=1 runs it for the per-conv launches, which must reproduce the chained launch bit for bit."""
     from egohmr_amd import _lib
     if "wide_tile" not in _lib.build_features():

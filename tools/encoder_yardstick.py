@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The vendor libraries on the two step-invariant encoders at the benchmark shape (B = 256 images 224 x 224, 256 x 4096 scene points): eager PyTorch =
 MIOpen convolutions / hipBLASLt GEMMs, in float32 (the precision class the repository's split-f16 kernels deliver) and under float16 autocast (NOT a parity
-path: a cost reference), against `ResNet50Features.folded()` / `ResnetPointnet.forward` of this package.  
+path: a cost reference), against `ResNet50Features.folded()` / `ResnetPointnet.forward` of this package.  (docs/EXPERIMENTS.md 3.3 / 3.4)
 
     MIOPEN_FIND_MODE=FAST python tools/encoder_yardstick.py
 """

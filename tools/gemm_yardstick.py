@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The vendor library on the hidden conv's GEMM: what does hipBLASLt (through torch.matmul, f16 inputs, f32 accumulate) sustain on
 [rows = 12288, K = 1024] x [1024, 2 x 1024] - the two branches of one f16 hidden conv at B = 256 x 2 passes - on relu-like activations, with NO
-epilogue (no adjacency mix, BN, ReLU, residual, no f16 conversion of the result)?  The yardstick for gcn_hidden_chain_kernel<1, 8>.
+epilogue (no adjacency mix, BN, ReLU, residual, no f16 conversion of the result)?  The yardstick for gcn_hidden_chain_kernel<1, 8> (docs/EXPERIMENTS.md 3.2).
 
     python tools/gemm_yardstick.py [seconds]
 """

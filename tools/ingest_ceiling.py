@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-CU operand-ingest ceiling of an MI355X from L2: bytes per clock through global_load_lds (plain / sc1), through global_load_dwordx4
 into registers, and through both alternating - with nothing else running (tools/ingest_ceiling.hip).  The chained conv kernels stage
-80 KiB (split-f16) / 56 KiB (f16) per K tile and CU and are measured at 24-26 B/clk; this is what the path can do alone.
+80 KiB (split-f16) / 56 KiB (f16) per K tile and CU and are measured at 24-26 B/clk (docs/EXPERIMENTS.md 3.2); this is what the path can do alone.
 
     python tools/ingest_ceiling.py            -> one JSON line per mode
 """

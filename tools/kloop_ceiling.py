@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What does the split-f16 K loop's STRUCTURE sustain, with no epilogue at all?  (tools/simd_overlap.hip)
+"""What does the split-f16 K loop's STRUCTURE sustain, with no epilogue at all?  (tools/simd_overlap.hip; docs/EXPERIMENTS.md 3.2)
 One MFMA wave per SIMD (36 MFMAs + 20 fragment reads per K tile = the conv's wave tile) beside one loader wave per SIMD (10 pieces of 1 KiB per
 K tile = the conv's operand stream), each configuration looped for 3 s (the numbers are sustained ones, taken from the second half), with the
 pieces coming from a 2 MiB window (every piece an L2 hit) or a 64 MiB one (every piece an L2 miss served by the MALL).  Prints one JSON line each.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Can the second wave of a SIMD stage operands while the first one issues MFMAs?  (tools/simd_overlap.hip)
+"""Can the second wave of a SIMD stage operands while the first one issues MFMAs?  (tools/simd_overlap.hip; docs/EXPERIMENTS.md 3.2)
 Per iteration: compute waves 36 MFMAs (= one split-f16 K tile of a wave, 1152 matrix cycles per SIMD), loader waves P pieces of 1 KiB.
 Prints cycles per iteration (at the SMU's clock, whatever it is: ratios are what matters) for compute alone, loader alone, both.
 

@@ -3,7 +3,7 @@
 //   P = 3  "f16x3": both GEMM operands stored as hi + lo f16 pairs (X2<32>, gcn_dev.h), three v_mfma_f32_32x32x16_f16 per
 //          product (lo*hi + hi*lo + hi*hi), f32 accumulate: 22-bit operands, f32-grade results (the parity path);
 //   P = 1  "f16":   plain f16 storage [rows][hid] and one MFMA per product (BASELINE config 5's fp16 denoiser, and the early
-//          steps of the precision schedule, docs/EXPERIMENTS.md 3.6).
+//          steps of the precision schedule).
 // Tile = 192 rows (8 bodies x 24 joints) x 64 channels x both branches (W0 | W1); 4 waves as 2 x 2, 96 x 32(x2) per wave;
 // operands stream L2 -> LDS with 16-byte global_load_lds DMA, one K tile = 128 bytes per row (64 k in f16, 32 k hi|lo in X2),
 // two 40 KiB stages, XOR-swizzled on the source address so every ds_read_b128 fragment read is bank-conflict free; register
@@ -108,7 +108,7 @@ __device__ __forceinline__ const float* layer_weights(const LayerDev& L) {
 // completion counters (see the header of ehm_gcn_tile_chain_impl); CHAIN = false: one tile per block, one conv per launch.
 // NW = waves per block.  4: 192 rows x 64 channels per block, two blocks per CU.  8 (f16 chain only): ONE block per CU owns 192 rows x 128
 // channels - the activation tile is staged once for both channel halves, 56 KiB instead of 80 KiB of operands per K tile and CU; with
-// one MFMA per product the K loop is bound by LDS bandwidth (writes + fragment reads), see docs/EXPERIMENTS.md 3.2.
+// one MFMA per product the K loop is bound by LDS bandwidth (writes + fragment reads), see DESIGN.md 3.2.
 
 #ifdef EHM_WITH_LOOP_ENGINE
 #include "gcn_loop_dev.h"
@@ -167,7 +167,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
   // operand stream addressing: buffer form - a tile's base in an SGPR descriptor, the lane's row / chunk in ONE 32-bit VGPR offset that is
   // the same for every piece of the tile, the piece (rows + K tile) in the scalar offset: no vector-ALU address arithmetic in the K loop
   // (with 64-bit global pointers every piece cost two v_add: 20 VALU per K tile and wave, and VALU issue is time the matrix pipe of the
-  // SIMD does not get, docs/EXPERIMENTS.md 3.2)
+  // SIMD does not get)
   __amdgpu_buffer_rsrc_t rsA, rsB;
   int voAB;
   auto io_of = [&](const Tile& t) -> TileIO {

@@ -64,6 +64,11 @@ def build(verbose: bool = False, force: bool = False) -> str:
         for (src, _), r in zip(jobs, ex.map(compile_one, jobs)):
             if r.returncode != 0:
                 raise EgoHMRHipError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+            if "failed to meet occupancy target" in r.stderr:
+                # __launch_bounds__(256, 2) is a wish, not a limit: a kernel that lost its second block per CU still compiles (with this warning) and
+                # every test stays green at half the speed - the host-side plans count on the occupancy, so treat it as a build error
+                os.remove(os.path.join(objdir, os.path.basename(src).replace(".hip", ".o")))
+                raise EgoHMRHipError(f"hipcc: a kernel of {src} missed its occupancy target:\n{r.stderr}")
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -244,6 +244,8 @@ struct ConvX2Args {
   unsigned int* sk_flags;      // [tiles], zeroed by ehm_conv_x2
   float* sk_part;              // [tiles][kSkMaxParts][acc floats per thread][256]
   int sk_per;                  // pairs of K tiles per block
+  int sk_rounds;               // whole tiles first: rounds [0, sk_rounds) of the grid run one whole tile per block (the plain schedule), only the tiles BEHIND them - the
+                               // last, partly filled round: e.g. 12 of 524 tiles on 512 slots - are dealt out as K runs (0: every tile is, the long-K plan)
   // second K segment (DS = true): a 1 x 1 convolution of ANOTHER tensor x2 [N, H2, W2, Ci2] with stride stride2, accumulated into the same
   // output - a bottleneck's projection shortcut inside its last conv (torchvision Bottleneck.forward: out = conv3(.) + downsample(x)): the
   // weights are [W | W2] along K, the K tiles past the first segment gather x2's pixels (2 stride2 ho, stride2 wo)
@@ -252,6 +254,7 @@ struct ConvX2Args {
   unsigned int zero_off2;
 };
 constexpr int kSkMaxParts = 3;
+constexpr int kSkHandoffKTiles = 14;   // what a cut tile's hand-off costs, in K-tile times (measured, see sk_plan)
 
 template <int NU>
 struct XFrags {
@@ -265,7 +268,6 @@ struct XFrags {
 // of an operand piece that carry lo chunks are masked off), multiplied (one MFMA per product instead of three), and written; lo halves are don't-care.
 template <int NU, bool SK, bool DS = false, bool HO = false>
 __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
-  static_assert(!(SK && DS), "the dual-source conv runs whole tiles");
   constexpr int XBN = 64 * NU, XSTG = x_stage_floats(NU);
   __shared__ __attribute__((aligned(16))) float lds[2 * XSTG];   // 80 / 64 KiB; the ONLY LDS object
   // MODE.FP16_OVFL = 1 for the life of the wave: every f32 -> f16 conversion of the epilogue clamps to +-65504 instead of producing inf - the
@@ -450,19 +452,25 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   struct Piece { int m, n, k0, k1, tile; };
   const int P2 = KT / 2;                                         // pairs of K tiles per tile (stream-K deals in pairs: every piece has >= 2 K tiles)
   long long sk_cur = 0, sk_end = 0;
+  [[maybe_unused]] int sk_t0 = 0;                                // first tile (linear index m * n_tiles + n) of the K-run part
   if constexpr (SK) {
-    const long long U2 = (long long)m_tiles * n_tiles * P2;
+    sk_t0 = p.sk_rounds * G;                                     // (round `it` of tile_of covers the linear tiles [it G, (it + 1) G) in either block order)
+    const long long U2 = ((long long)m_tiles * n_tiles - sk_t0) * P2;
     sk_cur = (long long)b * p.sk_per;
     sk_end = sk_cur + p.sk_per < U2 ? sk_cur + p.sk_per : U2;
   }
   auto piece_of = [&](int it, Piece& o) -> bool {
     if constexpr (SK) {
+      if (it < p.sk_rounds) {                                    // a whole tile of the plain schedule (tile = -1: no hand-off)
+        o.k0 = 0; o.k1 = KT; o.tile = -1;
+        return tile_of(it, o.m, o.n);
+      }
       if (sk_cur >= sk_end) return false;
-      o.tile = (int)(sk_cur / P2);
+      o.tile = (int)(sk_cur / P2);                               // (index within the K-run part: flags and partial sums are kept per such tile)
       const int kp0 = (int)(sk_cur % P2);
       const long long left = sk_end - sk_cur;
       const int kp1 = left < P2 - kp0 ? kp0 + (int)left : P2;
-      o.m = o.tile / n_tiles; o.n = o.tile % n_tiles;
+      o.m = (sk_t0 + o.tile) / n_tiles; o.n = (sk_t0 + o.tile) % n_tiles;
       o.k0 = 2 * kp0; o.k1 = 2 * kp1;
       return true;
     } else {
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
       return tile_of(it, o.m, o.n);
     }
   };
-  auto advance = [&](const Piece& o) { if constexpr (SK) sk_cur += (o.k1 - o.k0) / 2; };
+  auto advance = [&](const Piece& o) { if constexpr (SK) { if (o.tile >= 0) sk_cur += (o.k1 - o.k0) / 2; } };
   int it = 0;
   Piece pc;
   if (!piece_of(0, pc)) return;
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     // ---- stream-K hand-off.  A piece that does not start its tile leaves its accumulators for the block that does; the block that starts a
     //      tile (always the LAST piece of its run) collects the later pieces - they were the FIRST pieces of their blocks' runs - in k order.
     bool finish = true;
-    if constexpr (SK) {
+    if (SK && pc.tile >= 0) {
       constexpr int NACC = 3 * NU * 16;
       const int owner = (int)(((long long)pc.tile * P2) / p.sk_per), last_blk = (int)(((long long)pc.tile * P2 + P2 - 1) / p.sk_per);
       float* part = p.sk_part + (size_t)pc.tile * kSkMaxParts * NACC * 256;
@@ -570,23 +578,23 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
           __hip_atomic_fetch_add(p.sk_flags + pc.tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       } else if (last_blk > owner) {
-        int gave_up = 0;
+        const unsigned int expect = (unsigned int)(last_blk - owner);
         if (tid == 0) {
           int spins = 0;
-          while (__hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(last_blk - owner) && ++spins < (1 << 24))
+          while (__hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect && ++spins < (1 << 24))
             __builtin_amdgcn_s_sleep(2);
-          gave_up = spins >= (1 << 24);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
+        __syncthreads();
         // never hang the device - but never hand out a sum with a missing K range either: a tile whose partners did not arrive in ~1 s (a
-        // preempted / shared GPU) comes out as NaN, which the callers' finite checks and every downstream consumer make loud
-        if (__syncthreads_or(gave_up)) {
+        // preempted / shared GPU) comes out as NaN, which the callers' finite checks and every downstream consumer make loud.  Every thread
+        // looks at the (monotonic) counter itself and poisons through the bias term (every output is acc * inv_scale + add): __syncthreads_or
+        // brings its own LDS word, and with 80 KiB + 4 bytes the kernel lost its second block per CU (hipcc then spent 183 VGPRs + 96 AGPRs);
+        // writing NaN into the 96 accumulators has the same effect on the register budget.
+        const bool missing = __hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (missing) {
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[t][u][r] = __builtin_nanf("");
+          for (int u = 0; u < NU; ++u) add[u] = __builtin_nanf("");
         }
         for (int q = 0; q < last_blk - owner; ++q) {
           const float* theirs = part + (size_t)q * NACC * 256 + tid;
@@ -725,27 +733,47 @@ extern "C" int ehm_conv_nhwc_split(const ehm_conv_desc* d, void* stream) {
 extern "C" int64_t ehm_conv_x2_rows(int64_t pixels) { return round_up(pixels, XBM) + 1; }
 
 namespace {
-// stream-K plan of a conv: used when whole tiles would leave more than ~1/8 of the block slots idle in the last round (e.g. 524 tiles on
-// 512 slots: two rounds for 1.02 rounds of work) and the K loop is long enough to deal out in runs
-struct SkPlan { bool on; int per; int64_t tiles, flag_bytes, bytes; int nacc; };
+// stream-K plans of a conv (whole tiles only: the last round of the grid is as long as a full one however few tiles it holds - 524 tiles on 512
+// slots are two rounds for 1.02 rounds of work, and at N = 256 images most of ResNet-50's layers 2 - 4 land just above a multiple of the slots):
+//  * rounds = 0, "every tile": the K tiles of ALL tiles are one sequence dealt out in equal runs - for K loops of >= 64 K tiles whose tile count is
+//    below one round (layer 4) or just above it (the 3 x 3 convs of layer 3); with shorter K loops nearly every tile would be cut and the 96 KiB
+//    partial-sum hand-off of a cut tile costs more than the idle slots (measured: 1 x 1 convs 0.14 -> 0.175 ms);
+//  * rounds = R >= 1, "tail only": R whole rounds run the plain schedule, only the L < slots tiles behind them are cut, into <= kSkMaxParts runs each,
+//    so that the last round lasts a third of a K loop + one hand-off instead of a whole K loop.
+struct SkPlan { bool on; int per, rounds; int64_t tiles, cut_tiles, blocks, flag_bytes, bytes; int nacc; };
 SkPlan sk_plan(const ehm_conv_x2_desc* d, int Ho, int Wo) {
   SkPlan s{};
   const int64_t M = (int64_t)d->N * Ho * Wo, slots = 2 * (int64_t)ehm_num_cus();
   const bool narrow = d->Co % 128 != 0;
-  const int KT = d->KH * d->KW * (d->Ci / XRK);
+  const int KT = d->KH * d->KW * (d->Ci / XRK) + (d->x2 != nullptr ? d->Ci2 / XRK : 0);
   s.tiles = ceil_div(M, XBM) * ceil_div(d->Co, narrow ? 64 : 128);
   s.nacc = 3 * (narrow ? 1 : 2) * 16;
+  if (KT % 2 != 0 || KT < 4) return s;
+  const int P2 = KT / 2;
+  const int64_t R = s.tiles / slots, L = s.tiles - R * slots;
   const int64_t rounds = ceil_div(s.tiles, slots);
   const double eff = (double)s.tiles / (double)(rounds * slots);
-  // (K loops shorter than 64 K tiles: measured slower - the 96 KiB partial-sum hand-off of a cut tile costs more than the idle slots)
-  if (d->x2 != nullptr || KT % 2 != 0 || KT < 64 || eff >= 0.875 || s.tiles < slots / 2) return s;
-  const int P2 = KT / 2;
-  const int64_t U2 = s.tiles * P2;
-  s.per = (int)ceil_div(U2, slots);
-  if (s.per < 2 || ceil_div(P2, s.per) > kSkMaxParts) return s;
+  if (KT >= 64 && d->x2 == nullptr && eff < 0.875 && s.tiles >= slots / 2 && R <= 1) {          // every tile
+    s.per = (int)ceil_div(s.tiles * P2, slots);
+    if (s.per < 2 || ceil_div(P2, s.per) > kSkMaxParts) return s;
+    s.rounds = 0; s.cut_tiles = s.tiles;
+    s.blocks = ceil_div(s.tiles * P2, (int64_t)s.per);
+  } else if (R >= 1 && L > 0) {                                                                    // tail only
+    const int64_t parts = std::min<int64_t>(std::min<int64_t>(kSkMaxParts, slots / L), P2);
+    if (parts < 2) return s;
+    s.per = (int)ceil_div(P2, parts);
+    // worth it when the cut tail - its K run + the hand-off - is shorter than a whole K loop.  Measured per conv at N = 256 (tools/enc_layers.py, same box,
+    // against whole tiles): K loops of 32 / 36 K tiles gain 13 - 19 us (5 x layer 3 c1 0.121 -> 0.102 ms, layer 2's 3 x 3 convs 0.210 -> 0.196), K loops of 16 / 18
+    // K tiles LOSE 10 - 28 us: the hand-off (partial sums out, agent-scope release / acquire, partial sums in) costs about 14 K tiles' time
+    if (2 * s.per + kSkHandoffKTiles > KT - 2 || ceil_div(P2, s.per) > kSkMaxParts) return s;
+    s.rounds = (int)R; s.cut_tiles = L;
+    s.blocks = slots;
+  } else {
+    return s;
+  }
   s.on = true;
-  s.flag_bytes = round_up(s.tiles * 4, 256);
-  s.bytes = s.flag_bytes + s.tiles * kSkMaxParts * s.nacc * 256 * 4;
+  s.flag_bytes = round_up(s.cut_tiles * 4, 256);
+  s.bytes = s.flag_bytes + s.cut_tiles * kSkMaxParts * s.nacc * 256 * 4;
   return s;
 }
 }  // namespace
@@ -797,19 +825,23 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   const bool narrow = d->Co % 128 != 0;
   const int64_t tiles = ceil_div(a.M, XBM) * ceil_div(d->Co, narrow ? 64 : 128);
   const SkPlan sk = sk_plan(d, Ho, Wo);
-  a.sk_flags = nullptr; a.sk_part = nullptr; a.sk_per = 0;
+  a.sk_flags = nullptr; a.sk_part = nullptr; a.sk_per = 0; a.sk_rounds = 0;
   if (sk.on && d->workspace && d->workspace_bytes >= sk.bytes) {
-    // stream-K: every slot gets the same number of K tiles; a tile cut by a run boundary is finished by the block that started it
+    // stream-K (every tile, or the tail round only): a tile cut by a run boundary is finished by the block that started it
     a.sk_flags = (unsigned int*)d->workspace;
     a.sk_part = (float*)((char*)d->workspace + sk.flag_bytes);
     a.sk_per = sk.per;
+    a.sk_rounds = sk.rounds;
     EHM_HIP(hipMemsetAsync(a.sk_flags, 0, (size_t)sk.flag_bytes, (hipStream_t)stream));
-    const int64_t blocks = ceil_div(tiles * (d->KH * d->KW * (d->Ci / XRK) / 2), (int64_t)sk.per);
+    const dim3 grid((unsigned)sk.blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
     if (d->hi_only) {
-      if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    } else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+      if (dual) hipLaunchKernelGGL((conv_x2_tile_kernel<2, true, true, true>), grid, blk, 0, st, a);
+      else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true, false, true>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true, false, true>), grid, blk, 0, st, a);
+    } else if (dual) hipLaunchKernelGGL((conv_x2_tile_kernel<2, true, true>), grid, blk, 0, st, a);
+    else if (narrow) hipLaunchKernelGGL((conv_x2_tile_kernel<1, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_x2_tile_kernel<2, true>), grid, blk, 0, st, a);
     EHM_LAUNCH_CHECK();
     return 0;
   }

@@ -559,6 +559,8 @@ def test_skinny_gemm_f32_vs_torch_fp64(dev, shape):
     (18, 56, 56, 256, 128, 3, 1, True, True),  # 294 tiles on 512 block slots, 72 K tiles: the STREAM-K schedule (K tiles dealt out in runs, tiles cut by a run boundary summed in k order)
     (5, 56, 56, 64, 64, 3, 1, False, True),    # the same with 64-wide column tiles (Co = 64): 82 row tiles x 1 ... whole tiles (too few for stream-K)
     (40, 28, 28, 128, 64, 1, 1, True, False),  # stream-K with the narrow tile: 164 x 1 ... whole tiles; kept as a shape check
+    (256, 14, 14, 1024, 256, 1, 1, True, True),  # layer 3's first conv: 524 tiles on 512 slots, 32 K tiles: one whole round, then the 12 tiles behind it cut into three K runs each (TAIL-ONLY stream-K)
+    (130, 28, 28, 128, 128, 3, 1, False, True),  # 531 tiles, 36 K tiles (3 x 3): tail of 19 tiles, runs that straddle tile boundaries
 ])
 def test_conv_x2_vs_torch_fp64(dev, case):
     """ehm_conv_x2 (torchvision Bottleneck convs on X2 activations, models/resnet.py:139-150 via egohmr.py:183) against torch float64
@@ -604,7 +606,7 @@ def test_conv_x2_vs_torch_fp64(dev, case):
     d = _lib.ConvX2Desc(xd.data_ptr(), xd.shape[0], wbuf.data_ptr(), bd.data_ptr(), rd.data_ptr() if has_res else None, y.data_ptr(),
                         N, H, W, Ci, Co, k, k, stride, pad, int(relu), scale, None, 0)
     need = int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))
-    assert (need > 0) == (case[0] == 18), need                    # only the 294-tile case qualifies for stream-K
+    assert (need > 0) == (case[0] in (18, 256, 130)), need        # the 294-tile case (every tile cut) and the two just-over-one-round cases (tail only)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     if need:
         d.workspace, d.workspace_bytes = ws.data_ptr(), need
@@ -627,6 +629,7 @@ def test_conv_x2_vs_torch_fp64(dev, case):
     (3, 56, 56, 64, 64, 1, 256),       # layer 1 block 0: shortcut on the same grid
     (3, 28, 28, 128, 256, 2, 512),     # layer 2 block 0: the shortcut samples every second pixel of a 56 x 56 input
     (5, 7, 7, 512, 1024, 2, 2048),     # layer 4 block 0: ragged row tile (245 rows), odd input size 13 -> (13 - 1) / 2 + 1 = 7
+    (130, 7, 7, 512, 1024, 2, 2048),   # the same at 544 tiles on 512 slots: one whole round + the tail's 32 tiles cut into K runs across BOTH K segments
 ])
 def test_conv_x2_projection_shortcut_inside_the_last_conv(dev, case):
     """ehm_conv_x2 with the second K segment (ehm_conv_x2_desc.x2): relu(conv1x1(h) + b3 + conv1x1_stride(x) + bd) - torchvision
@@ -674,7 +677,11 @@ def test_conv_x2_projection_shortcut_inside_the_last_conv(dev, case):
     y = torch.full((rows_out, Co), float("nan"), device=dev)
     d = _lib.ConvX2Desc(hd.data_ptr(), hd.shape[0], wcat.data_ptr(), bsum.data_ptr(), None, y.data_ptr(), N, Ho, Wo, Ci, Co, 1, 1, 1, 0, 1, 256.0, None, 0)
     d.x2, d.x2_rows, d.H2, d.W2, d.Ci2, d.stride2 = xd.data_ptr(), xd.shape[0], H2, W2, Ci2, s2
-    assert int(L.ehm_conv_x2_workspace_bytes(C.byref(d))) == 0
+    need = int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))
+    assert (need > 0) == (N == 130), need
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    if need:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
     _lib.check(L.ehm_conv_x2(C.byref(d), None), "ehm_conv_x2")
     got = unpack(y)
     err = (got - ref).abs().max().item()
@@ -688,7 +695,8 @@ def test_conv_x2_projection_shortcut_inside_the_last_conv(dev, case):
     _lib.check(L.ehm_conv_x2(C.byref(d2), None), "ehm_conv_x2")
     two = unpack(y2)
     print(f"[conv_x2 shortcut {case}] max|err| vs fp64 = {err:.3e}, two launches: {(two - ref).abs().max().item():.3e}")
-    assert err < 1e-5 and (two - got).abs().max().item() < 1e-5
+    tol = 1e-5 if N < 100 else 2.5e-5                            # (13 M outputs of a K = 1536 sum in the big case: the float32-grade tail is longer)
+    assert err < tol and (two - got).abs().max().item() < tol
     d.H2 += 2                                                    # a shortcut grid that does not map onto the output grid is refused
     assert L.ehm_conv_x2(C.byref(d), None) != 0
     d.H2 -= 2

@@ -390,7 +390,9 @@ __device__ __forceinline__ void skin_mfma_body(float (*sA)[kJ][12], int bid, con
   SSTAMP(3);
 }
 
-__global__ __launch_bounds__(256) void skin_mfma_kernel(SkinArgs a) {
+// (four blocks per CU - 128 registers, 36 KiB of LDS each: the kernel is a chain of L2 round trips per block, and with hipcc's own choice of 168 VGPRs + 48 AGPRs
+//  only two were resident.  Same box: 1.40 -> 1.29 ms per 100 steps at 256 bodies, 8.55 -> 7.81 ms at 1280; three blocks measured like two)
+__global__ __launch_bounds__(256, 4) void skin_mfma_kernel(SkinArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[32][kJ][12];
   skin_mfma_body(sA, blockIdx.x, a);
 }

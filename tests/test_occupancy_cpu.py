@@ -96,3 +96,10 @@ def test_per_body_step_kernels_do_not_spill(kernels):
             # (the 512-thread form - more bodies than CUs - keeps a dozen spilled dwords at its 128-register cap; the 1024-thread form none)
             assert k[".private_segment_fixed_size"] <= (64 if nt == 512 else 0), f"{name}: {k['.private_segment_fixed_size']} bytes of scratch per lane"
     assert seen >= 4
+
+
+def test_skinning_keeps_four_blocks_per_cu(kernels):
+    ks = [k for n, k in kernels.items() if "skin_mfma_kernel" in n or "skin_input_kernel" in n]
+    assert len(ks) == 4
+    for k in ks:
+        assert _regs(k) <= 128 and k[".group_segment_fixed_size"] <= 40 * 1024 and k[".private_segment_fixed_size"] == 0, k[".name"]

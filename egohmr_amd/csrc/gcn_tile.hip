@@ -136,6 +136,11 @@ template <int P, int MODE, int NW, class Args>
 __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
   constexpr bool CHAIN = MODE >= 1;
   constexpr bool LOOP = MODE == 2;
+#ifdef EHM_P3_MFMA32
+  constexpr bool M16 = false;        // the split-f16 mode on v_mfma_f32_32x32x16_f16 as in rounds 2 - 4 (same-box A/B of the two forms)
+#else
+  constexpr bool M16 = P == 3;       // split-f16 mode: v_mfma_f32_16x16x32_f16 (see "16 x 16 x 32" below)
+#endif
   static_assert(NW == 4 || (NW == 8 && P == 1 && CHAIN), "the 8-wave tile exists for the chained f16 kernel (f16x3 is power-bound: 8 waves measured 150 vs 152 us)");
   const auto& a = [&]() -> const auto& { if constexpr (MODE >= 1) return chain_view(a_); else return a_; }();
   // MODE.FP16_OVFL = 1 for the life of the wave: every f32 -> f16 conversion of the epilogue clamps to +-65504 instead of producing inf
@@ -170,6 +175,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
   // SIMD does not get)
   __amdgpu_buffer_rsrc_t rsA, rsB;
   int voAB;
+  [[maybe_unused]] int voA16 = 0;                            // M16: my activation row is a permuted one (below)
   auto io_of = [&](const Tile& t) -> TileIO {
     TileIO o;
     if constexpr (CHAIN) {
@@ -195,9 +201,19 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     rsA = ehm_buffer_rsrc(o.X + (size_t)t.m_tile * 192 * rowf);
     rsB = ehm_buffer_rsrc(o.W + (size_t)t.n_tile * BROWS * rowf);
     voAB = (r0 * rowf + swz) * 4;
+    if constexpr (M16) {
+      // 16 x 16 x 32: LDS row rho = 16 rt + i of a wave's 96 (MFMA row i of row tile rt) holds the tile row 24 (i >> 2) + 4 rt + (i & 3), so that the C
+      // layout (row = 4 (lane >> 4) + reg) hands lane group rg = lane >> 4 the 24 joints of body rg: joint 4 rt + reg.  My LDS rows are r0 + 32 i
+      // (i = 0..5; r0 < 32): row tiles (r0 >> 4) + 2 (i % 3) of wave-row i / 3 - the tile row moves by 96 (i / 3) + 8 (i % 3), the same for every lane.
+      const int i16 = r0 & 15;
+      voA16 = ((24 * (i16 >> 2) + 4 * (r0 >> 4) + (i16 & 3)) * rowf + swz) * 4;
+    }
   };
   auto dma_a = [&](int buf, int kt, int i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (AS3 void*)(lds + buf * STG + (wave + NW * i) * 256), 16, voAB, (i * (int)row32 + kt * RK) * 4, 0, kLoadAux);
+    if constexpr (M16)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (AS3 void*)(lds + buf * STG + (wave + NW * i) * 256), 16, voA16, ((96 * (i / 3) + 8 * (i % 3)) * rowf + kt * RK) * 4, 0, kLoadAux);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (AS3 void*)(lds + buf * STG + (wave + NW * i) * 256), 16, voAB, (i * (int)row32 + kt * RK) * 4, 0, kLoadAux);
   };
   auto dma_b = [&](int buf, int kt, int i) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (AS3 void*)(lds + buf * STG + A_T + (wave + NW * i) * 256), 16, voAB, (i * (int)row32 + kt * RK) * 4, 0, 0);
@@ -243,6 +259,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
   //   keyA = (rA>>1)&7 (+8t flips its bit 2 for odd t), keyB = (rB>>1)&7 (+64 leaves it)
   // logical chunk of (k-step s, hi/lo hl, lane half g): X2 tile = [hi k0-31 | lo k0-31] -> 4 hl + 2 s + g;  f16 tile = k0-63 -> 2 s + g
   int oA[KS][P == 3 ? 2 : 1][2], oB[KS][P == 3 ? 2 : 1];
+  [[maybe_unused]] int oA16[2], oB16[2];
   auto thread_consts = [&]() {
     int t = tid;
     asm volatile("" : "+v"(t));                              // opaque: keeps hipcc from hoisting what follows out of the tile loop
@@ -265,6 +282,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         for (int o = 0; o < 2; ++o) oA[s][hl][o] = rA * RK + (((c ^ keyA) ^ (4 * o)) << 2);
         oB[s][hl] = A_T + rB * RK + ((c ^ keyB) << 2);
       }
+    if constexpr (M16) {
+      const int i16 = lane & 15, kg = lane >> 4, key = (i16 >> 1) & 7;
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        oA16[hl] = (96 * wm + i16) * RK + (((4 * hl + kg) ^ key) << 2);
+        oB16[hl] = A_T + (32 * wn + i16) * RK + (((4 * hl + kg) ^ key) << 2);
+      }
+    }
   };
   thread_consts();
   auto read_frags = [&](Frags<P>& f, int buf, int s) {
@@ -534,8 +559,98 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     unsigned int dep_seen = 0;
     zero_acc();
     Frags<P> f0, f1;
-    read_frags(f0, 0, 0);
+    if constexpr (!M16) read_frags(f0, 0, 0);
     TSTAMP(1);
+    // ---- EHM_EXP_MFMA16: operand halves A[rh] (row tiles 3 rh .. + 2 of 16 rows), B[ch] (branch ch: two 16-channel column tiles), 6 x 4 accumulators
+    [[maybe_unused]] half8 Ah[2][3], Al[2][3], Bh[2][2], Bl[2][2];
+    typedef float f32x4a __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] f32x4a c16[6][4];
+    [[maybe_unused]] auto ldA = [&](auto rhc, int buf) {
+      constexpr int rh = decltype(rhc)::value;
+      const float* S = lds + buf * STG;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        Ah[rh][t] = *(const half8*)(S + oA16[0] + 16 * (3 * rh + t) * RK);
+        Al[rh][t] = *(const half8*)(S + oA16[1] + 16 * (3 * rh + t) * RK);
+      }
+    };
+    [[maybe_unused]] auto ldB = [&](auto chc, int buf) {
+      constexpr int ch = decltype(chc)::value;
+      const float* S = lds + buf * STG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        Bh[ch][u] = *(const half8*)(S + oB16[0] + (16 * u + 64 * ch) * RK);
+        Bl[ch][u] = *(const half8*)(S + oB16[1] + (16 * u + 64 * ch) * RK);
+      }
+    };
+    [[maybe_unused]] auto mm = [&](auto rhc, auto chc) {            // 18 MFMAs: small cross terms first, six independent accumulators per term
+      constexpr int rh = decltype(rhc)::value, ch = decltype(chc)::value;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[rh][t], Bh[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bl[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bh[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
+    };
+    [[maybe_unused]] auto pin16 = [&](int reads, int dmas) {          // reads one per MFMA from the start, DMAs one per MFMA behind them
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (i - reads < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    // one K tile of parity PAR (snake order of the four (row half, branch) phases: only one operand half changes between consecutive phases, so
+    // no half is ever double-buffered).  mode 0: steady (stages K tile kt + 2 into `buf`), 1: second-last, 2: last (no next-tile loads)
+    [[maybe_unused]] auto tile16 = [&](auto parc, int buf, int kt, int mode) {
+      constexpr int PAR = decltype(parc)::value;
+      typedef std::integral_constant<int, PAR> CF;
+      typedef std::integral_constant<int, 1 - PAR> CS;
+      ldB(CS{}, buf);
+      mm(I0{}, CF{});
+      pin16(4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(I1{}, buf);
+      mm(I0{}, CS{});
+      pin16(6, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (pending_publish) { publish(prev); pending_publish = false; }
+      if (mode == 2) return;
+      ldA(I0{}, buf ^ 1);
+      if (mode == 0) {
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) dma_a(buf, kt + 2, i);
+      }
+      mm(I1{}, CS{});
+      pin16(6, mode == 0 ? NDA : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(CS{}, buf ^ 1);
+      if (mode == 0) {
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) dma_b(buf, kt + 2, i);
+      }
+      mm(I1{}, CF{});
+      pin16(4, mode == 0 ? NDB : 0);
+      if (mode == 0) __builtin_amdgcn_s_setprio(0);
+    };
+    if constexpr (M16) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c16[t][u] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      ldA(I0{}, 0);
+      ldB(I0{}, 0);
+    }
 
     // One K tile, phases s = 0 .. KS-1 on alternating fragment sets.  MODE 0: steady state (fetches tile kt + 2 into the stage it
     // just emptied), 1: second-last tile (nothing left to fetch), 2: last tile (stops after the barrier; the caller issues the
@@ -555,6 +670,12 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     };
     Frags<P>& f_last = ((KS - 1) & 1) ? f1 : f0;   // set of a tile's last k-step
 
+    if constexpr (M16) {
+      for (int kt = 0; kt < KT - 2; kt += 2) {
+        tile16(I0{}, 0, kt, 0);
+        tile16(I1{}, 1, kt + 1, 0);
+      }
+    } else
     for (int kt = 0; kt < KT - 2; ++kt) {
       const int buf = kt & 1;
       phases_before_barrier(buf);
@@ -580,6 +701,31 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         dep_seen = tn.kind != K_HIDDEN ? 0u : ((f == nullptr || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) ? 1u : 0u);
       }
     }
+    if constexpr (M16) {
+      // second-last K tile (stage 0): its first half up to the barrier by hand so that the slot words can be written behind the barrier
+      ldB(I1{}, 0);
+      mm(I0{}, I0{});
+      pin16(4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(I1{}, 0);
+      mm(I0{}, I1{});
+      pin16(6, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (pending_publish) { publish(prev); pending_publish = false; }
+      if constexpr (CHAIN)
+        if (tid == 0) {                                           // stage 0 is dead from here on
+          slot[0] = t_next; slot[1] = dep_seen;
+          if constexpr (LOOP) { slot[2] = (unsigned int)pk_next; slot[3] = (unsigned int)(pk_next >> 32); }
+        }
+      ldA(I0{}, 1);
+      mm(I1{}, I1{});
+      pin16(6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(I1{}, 1);
+      mm(I1{}, I0{});
+      pin16(4, 0);
+    } else
     {
       const int buf = (KT - 2) & 1;
       phases_before_barrier(buf);
@@ -595,13 +741,15 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     }
     // ---- last K tile; the per-channel epilogue constants are fetched under its MFMAs
     const TileIO io = io_of(cur);
-    const int n = NT * cur.n_tile + 32 * wn + mi;
+    const int n = NT * cur.n_tile + 32 * wn + (M16 ? (lane & 15) : mi);
     const unsigned int n4 = (unsigned int)n * 4u;
     const unsigned int tblrow = (unsigned int)N * 4u;
     float dj[kJ], mj[kJ], sh;
+    [[maybe_unused]] float djb[kJ], mjb[kJ], shb = 0.f;          // M16: a lane owns TWO channels (n and n + 16) of one body
     half8 af[3];                       // P == 1: [Aoff | I] fragments of the matrix-core adjacency mix
     unsigned int nt = 0xffffffffu, ready = 0;
-    phases_before_barrier((KT - 1) & 1);
+    if constexpr (M16) tile16(I1{}, 1, KT - 1, 2);            // last K tile (stage 1): first half + barrier; its second half runs under the table loads below
+    else phases_before_barrier((KT - 1) & 1);
     unsigned int pk_lo = 0, pk_hi = 0;
     if constexpr (CHAIN) { nt = slot[0]; ready = slot[1]; }
     if constexpr (LOOP) { pk_lo = slot[2]; pk_hi = slot[3]; }
@@ -629,7 +777,26 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(fm);
+      if constexpr (M16) {
+        mm(I1{}, I0{});
+        mm(I1{}, I1{});
+        // the second channel's constants: requested here, behind the last MFMAs (their fragments are dead), consumed behind the next tile's DMA issue
+        __builtin_amdgcn_sched_barrier(0);
+        shb = io.shift[n + 16];
+#pragma unroll
+        for (int q4 = 0; q4 < kJ / 4; ++q4) {
+          const u32x4_tbl d4 = __builtin_amdgcn_raw_buffer_load_b128(dsB, nrow + 16u * (kJ * 4), 16 * q4, 0);
+          const u32x4_tbl m4 = __builtin_amdgcn_raw_buffer_load_b128(m1B, nrow + 16u * (kJ * 4), 16 * q4, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned int du = d4[i], mu = m4[i];
+            djb[4 * q4 + i] = __builtin_bit_cast(float, du);
+            mjb[4 * q4 + i] = __builtin_bit_cast(float, mu);
+          }
+        }
+      } else {
+        mfmas(fm);
+      }
     }
     TSTAMP(2);
     // ---- next tile's operand DMA goes out before this tile's epilogue
@@ -679,8 +846,10 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     const unsigned int orow = out_f32 ? tblrow : arow;
     // wave row of scratch row rl in pass p:  P == 1: pass = half-wave x -> 48 p + rl;  P == 3: pass = body beta, scratch rows = 24 g + joint
     // -> 48 (rl / 24) + 24 p + rl % 24
+    // M16: pass = joints 12 p .. + 11 of the wave's four bodies, scratch row = 4 (joint - 12 p) + body -> wave row 24 (rl & 3) + 12 p + (rl >> 2)
     auto item_vrow = [&](int p, int it) -> unsigned int {
       const int rl = 16 * it + lr;
+      if constexpr (M16) return (unsigned int)(24 * (lr & 3) + 12 * p + 4 * it + (lr >> 2));
       return (unsigned int)(P == 1 ? 48 * p + rl : 24 * p + rl + (rl >= 24 ? 24 : 0));
     };
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -704,10 +873,17 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     f32x2 dp[kJ], gp[kJ];
 #pragma unroll
     for (int j = 0; j < kJ; ++j) {
-      const f32x2 a0 = f32x2{acc0[j >> 3][2 * (j & 7)], acc0[j >> 3][2 * (j & 7) + 1]};
-      const f32x2 a1 = f32x2{acc1[j >> 3][2 * (j & 7)], acc1[j >> 3][2 * (j & 7) + 1]};
-      dp[j] = __builtin_elementwise_fma(f32x2{dj[j], dj[j]}, a0, f32x2{sh, sh});
-      gp[j] = a1 * f32x2{mj[j], mj[j]};
+      if constexpr (M16) {                     // the pair = my two channels (n, n + 16) of ONE body; joint j = accumulator row tile j >> 2, register j & 3
+        const f32x2 a0 = f32x2{c16[j >> 2][0][j & 3], c16[j >> 2][1][j & 3]};
+        const f32x2 a1 = f32x2{c16[j >> 2][2][j & 3], c16[j >> 2][3][j & 3]};
+        dp[j] = __builtin_elementwise_fma(f32x2{dj[j], djb[j]}, a0, f32x2{sh, shb});
+        gp[j] = a1 * f32x2{mj[j], mjb[j]};
+      } else {
+        const f32x2 a0 = f32x2{acc0[j >> 3][2 * (j & 7)], acc0[j >> 3][2 * (j & 7) + 1]};
+        const f32x2 a1 = f32x2{acc1[j >> 3][2 * (j & 7)], acc1[j >> 3][2 * (j & 7) + 1]};
+        dp[j] = __builtin_elementwise_fma(f32x2{dj[j], dj[j]}, a0, f32x2{sh, sh});
+        gp[j] = a1 * f32x2{mj[j], mj[j]};
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     TSTAMP(6);
@@ -794,15 +970,27 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         }
       }
       wbase = STG + wave * 256 + (NW == 8 ? STG : 3072) * g + mi;   // scratch row 24 g + joint: pieces 3 g + (joint >> 3) (8 waves: poff(3 + x) - poff(x) = STG)
+      // M16: V[c][j] = channel n + 16 c, joint j of body rg = lane >> 4.  Scratch row of (joint 12 p + jj, body rg) = 4 jj + rg: piece jj >> 1, row
+      // 4 (jj & 1) + rg of its eight; the two 16-channel halves of a row swap places for bodies 2, 3, so that the four lane groups of a write hit
+      // four different 16-bank groups
+      if constexpr (M16) wbase = STG + wave * 256 + (lane >> 4) * 32 + ((lane & 15) ^ (16 * (lane >> 5)));
     }
     TSTAMP(7);
-    const int rbase = STG + wave * 256 + (lr & 7) * 32 + c8;                      // item it: + piece 2 it + (lr >> 3)
+    const int rbase = STG + wave * 256 + (lr & 7) * 32 + (M16 ? (c8 ^ (16 * ((lr & 3) >> 1))) : c8);   // item it: + piece 2 it + (lr >> 3)
     auto roff = [&](int it) { return rbase + ((lr >> 3) ? poff(2 * it + 1) : poff(2 * it)); };
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (P == 3) { if (p == 1) load_res_pass(1); }
+      if constexpr (M16) {
 #pragma unroll
-      for (int k = 0; k < 24; ++k) lds[wbase + vimm(k)] = V[p][k];
+        for (int jj = 0; jj < 12; ++jj) {
+          lds[wbase + poff(jj >> 1) + (jj & 1) * 128] = V[0][12 * p + jj];
+          lds[(wbase ^ 16) + poff(jj >> 1) + (jj & 1) * 128] = V[1][12 * p + jj];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) lds[wbase + vimm(k)] = V[p][k];
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-private: program order is enough
       f32x4 t[3][2];
 #pragma unroll

@@ -60,11 +60,15 @@ bh, bl = split(xb[:2])
 cases.append(("f16x3_relu_like_activations", 1, torch.cat([ah, al]), torch.cat([bh, bl])))
 ah, al = split(xa[:4])
 cases.append(("f16x3_dense_random", 1, torch.cat([ah, al]), torch.cat([bh, bl])))
+for name, variant, A, B in list(cases):                     # the same operands through v_mfma_f32_16x16x32_f16 (variants 2 / 3)
+    if "zeros" not in name:
+        cases.append((name + "_mfma16x16x32", variant + 2, A, B))
 out = torch.empty(n, device=dev)
 iters = 4000
 for name, variant, A, B in cases:
     A, B = A.contiguous(), B.contiguous()
-    per_iter = 24 if variant == 0 else 72
+    per_iter = {0: 24, 1: 72, 2: 48, 3: 144}[variant]
+    flop_per_mfma = (32 * 32 * 16 * 2) if variant < 2 else (16 * 16 * 32 * 2)
     stop, count = threading.Event(), [0]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -90,7 +94,7 @@ for name, variant, A, B in cases:
     stop.set()
     th.join()
     ms = e0.elapsed_time(e1)
-    flops = count[0] * float(iters) * per_iter * blocks * 8 * (32 * 32 * 16 * 2)
+    flops = count[0] * float(iters) * per_iter * blocks * 8 * flop_per_mfma
     ws = [w for w, _ in samples if w is not None]
     cs = [c for _, c in samples if c is not None]
     print(json.dumps({"case": name, "issued_mfma_tflops": flops / (ms * 1e-3) / 1e12, "frac_of_2500": flops / (ms * 1e-3) / 2.5e15,

@@ -15,6 +15,8 @@
 //     the loads of tile k+1 are issued before the MFMAs of tile k and converted after them.
 //   B (weights, pre-split X2<32> [Co_pad][K], scaled by a power of two): global_load_lds DMA, double buffered.
 //   Epilogue: through a float [128][128] LDS tile so that rows leave as 16-byte stores with the residual read the same way.
+#include <type_traits>
+
 #include "common.h"
 #include "egohmr_hip.h"
 #include "gcn_dev.h"
@@ -276,6 +278,9 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
 
   constexpr int KS = 2, NM = 9 * NU, NR = 6 + 2 * NU, NBD = 2 * NU;
+  // split-f16 products on v_mfma_f32_16x16x32_f16 (a K tile = ONE k-step; the K loop of gcn_tile.hip's split mode: four (row half, column half) phases in
+  // snake order, no operand half double-buffered); the hi-only tier keeps the 32 x 32 x 16 form
+  constexpr bool M16 = !HO;
   const int tid = threadIdx.x;
   const int K = p.KH * p.KW * p.Ci + (DS ? p.Ci2 : 0);
   const int cpt = p.Ci / XRK;                    // K tiles per tap
@@ -287,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
   int lane, wave, wm, wn, mi, g, r0, swz;
   bool hi_lane;                                   // my 16-byte chunk of an operand piece holds hi halves (logical chunks 0-3 of the 128-byte K tile)
   int oA[KS][2], oB[KS][2];
+  [[maybe_unused]] int oA16[2], oB16[2];
   auto thread_consts = [&]() {
     int t = tid;
     asm volatile("" : "+v"(t));
@@ -307,6 +313,14 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
         oA[s][hl] = rA * XRK + ((c ^ keyA) << 2);
         oB[s][hl] = XA_T + rB * XRK + ((c ^ keyB) << 2);
       }
+    if constexpr (M16) {      // lane (i = l & 15, kg = l >> 4): row i of a 16-row tile, logical chunk kg (hi) / 4 + kg (lo) of the 128-byte K tile
+      const int i16 = lane & 15, kg = lane >> 4, key = (i16 >> 1) & 7;
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        oA16[hl] = (96 * wm + i16) * XRK + (((4 * hl + kg) ^ key) << 2);
+        oB16[hl] = XA_T + (32 * NU * wn + i16) * XRK + (((4 * hl + kg) ^ key) << 2);
+      }
+    }
   };
   thread_consts();
 
@@ -504,7 +518,105 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
     XFrags<NU> f0, f1;
-    read_frags(f0, 0, 0);
+    if constexpr (!M16) read_frags(f0, 0, 0);
+    const int KL = pc.k1 - pc.k0;                                // K tiles of this piece (>= 2)
+    // ---- 16 x 16 x 32: operand halves A[rh] (row tiles 3 rh .. + 2 of 16 rows), B[ch] (column tiles NU ch .. + NU - 1 of 16), 6 x 2 NU accumulators
+    [[maybe_unused]] half8 Ah[2][3], Al[2][3], Bh[2][NU], Bl[2][NU];
+    typedef float f32x4a __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] f32x4a c16[6][2 * NU];
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    [[maybe_unused]] auto ldA = [&](auto rhc, int buf) __attribute__((always_inline)) {
+      constexpr int rh = decltype(rhc)::value;
+      const float* S = lds + buf * XSTG;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        Ah[rh][t] = *(const half8*)(S + oA16[0] + 16 * (3 * rh + t) * XRK);
+        Al[rh][t] = *(const half8*)(S + oA16[1] + 16 * (3 * rh + t) * XRK);
+      }
+    };
+    [[maybe_unused]] auto ldB = [&](auto chc, int buf) __attribute__((always_inline)) {
+      constexpr int ch = decltype(chc)::value;
+      const float* S = lds + buf * XSTG;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        Bh[ch][u] = *(const half8*)(S + oB16[0] + 16 * (NU * ch + u) * XRK);
+        Bl[ch][u] = *(const half8*)(S + oB16[1] + 16 * (NU * ch + u) * XRK);
+      }
+    };
+    [[maybe_unused]] auto mm = [&](auto rhc, auto chc) __attribute__((always_inline)) {      // 9 NU MFMAs: small cross terms first, 3 NU independent accumulators per term
+      constexpr int rh = decltype(rhc)::value, ch = decltype(chc)::value;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) c16[3 * rh + t][NU * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[rh][t], Bh[ch][u], c16[3 * rh + t][NU * ch + u], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) c16[3 * rh + t][NU * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bl[ch][u], c16[3 * rh + t][NU * ch + u], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) c16[3 * rh + t][NU * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bh[ch][u], c16[3 * rh + t][NU * ch + u], 0, 0, 0);
+    };
+    [[maybe_unused]] auto pin16 = [&](int reads, int dmas) __attribute__((always_inline)) {   // reads one per MFMA from the start, DMAs behind them
+#pragma unroll
+      for (int i = 0; i < 9 * NU; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (i - reads < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    };
+    // K tile j of the piece (parity PAR = j & 1 = its stage).  Phases (0, cf) (0, cs) | barrier | (1, cs) (1, cf) with cf = PAR: the next tile's first phase
+    // is (0, cs) - the halves that are free to be refilled during this tile's last two phases.  Returns false behind the barrier of the piece's LAST K tile
+    // (its last two phases run below); K tile j + 2 is staged while there is one.
+    [[maybe_unused]] auto tile16 = [&](auto parc, int j) __attribute__((always_inline)) -> bool {
+      constexpr int PAR = decltype(parc)::value;
+      constexpr int buf = PAR;
+      typedef std::integral_constant<int, PAR> CF;
+      typedef std::integral_constant<int, 1 - PAR> CS;
+      ldB(CS{}, buf);
+      mm(I0{}, CF{});
+      pin16(2 * NU, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(I1{}, buf);
+      mm(I0{}, CS{});
+      pin16(6, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (j == KL - 1) return false;
+      const bool more = j + 2 < KL;                            // (block-uniform)
+      ldA(I0{}, buf ^ 1);
+      __builtin_amdgcn_s_setprio(2);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dma_a(buf, pc.k0 + j + 2, i);
+      }
+      mm(I1{}, CS{});
+      pin16(6, NU == 2 ? 6 : 3);
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(CS{}, buf ^ 1);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NBD; ++i) dma_b(buf, pc.k0 + j + 2, i);
+      }
+      mm(I1{}, CF{});
+      pin16(2 * NU, NU == 2 ? NBD : NBD + 3);
+      __builtin_amdgcn_s_setprio(0);
+      return true;
+    };
+    if constexpr (M16) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int u = 0; u < 2 * NU; ++u) c16[t][u] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      ldA(I0{}, 0);
+      ldB(I0{}, 0);
+      for (int j = 0;; j += 2) {
+        if (!tile16(I0{}, j)) break;
+        if (!tile16(I1{}, j + 1)) break;
+      }                                                           // (the last K tile's second half - phases (1, 0) and (1, 1) - runs below)
+    } else {
     auto first_phase = [&](int buf) {
       read_frags(f1, buf, 1);
       mfmas(f0);
@@ -512,7 +624,6 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     };
-    const int KL = pc.k1 - pc.k0;                                // K tiles of this piece (>= 2)
     for (int j = 0; j < KL - 2; ++j) {
       const int buf = j & 1;
       first_phase(buf);
@@ -529,18 +640,25 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
       pin_reads();
     }
     first_phase((KL - 1) & 1);
+    }
 
     const int n0 = pc.n * XBN;
     const size_t row0 = (size_t)pc.m * XBM;
     const bool cols_live = n0 + 32 * NU * wn < p.Co;             // (NU = 2 with Co = 64: the upper column half of the tile is padding)
-    float add[NU];
+    constexpr int NADD = M16 ? 2 * NU : NU;                      // M16: my columns are 32 NU wn + 16 ct + (lane & 15), ct < 2 NU
+    float add[NADD];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int col = n0 + 32 * NU * wn + 32 * u + mi;
+    for (int u = 0; u < NADD; ++u) {
+      const int col = M16 ? n0 + 32 * NU * wn + 16 * u + (lane & 15) : n0 + 32 * NU * wn + 32 * u + mi;
       add[u] = (p.bias && col < p.Co) ? p.bias[col] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(f1);
+    if constexpr (M16) {
+      mm(I1{}, I0{});
+      mm(I1{}, I1{});
+    } else {
+      mfmas(f1);
+    }
     Piece nx;
     const bool have_next = piece_of(it + 1, nx);
     if (have_next) {
@@ -564,12 +682,21 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
       if (pc.k0 != 0) {
         finish = false;
         float* mine = part + (size_t)(b - owner - 1) * NACC * 256 + tid;
+        if constexpr (M16) {
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int u = 0; u < 2 * NU; ++u)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mine[((t * 2 * NU + u) * 4 + r) * 256] = c16[t][u][r];
+        } else {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[((t * NU + u) * 16 + r) * 256] = acc[t][u][r];
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -594,16 +721,25 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (missing) {
 #pragma unroll
-          for (int u = 0; u < NU; ++u) add[u] = __builtin_nanf("");
+          for (int u = 0; u < NADD; ++u) add[u] = __builtin_nanf("");
         }
         for (int q = 0; q < last_blk - owner; ++q) {
           const float* theirs = part + (size_t)q * NACC * 256 + tid;
+          if constexpr (M16) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+              for (int u = 0; u < 2 * NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c16[t][u][r] += theirs[((t * 2 * NU + u) * 4 + r) * 256];
+          } else {
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int u = 0; u < NU; ++u)
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[t][u][r] += theirs[((t * NU + u) * 16 + r) * 256];
+          }
         }
       }
     }
@@ -611,6 +747,81 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     // Epilogue per wave through its six 1 KiB pieces of stage 1's activation region.  Accumulator register r of acc[t][u] is row
     // 32 t + 8 (r >> 2) + 4 g + (r & 3): row groups Gq = 4 t + (r >> 2) of 8 rows.  NU = 2: a pass turns 3 groups x 64 columns (piece
     // 2 gi + u), 4 passes; NU = 1: 6 groups x 32 columns (piece gi), 2 passes.  Read items = (row, 8 columns), three per lane.
+    if constexpr (M16) {
+     if (cols_live && finish) {
+      // accumulator layout: lane (i = l & 15, rg = l >> 4) owns columns 32 NU wn + 16 ct + i; register r of c16[rt][ct] is row 16 rt + 4 rg + r.  One pass per
+      // row tile (16 rows x 32 NU columns through 2 NU of the wave's six 1 KiB pieces): piece NU (row >> 3) + (col >> 5) holds [8 rows][32 columns]; inside a piece
+      // row (row & 7) sits at (row & 7) ^ (row >> 3) and its two 16-column halves swap places for odd rg (four lane groups of a write -> four 16-bank groups).
+      // Read items = (row, 8 columns): NU per lane.
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      const unsigned int yrow = (unsigned int)p.Co * 4u;
+      const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(p.y + (row0 + 96 * wm) * (size_t)yrow);
+      const __amdgpu_buffer_rsrc_t rB = ehm_buffer_rsrc((p.res ? p.res : p.y) + (row0 + 96 * wm) * (size_t)yrow);
+      const bool relu = p.relu != 0, has_res = p.res != nullptr;
+      const int i16 = lane & 15, rg = lane >> 4;
+      int wb[2][2];                                                // write address of (r, ct) = wb[r & 1][ct & 1] + (ct >> 1) 1024 + 32 r
+      {
+        const int base = XSTG + wave * 256 + (rg >> 1) * (NU * 1024) + (rg & 1) * 128 + i16, hoff = 32 * (rg >> 1), ooff = 16 * (rg & 1);
+        wb[0][0] = base + hoff + ooff;       wb[0][1] = base + hoff + 16 - ooff;
+        wb[1][0] = base - hoff + ooff;       wb[1][1] = base - hoff + 16 - ooff;
+      }
+      // items: NU = 2: item k = row (l >> 3) + 8 k, columns 8 (l & 7) .. + 7 of 64;  NU = 1: one item, row l >> 2, columns 8 (l & 3) .. + 7 of 32
+      const int irow0 = NU == 2 ? lane >> 3 : lane >> 2, oct = NU == 2 ? lane & 7 : lane & 3;
+      const int colw = n0 + 32 * NU * wn + 8 * oct;
+      const unsigned int col_off = (unsigned int)(((colw >> 5) * 64 + (colw & 31)) * 2);
+      int rbase[NU];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        const int rho = NU == 2 ? irow0 + 8 * k : irow0;          // row of the pass (0..15): piece row (rho & 7) ^ (rho >> 3), column halves swapped for odd rho >> 2
+        rbase[k] = XSTG + wave * 256 + (NU * (rho >> 3) + (oct >> 2)) * 1024 + ((rho & 7) ^ (rho >> 3)) * 32 + ((8 * (oct & 3)) ^ (16 * ((rho >> 2) & 1)));
+      }
+#pragma unroll
+      for (int rt = 0; rt < 6; ++rt) {
+        u32x4_t rq[NU][2];
+        if (has_res) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k) {
+            const unsigned int vo = (unsigned int)(16 * rt + (NU == 2 ? irow0 + 8 * k : irow0)) * yrow + col_off;
+            rq[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, 0, 0);
+            rq[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo + 64u, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2 * NU; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[wb[r & 1][ct & 1] + (ct >> 1) * 1024 + 32 * r] = fmaf(c16[rt][ct][r], p.inv_scale, add[ct]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 tq[NU][2];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+          tq[k][0] = *(const f32x4*)(lds + rbase[k]);
+          tq[k][1] = *(const f32x4*)(lds + rbase[k] + 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+          float v[8] = {tq[k][0][0], tq[k][0][1], tq[k][0][2], tq[k][0][3], tq[k][1][0], tq[k][1][1], tq[k][1][2], tq[k][1][3]};
+          if (has_res) {
+            const half8 rh = __builtin_bit_cast(half8, rq[k][0]), rl = __builtin_bit_cast(half8, rq[k][1]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] += (float)rh[c] + (float)rl[c];
+          }
+          half8 hh, ll;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (relu) v[c] = fmaxf(v[c], 0.f);
+            hh[c] = (half_t)v[c];                              // (MODE.FP16_OVFL: the conversions saturate at +-65504, see the kernel's head)
+            ll[c] = (half_t)(v[c] - (float)hh[c]);
+          }
+          const unsigned int vo = (unsigned int)(16 * rt + (NU == 2 ? irow0 + 8 * k : irow0)) * yrow + col_off;
+          if (colw < p.Co) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
+          }
+        }
+      }
+     }
+    } else
     if (cols_live && finish) {
       constexpr int GP = NU == 2 ? 3 : 6, NPASS = 12 / GP;       // row groups per pass
       const unsigned int yrow = (unsigned int)p.Co * 4u;

@@ -10,6 +10,8 @@
 //   * the global max-pool over the N points is fused into the epilogue (wave shuffle -> LDS -> one atomic per column and block).
 // Operands are in the X2 split format of gcn_dev.h (32 hi halves + 32 lo halves per 32-k group).  Tile 192 x 128 x 32,
 // 4 waves (2 x 2, 96 x 64 each), persistent blocks, see linear_tile_kernel.
+#include <type_traits>
+
 #include "common.h"
 #include "egohmr_hip.h"
 #include "gcn_dev.h"
@@ -89,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
 
   constexpr int KS = 2, NM = 18, NR = 10;
+  // split-f16 products on v_mfma_f32_16x16x32_f16 (a K tile = ONE k-step; the K loop of gcn_tile.hip's split mode: four (row half, column half) phases in
+  // snake order, no operand half double-buffered); the hi-only tier keeps the 32 x 32 x 16 form
+  constexpr bool M16 = !HO;
   const int tid = threadIdx.x;
   const int K = p.K0 + p.K1;
   const int KT0 = p.K0 / RK, KT = K / RK;
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
   int lane, wave, wm, wn, mi, g, r0, swz;
   bool hi_lane;                                                // my 16-byte chunk of an operand piece holds hi halves
   int oA[KS][2], oB[KS][2];
+  [[maybe_unused]] int oA16[2], oB16[2];
   auto thread_consts = [&]() {                                 // re-derived per tile: nothing of this stays live across the epilogue
     int t = tid;
     asm volatile("" : "+v"(t));
@@ -117,6 +123,14 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
         oA[s][hl] = rA * RK + ((c ^ keyA) << 2);
         oB[s][hl] = LA_T + rB * RK + ((c ^ keyB) << 2);
       }
+    if constexpr (M16) {      // lane (i = l & 15, kg = l >> 4): row i of a 16-row tile, logical chunk kg (hi) / 4 + kg (lo) of the 128-byte K tile
+      const int i16 = lane & 15, kg = lane >> 4, key = (i16 >> 1) & 7;
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        oA16[hl] = (96 * wm + i16) * RK + (((4 * hl + kg) ^ key) << 2);
+        oB16[hl] = LA_T + (64 * wn + i16) * RK + (((4 * hl + kg) ^ key) << 2);
+      }
+    }
   };
   thread_consts();
 
@@ -310,7 +324,111 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
     LFrags f0, f1;
-    read_frags(f0, 0, 0);
+    if constexpr (!M16) read_frags(f0, 0, 0);
+
+    // ---- 16 x 16 x 32: operand halves A[rh] (row tiles 3 rh .. + 2 of 16 rows), B[ch] (column tiles 2 ch, 2 ch + 1 of 16), 6 x 4 accumulators
+    [[maybe_unused]] half8 Ah[2][3], Al[2][3], Bh[2][2], Bl[2][2];
+    typedef float f32x4a __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] f32x4a c16[6][4];
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    [[maybe_unused]] auto ldA = [&](auto rhc, int buf) __attribute__((always_inline)) {
+      constexpr int rh = decltype(rhc)::value;
+      const float* S = lds + buf * LSTG;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        Ah[rh][t] = *(const half8*)(S + oA16[0] + 16 * (3 * rh + t) * RK);
+        Al[rh][t] = *(const half8*)(S + oA16[1] + 16 * (3 * rh + t) * RK);
+        if constexpr (RELU_A) relu_split(Ah[rh][t], Al[rh][t]);
+      }
+    };
+    [[maybe_unused]] auto ldB = [&](auto chc, int buf) __attribute__((always_inline)) {
+      constexpr int ch = decltype(chc)::value;
+      const float* S = lds + buf * LSTG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        Bh[ch][u] = *(const half8*)(S + oB16[0] + 16 * (2 * ch + u) * RK);
+        Bl[ch][u] = *(const half8*)(S + oB16[1] + 16 * (2 * ch + u) * RK);
+      }
+    };
+    [[maybe_unused]] auto mm = [&](auto rhc, auto chc) __attribute__((always_inline)) {            // 18 MFMAs: small cross terms first, six independent accumulators per term
+      constexpr int rh = decltype(rhc)::value, ch = decltype(chc)::value;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[rh][t], Bh[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bl[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bh[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
+    };
+    [[maybe_unused]] auto pin16 = [&](int reads, int dmas) __attribute__((always_inline)) {          // reads one per MFMA from the start, DMAs one per MFMA behind them
+      if constexpr (RELU_A) return;                               // (the rectifying loads are left to the scheduler)
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (i - reads < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    };
+    // one K tile of parity PAR = kt & 1 (stage kt & 1).  Phases (0, cf) (0, cs) | barrier | (1, cs) (1, cf) with cf = PAR: the next tile's first phase is
+    // (0, cs) - exactly the halves that are free to be refilled during this tile's last two phases.  Returns false behind the barrier of the LAST K tile
+    // (its last two phases run below, under the epilogue's loads); K tile kt + 2 is staged while there is one.
+    [[maybe_unused]] auto tile16 = [&](auto parc, int kt) __attribute__((always_inline)) -> bool {
+      constexpr int PAR = decltype(parc)::value;
+      constexpr int buf = PAR;
+      typedef std::integral_constant<int, PAR> CF;
+      typedef std::integral_constant<int, 1 - PAR> CS;
+      ldB(CS{}, buf);
+      mm(I0{}, CF{});
+      pin16(4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(I1{}, buf);
+      mm(I0{}, CS{});
+      pin16(6, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                         // tile kt is in everyone's registers; tile kt + 1 is complete in LDS
+      if (kt == KT - 1) return false;
+      const bool more = kt + 2 < KT;                           // (block-uniform)
+      ldA(I0{}, buf ^ 1);
+      __builtin_amdgcn_s_setprio(2);
+      if (more) {
+        if constexpr (LIFT) {
+          gen_a(buf, kt + 2);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) dma_a(buf, kt + 2, i);
+        }
+      }
+      mm(I1{}, CS{});
+      pin16(6, LIFT ? 0 : 6);
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(CS{}, buf ^ 1);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b(buf, kt + 2, i);
+      }
+      mm(I1{}, CF{});
+      pin16(4, 4);
+      __builtin_amdgcn_s_setprio(0);
+      return true;
+    };
+    if constexpr (M16) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c16[t][u] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      ldA(I0{}, 0);
+      ldB(I0{}, 0);
+      for (int kt = 0;; kt += 2) {
+        if (!tile16(I0{}, kt)) break;
+        if (!tile16(I1{}, kt + 1)) break;
+      }                                                           // (the last K tile's second half - phases (1, 0) and (1, 1) in either order - runs below)
+    }
 
     auto first_phase = [&](int buf) {                  // k-step 0 of K tile kt: multiply f0 while f1 fills with k-step 1
       read_frags(f1, buf, 1);
@@ -319,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                         // tile kt is in everyone's registers; tile kt + 1 is complete in LDS
     };
+    if constexpr (!M16) {
     for (int kt = 0; kt < KT - 2; ++kt) {
       const int buf = kt & 1;
       first_phase(buf);
@@ -337,21 +456,27 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       pin_reads();
     }
     first_phase((KT - 1) & 1);                         // ends with a barrier: every fragment is in registers, all LDS is dead
+    }
 
     // ---- per-column constants, then the next tile's operand DMA, then this tile's epilogue
     const int n0 = n * LBN;
     const size_t row0 = (size_t)m * LBM;
     const int group = (int)(row0 / p.rows_per_group);
     const int lim = p.valid_rows_per_group - (int)(row0 % p.rows_per_group) - 96 * wm;   // rows of this wave that count for the maximum
-    float add[2];
+    float add[M16 ? 4 : 2];                                  // M16: my columns are 64 wn + 16 ct + (lane & 15), ct = 0..3
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int col = n0 + 64 * wn + 32 * u + mi;
+    for (int u = 0; u < (M16 ? 4 : 2); ++u) {
+      const int col = M16 ? n0 + 64 * wn + 16 * u + (lane & 15) : n0 + 64 * wn + 32 * u + mi;
       add[u] = p.bias ? p.bias[col] : 0.f;
       if (p.gbias) add[u] += p.gbias[(size_t)group * p.N + col];
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(f1);
+    if constexpr (M16) {
+      mm(I1{}, I0{});
+      mm(I1{}, I1{});
+    } else {
+      mfmas(f1);
+    }
     int m_next, n_next;
     const bool have_next = tile_of(it + 1, m_next, n_next);
     if (have_next) {
@@ -369,19 +494,98 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
       }
     }
 
-    // accumulator layout: lane (mi, g) owns column 64 wn + 32 u + mi; register r of acc[t][u] is row 32 t + 8 (r >> 2) + 4 g + (r & 3).
-    // Row group Gq = 4 t + (r >> 2) = 8 rows; a pass turns three groups (24 rows x 64 columns = the wave's six 1 KiB pieces):
-    // piece 2 gi + u holds [8 rows][32 columns] of group 3 pass + gi.
     const __amdgpu_buffer_rsrc_t yB = ehm_buffer_rsrc(p.Y ? p.Y + (row0 + 96 * wm) * (size_t)p.N * 4 : (char*)p.A0);
     const unsigned int yrow = (unsigned int)p.N * 4u;
     const bool relu_out = p.relu_out != 0, has_y = p.Y != nullptr;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    if constexpr (M16) {
+      // accumulator layout: lane (i = l & 15, rg = l >> 4) owns columns 64 wn + 16 ct + i; register r of c16[rt][ct] is row 16 rt + 4 rg + r.
+      // One pass per row tile (16 rows x 64 columns through four of the wave's six 1 KiB pieces): piece 2 (row >> 3) + (col >> 5) holds [8 rows][32 columns];
+      // inside a piece row (row & 7) sits at (row & 7) ^ (row >> 3) and its two 16-column halves swap places for odd rg, so that the four lane groups of a
+      // write go to four different 16-bank groups.  Read items = (row, 8 columns): two per lane, rows (l >> 3) and (l >> 3) + 8.
+      const int i16 = lane & 15, rg = lane >> 4;
+      // write address of (r, ct) = wb[r & 1][ct & 1] + (ct >> 1) 1024 + 32 r:  row-in-piece (4 (rg & 1) + r) ^ (rg >> 1), column (16 (ct & 1) + i) ^ 16 (rg & 1)
+      int wb[2][2];
+      {
+        const int base = LSTG + wave * 256 + (rg >> 1) * 2048 + (rg & 1) * 128 + i16, hoff = 32 * (rg >> 1), ooff = 16 * (rg & 1);
+        wb[0][0] = base + hoff + ooff;       wb[0][1] = base + hoff + 16 - ooff;
+        wb[1][0] = base - hoff + ooff;       wb[1][1] = base - hoff + 16 - ooff;
+      }
+      const int rr = lane >> 3, oct = lane & 7;
+      const int colw = n0 + 64 * wn + 8 * oct;
+      const unsigned int col_off = (unsigned int)(((colw >> 5) * 64 + (colw & 31)) * 2);   // X2: 8 hi halves here, the 8 lo halves 64 B on
+      int rbase[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        rbase[k] = LSTG + wave * 256 + (2 * k + (oct >> 2)) * 1024 + (rr ^ k) * 32 + ((8 * (oct & 3)) ^ (16 * ((lane >> 5) & 1)));
+      float cmax[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+      for (int rt = 0; rt < 6; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = fmaf(c16[rt][ct][r], p.inv_scale, add[ct]);
+            if (relu_out) v = fmaxf(v, 0.f);
+            cmax[ct] = fmaxf(cmax[ct], v);
+            if (has_y) lds[wb[r & 1][ct & 1] + (ct >> 1) * 1024 + 32 * r] = v;
+          }
+        if (has_y) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private scratch: program order is enough
+          f32x4 tq[2][2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            tq[k][0] = *(const f32x4*)(lds + rbase[k]);
+            tq[k][1] = *(const f32x4*)(lds + rbase[k] + 4);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float v[8] = {tq[k][0][0], tq[k][0][1], tq[k][0][2], tq[k][0][3], tq[k][1][0], tq[k][1][1], tq[k][1][2], tq[k][1][3]};
+            half8 hh, ll;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              hh[c] = (half_t)v[c];                              // (MODE.FP16_OVFL: the conversions saturate at +-65504, see the kernel's head)
+              ll[c] = (half_t)(v[c] - (float)hh[c]);
+            }
+            const unsigned int vo = (unsigned int)(16 * rt + 8 * k + rr) * yrow + col_off;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, hh), yB, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ll), yB, vo + 64u, 0, 0);
+          }
+        }
+      }
+      if (p.colmax) {
+        if (lim < 96) {                                           // (rare: the group's last row tile) redo the maximum over the valid rows only
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            cmax[ct] = -3.4e38f;
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float v = fmaf(c16[rt][ct][r], p.inv_scale, add[ct]);
+                if (relu_out) v = fmaxf(v, 0.f);
+                if (16 * rt + 4 * rg + r < lim) cmax[ct] = fmaxf(cmax[ct], v);
+              }
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          float cm = fmaxf(cmax[ct], __shfl_xor(cmax[ct], 16));
+          cm = fmaxf(cm, __shfl_xor(cm, 32));
+          if (rg == 0 && lim > 0) atomic_max_float(p.colmax + (size_t)group * p.N + n0 + 64 * wn + 16 * ct + i16, cm);
+        }
+      }
+    } else {
+    // accumulator layout: lane (mi, g) owns column 64 wn + 32 u + mi; register r of acc[t][u] is row 32 t + 8 (r >> 2) + 4 g + (r & 3).
+    // Row group Gq = 4 t + (r >> 2) = 8 rows; a pass turns three groups (24 rows x 64 columns = the wave's six 1 KiB pieces):
+    // piece 2 gi + u holds [8 rows][32 columns] of group 3 pass + gi.
     const int wbase = LSTG + wave * 256 + (4 * g) * 32 + mi;
     const int rr = lane >> 3, oct = lane & 7;                  // my read items: row rr of group gi = item index, columns 8 oct .. + 7 of the wave's 64
     const int rbase = LSTG + wave * 256 + (oct >> 2) * 1024 + rr * 32 + 8 * (oct & 3);
     const int colw = n0 + 64 * wn + 8 * oct;                   // first column of my items
     const unsigned int col_off = (unsigned int)(((colw >> 5) * 64 + (colw & 31)) * 2);   // X2: 8 hi halves here, the 8 lo halves 64 B on
     float cmax[2] = {-3.4e38f, -3.4e38f};
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
 #pragma unroll
@@ -442,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
         const float cm = fmaxf(cmax[u], __shfl_xor(cmax[u], 32));
         if (g == 0 && lim > 0) atomic_max_float(p.colmax + (size_t)group * p.N + n0 + 64 * wn + 32 * u + mi, cm);
       }
+    }
     }
     if (!have_next) break;
     if constexpr (!LIFT) {

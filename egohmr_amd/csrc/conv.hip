@@ -561,10 +561,10 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
     };
     [[maybe_unused]] auto pin16 = [&](int reads, int dmas) __attribute__((always_inline)) {   // reads one per MFMA from the start, DMAs behind them
 #pragma unroll
-      for (int i = 0; i < 9 * NU; ++i) {
+      for (int i = 0; i < 9 * NU; ++i) {                          // reads behind every second MFMA, DMAs in the gaps (as in gcn_tile.hip)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        else if (i - reads < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        if ((i & 1) == 0 && (i >> 1) < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if ((i & 1) == 1 && (i >> 1) < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
     };
     // K tile j of the piece (parity PAR = j & 1 = its stage).  Phases (0, cf) (0, cs) | barrier | (1, cs) (1, cf) with cf = PAR: the next tile's first phase

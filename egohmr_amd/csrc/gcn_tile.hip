@@ -1,7 +1,10 @@
 // Modulated-GCN hidden conv (_GraphConv hid -> hid, modulated_gcn.py:21-28 / modulated_gcn_conv.py:39-50, + the residual of
 // _ResGraphConv, modulated_gcn.py:38-42) on the f16 matrix cores of gfx950, two arithmetic modes from one tile engine:
-//   P = 3  "f16x3": both GEMM operands stored as hi + lo f16 pairs (X2<32>, gcn_dev.h), three v_mfma_f32_32x32x16_f16 per
-//          product (lo*hi + hi*lo + hi*hi), f32 accumulate: 22-bit operands, f32-grade results (the parity path);
+//   P = 3  "f16x3": both GEMM operands stored as hi + lo f16 pairs (X2<32>, gcn_dev.h), three MFMAs per product
+//          (lo*hi + hi*lo + hi*hi), f32 accumulate: 22-bit operands, f32-grade results (the parity path).  Since round 5 on
+//          v_mfma_f32_16x16x32_f16: at the socket's power cap - where this kernel runs - the matrix pipe sustains 2.26 PFLOP/s
+//          in that form against 1.86 as 32x32x16 on the same operands (tools/mfma_ceiling.py: a quarter of the accumulator
+//          traffic per MAC); chain kernel 1014 -> 905 us per launch, same box.  See "16 x 16 x 32" in run_tiles;
 //   P = 1  "f16":   plain f16 storage [rows][hid] and one MFMA per product (BASELINE config 5's fp16 denoiser, and the early
 //          steps of the precision schedule).
 // Tile = 192 rows (8 bodies x 24 joints) x 64 channels x both branches (W0 | W1); 4 waves as 2 x 2, 96 x 32(x2) per wave;
@@ -561,7 +564,13 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     Frags<P> f0, f1;
     if constexpr (!M16) read_frags(f0, 0, 0);
     TSTAMP(1);
-    // ---- EHM_EXP_MFMA16: operand halves A[rh] (row tiles 3 rh .. + 2 of 16 rows), B[ch] (branch ch: two 16-channel column tiles), 6 x 4 accumulators
+    // ---- 16 x 16 x 32 (split-f16 mode).  A K tile (32 k) is ONE k-step of this instruction: lane (i = l & 15, kg = l >> 4) holds row i of a 16-row tile and
+    // the 16-byte chunk kg (hi halves) / 4 + kg (lo halves) of the tile's 128-byte rows - one ds_read_b128 per 16 x 32 operand block, 20 per K tile and wave
+    // as before, for 72 MFMAs instead of 36.  A wave's 96 x 32 (x 2 branches) tile = 6 row tiles x 4 column tiles = 24 f32x4 accumulators (the same 96
+    // registers).  Holding a whole K tile's fragments twice would cost 160 registers; instead a K tile runs as four phases (row half rh, branch ch) of 18
+    // MFMAs in SNAKE order - (0,0) (0,1) (1,1) (1,0), then (0,1) (0,0) (1,0) (1,1) for the next K tile, and so on - so that consecutive phases share one
+    // operand half and the other is refilled from LDS while it is not in use: 80 fragment registers, nothing double-buffered.
+    // Operand halves A[rh] (row tiles 3 rh .. + 2 of 16 rows), B[ch] (branch ch: two 16-channel column tiles), 6 x 4 accumulators
     [[maybe_unused]] half8 Ah[2][3], Al[2][3], Bh[2][2], Bl[2][2];
     typedef float f32x4a __attribute__((ext_vector_type(4)));
     [[maybe_unused]] f32x4a c16[6][4];
@@ -598,12 +607,14 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) c16[3 * rh + t][2 * ch + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[rh][t], Bh[ch][u], c16[3 * rh + t][2 * ch + u], 0, 0, 0);
     };
-    [[maybe_unused]] auto pin16 = [&](int reads, int dmas) {          // reads one per MFMA from the start, DMAs one per MFMA behind them
+    // LDS reads behind every second MFMA of a phase, DMA instructions in the gaps between them (same box: 918 -> 903 us per launch against
+    // "reads one per MFMA from the start, DMAs behind them"; no pinning at all measured like the latter)
+    [[maybe_unused]] auto pin16 = [&](int reads, int dmas) {
 #pragma unroll
       for (int i = 0; i < 18; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        else if (i - reads < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        if ((i & 1) == 0 && (i >> 1) < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if ((i & 1) == 1 && (i >> 1) < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
     };
     typedef std::integral_constant<int, 0> I0;

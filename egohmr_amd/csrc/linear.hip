@@ -369,10 +369,10 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     [[maybe_unused]] auto pin16 = [&](int reads, int dmas) __attribute__((always_inline)) {          // reads one per MFMA from the start, DMAs one per MFMA behind them
       if constexpr (RELU_A) return;                               // (the rectifying loads are left to the scheduler)
 #pragma unroll
-      for (int i = 0; i < 18; ++i) {
+      for (int i = 0; i < 18; ++i) {                          // reads behind every second MFMA, DMAs in the gaps (as in gcn_tile.hip)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        else if (i - reads < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        if ((i & 1) == 0 && (i >> 1) < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if ((i & 1) == 1 && (i >> 1) < dmas) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
     };
     // one K tile of parity PAR = kt & 1 (stage kt & 1).  Phases (0, cf) (0, cs) | barrier | (1, cs) (1, cf) with cf = PAR: the next tile's first phase is

@@ -73,9 +73,7 @@ def test_tile_engines_keep_two_blocks_per_cu(kernels):
         assert k[".max_flat_workgroup_size"] == 256, name
         assert k[".group_segment_fixed_size"] <= 80 * 1024, f"{name}: {k['.group_segment_fixed_size']} bytes of LDS - the second block of a CU does not fit"
         assert _regs(k) <= 256, f"{name}: {k['.vgpr_count']} VGPRs + {k.get('.agpr_count', 0)} AGPRs - one wave per SIMD only"
-        # (the split-f16 chain kernel keeps a dozen dwords of its tile bookkeeping in scratch - none of it inside the K loop; everything else none)
-        allowed = 32 if "gcn_hidden_chain_kernelILi3ELi4E" in name else 0
-        assert k[".private_segment_fixed_size"] <= allowed, f"{name}: {k['.private_segment_fixed_size']} bytes of scratch per lane"
+        assert k[".private_segment_fixed_size"] == 0, f"{name}: {k['.private_segment_fixed_size']} bytes of scratch per lane"
     assert seen >= 20, f"{seen} tile-engine kernels matched: the name patterns are stale"
 
 

@@ -95,7 +95,7 @@ class LinearDesc(C.Structure):
     _fields_ = [("A0", C.c_void_p), ("A1", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("group_bias", C.c_void_p),
                 ("Y", C.c_void_p), ("colmax", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K0", C.c_int), ("K1", C.c_int),
                 ("rows_per_group", C.c_int), ("valid_rows_per_group", C.c_int), ("relu_in0", C.c_int), ("relu_out", C.c_int),
-                ("w_scale", C.c_float), ("lift_points", C.c_void_p), ("lift_W4", C.c_void_p), ("hi_only", C.c_int)]
+                ("w_scale", C.c_float), ("lift_points", C.c_void_p), ("lift_W4", C.c_void_p), ("hi_only", C.c_int), ("group_bias_stride", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -112,7 +112,8 @@ class ConvX2Desc(C.Structure):
                 ("N", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("Ci", C.c_int), ("Co", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("relu", C.c_int),
                 ("w_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("x2", C.c_void_p), ("x2_rows", C.c_int64), ("H2", C.c_int), ("W2", C.c_int), ("Ci2", C.c_int), ("stride2", C.c_int), ("hi_only", C.c_int)]
+                ("x2", C.c_void_p), ("x2_rows", C.c_int64), ("H2", C.c_int), ("W2", C.c_int), ("Ci2", C.c_int), ("stride2", C.c_int), ("hi_only", C.c_int),
+                ("workspace_clean", C.c_int)]
 
 
 class ItemPrepDesc(C.Structure):

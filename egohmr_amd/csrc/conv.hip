@@ -243,7 +243,7 @@ struct ConvX2Args {
   // stream-K (SK = true): the tiles' K tiles are dealt out to the blocks as ONE sequence in equal contiguous runs (pairs of K tiles), so a
   // tile may be computed by two or three blocks; the block that holds a tile's FIRST K tiles finishes it (adds the others' partial sums in k
   // order, epilogue), the others leave their accumulators in sk_part and count in sk_flags.
-  unsigned int* sk_flags;      // [tiles], zeroed by ehm_conv_x2
+  unsigned int* sk_flags;      // [cut tiles] arrival counters: zero at launch, zeroed again by the block that consumed them (bit 31: poisoned by a time-out)
   float* sk_part;              // [tiles][kSkMaxParts][acc floats per thread][256]
   int sk_per;                  // pairs of K tiles per block
   int sk_rounds;               // whole tiles first: rounds [0, sk_rounds) of the grid run one whole tile per block (the plain schedule), only the tiles BEHIND them - the
@@ -256,6 +256,7 @@ struct ConvX2Args {
   unsigned int zero_off2;
 };
 constexpr int kSkMaxParts = 3;
+constexpr int kSkFlagBytes = 4096;         // arrival counters of up to 1024 cut tiles at the head of the workspace
 constexpr int kSkHandoffKTiles = 14;   // what a cut tile's hand-off costs, in K-tile times (measured, see sk_plan)
 
 template <int NU>
@@ -717,8 +718,13 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
         // looks at the (monotonic) counter itself and poisons through the bias term (every output is acc * inv_scale + add): __syncthreads_or
         // brings its own LDS word, and with 80 KiB + 4 bytes the kernel lost its second block per CU (hipcc then spent 183 VGPRs + 96 AGPRs);
         // writing NaN into the 96 accumulators has the same effect on the register budget.
-        const bool missing = __hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect;
+        const unsigned int seen = __hip_atomic_load(p.sk_flags + pc.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool missing = seen < expect || (seen & 0x80000000u) != 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the counter goes back to zero for the next conv on this workspace (no memset node per launch: ehm_conv_x2_desc.workspace_clean); after a time-out it
+        // stays poisoned - a partner may still arrive late, and a later launch must not take its count for its own
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.sk_flags + pc.tile, missing ? 0x80000000u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (missing) {
 #pragma unroll
           for (int u = 0; u < NADD; ++u) add[u] = __builtin_nanf("");
@@ -983,7 +989,8 @@ SkPlan sk_plan(const ehm_conv_x2_desc* d, int Ho, int Wo) {
     return s;
   }
   s.on = true;
-  s.flag_bytes = round_up(s.cut_tiles * 4, 256);
+  if (s.cut_tiles * 4 > kSkFlagBytes) { s.on = false; return s; }
+  s.flag_bytes = kSkFlagBytes;                 // (a fixed region at the head of the workspace: convs of different shapes share one workspace and one zeroing)
   s.bytes = s.flag_bytes + s.cut_tiles * kSkMaxParts * s.nacc * 256 * 4;
   return s;
 }
@@ -1043,7 +1050,7 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
     a.sk_part = (float*)((char*)d->workspace + sk.flag_bytes);
     a.sk_per = sk.per;
     a.sk_rounds = sk.rounds;
-    EHM_HIP(hipMemsetAsync(a.sk_flags, 0, (size_t)sk.flag_bytes, (hipStream_t)stream));
+    if (!d->workspace_clean) EHM_HIP(hipMemsetAsync(a.sk_flags, 0, (size_t)sk.flag_bytes, (hipStream_t)stream));
     const dim3 grid((unsigned)sk.blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (d->hi_only) {

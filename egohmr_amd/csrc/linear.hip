@@ -35,6 +35,7 @@ struct LinArgs {
   int rows_per_group, valid_rows_per_group;
   int relu_in0, relu_out;
   float inv_scale;
+  int gstride;                                          // floats between the rows of gbias
 };
 
 struct LFrags {
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void linear_tile_kernel(LinArgs p) {
     for (int u = 0; u < (M16 ? 4 : 2); ++u) {
       const int col = M16 ? n0 + 64 * wn + 16 * u + (lane & 15) : n0 + 64 * wn + 32 * u + mi;
       add[u] = p.bias ? p.bias[col] : 0.f;
-      if (p.gbias) add[u] += p.gbias[(size_t)group * p.N + col];
+      if (p.gbias) add[u] += p.gbias[(size_t)group * p.gstride + col];
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (M16) {
@@ -679,6 +680,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_f32_kernel(const float* _
   const bool row_ok = row < M;
   const float* xa = X + (size_t)(row_ok ? row : 0) * K + k_begin + 4 * h;
   const float* wb = W + (size_t)(k_begin + 4 * h) * N + n0 + mi;
+  // `relu`: bit 0 = max(., 0) on the output; relu >> 1 = the number of leading output columns whose INPUT is rectified first (two products of one
+  // vector in one launch: [relu(x) . Wa | x . Wb], the per-body vectors of a PointNet block)
+  const bool relu_in = n0 < (relu >> 1);                          // (block-uniform)
+  relu &= 1;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -686,6 +691,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_f32_kernel(const float* _
   for (int k = 0; k < kq; k += 8) {
     f32x4 a = *(const f32x4*)(xa + k);
     if (!row_ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (relu_in) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = fmaxf(a[i], 0.f);
+    }
     float b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) b[i] = wb[(size_t)(k + i) * N];
@@ -823,6 +832,8 @@ extern "C" int ehm_linear_split(const ehm_linear_desc* d, void* stream) {
   a.rows_per_group = d->rows_per_group;
   a.valid_rows_per_group = d->valid_rows_per_group > 0 ? d->valid_rows_per_group : d->rows_per_group;
   a.relu_in0 = d->relu_in0; a.relu_out = d->relu_out; a.inv_scale = 1.f / d->w_scale;
+  EHM_CHECK_ARG(d->group_bias_stride == 0 || d->group_bias_stride >= d->N);
+  a.gstride = d->group_bias_stride > 0 ? d->group_bias_stride : d->N;
   const int64_t tiles = (d->M / LBM) * (d->N / LBN);
   int64_t blocks = 2 * (int64_t)ehm_num_cus();            // what is co-resident (80 KiB of LDS per block)
   if (blocks > tiles) blocks = tiles;

@@ -189,8 +189,8 @@ class ResNet50Features(nn.Module):
             if need:
                 ws = sk_ws.get(str(x.device))
                 if ws is None or ws.numel() < need:
-                    ws = sk_ws[str(x.device)] = torch.empty(need, dtype=torch.uint8, device=x.device)
-                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+                    ws = sk_ws[str(x.device)] = torch.zeros(need, dtype=torch.uint8, device=x.device)   # zeroed ONCE: the convs leave their counters zeroed
+                d.workspace, d.workspace_bytes, d.workspace_clean = ws.data_ptr(), ws.numel(), 1
             _lib.check(_lib.lib().ehm_conv_x2(C.byref(d), _lib.stream_ptr()), "ehm_conv_x2")
             if _x2_debug_hook is not None:
                 _x2_debug_hook(y, Co)
@@ -298,9 +298,11 @@ class ResnetPointnet(nn.Module):
             W0, S = d(bl.fc_0.weight), d(bl.shortcut.weight)
             P[f"g1_{i}"] = self._pack(W0[:, :H], device)
             P[f"g3_{i}"] = self._pack(torch.cat([d(bl.fc_1.weight), S[:, :H]], dim=1), device) + (bl.fc_1.bias.detach().float().contiguous(),)
-            # pooled halves: per-body bias vectors, [B,H] x [H,H] in exact float32 (ehm_skinny_gemm_f32 wants W as [K,N])
-            P[f"w0bT_{i}"], P[f"b0_{i}"] = W0[:, H:].t().float().contiguous().to(device), bl.fc_0.bias.detach().float().contiguous().to(device)
-            P[f"sbT_{i}"] = S[:, H:].t().float().contiguous().to(device)
+            # pooled halves: per-body bias vectors [relu(pooled) . W0b^T + b0 | pooled . Sb^T], [B,H] x [H,2H] in exact float32 and ONE launch
+            # (ehm_skinny_gemm_f32 wants W as [K,N]; its `relu` argument rectifies the input for the first H output columns)
+            P[f"wvsT_{i}"] = torch.cat([W0[:, H:].t(), S[:, H:].t()], dim=1).float().contiguous().to(device)
+            b0v = bl.fc_0.bias.detach().float()
+            P[f"bvs_{i}"] = torch.cat([b0v, torch.zeros_like(b0v)]).contiguous().to(device)
         P["fc_cT"], P["fc_cb"] = d(self.fc_c.weight).t().float().contiguous().to(device), self.fc_c.bias.detach().float().contiguous().to(device)
         self._packed, self._packed_key = P, key
         return P
@@ -327,39 +329,42 @@ class ResnetPointnet(nn.Module):
         p = p.contiguous()
         _lib.check(L.ehm_pointnet_lift(p.data_ptr(), None, None, None, P32.data_ptr(), B, N, Np, 2 * H, st), "ehm_pointnet_lift")
 
-        def gemm(A0, K0, A1, K1, W, bias, gbias, Y, colmax, relu_in0, relu_out, lift=False):
+        def gemm(A0, K0, A1, K1, W, bias, gbias, Y, colmax, relu_in0, relu_out, lift=False, gstride=0):
             d = _lib.LinearDesc(A0=A0.data_ptr() if A0 is not None else None, A1=A1.data_ptr() if A1 is not None else None, W=W[0].data_ptr(),
                                 lift_points=p.data_ptr() if lift else None, lift_W4=P["pos_w4"].data_ptr() if lift else None,
                                 bias=bias.data_ptr() if bias is not None else None,
                                 group_bias=gbias.data_ptr() if gbias is not None else None,
                                 Y=Y.data_ptr() if Y is not None else None, colmax=colmax.data_ptr() if colmax is not None else None,
                                 M=M, N=H, K0=K0, K1=K1, rows_per_group=Np, valid_rows_per_group=N, relu_in0=int(relu_in0),
-                                relu_out=int(relu_out), w_scale=W[1], hi_only=int(bool(self.hi_only)))
+                                relu_out=int(relu_out), w_scale=W[1], hi_only=int(bool(self.hi_only)), group_bias_stride=gstride)
             _lib.check(L.ehm_linear_split(d, st), "ehm_linear_split")
             if Y is not None and _x2_debug_hook is not None:
                 _x2_debug_hook(Y, H)
 
-        def small(x, Wt, bias):
+        def small(x, Wt, bias, relu_in_cols=0):
             """[B,K] x [K,N] (+ bias) in exact float32: the per-body vectors between the big GEMMs.  The BLAS ran each of these
-            256 x 256 x 256 products as one 256 x 256 workgroup (170 - 450 us, on the PointNet's critical path)."""
+            256 x 256 x 256 products as one 256 x 256 workgroup (170 - 450 us, on the PointNet's critical path).
+            relu_in_cols: the first that many output columns see relu(x)."""
             y = torch.empty(x.shape[0], Wt.shape[1], device=dev)
-            _lib.check(L.ehm_skinny_gemm_f32(x.contiguous().data_ptr(), Wt.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                             x.shape[0], Wt.shape[0], Wt.shape[1], 0, st), "ehm_skinny_gemm_f32")
+            _lib.check(L.ehm_skinny_gemm_f32(x.data_ptr(), Wt.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                             x.shape[0], Wt.shape[0], Wt.shape[1], relu_in_cols << 1, st), "ehm_skinny_gemm_f32")
             return y
 
         neg_inf = float("-inf")
         # block_0 on net0 = fc_pos(p):  h = fc_0(relu(net0));  net1 = fc_1(relu(h)) + shortcut(net0)
         # (relu(net0) is produced inside the GEMM's loader from the 12 bytes of each point: ehm_linear_desc.lift_points)
         gemm(None, 2 * H, None, 0, P["g1_0"], P["g1_0"][3], None, Hb, None, False, True, lift=True)
-        pooled = torch.full((B, H), neg_inf, device=dev)
+        pooled_all = torch.full((4, B, H), neg_inf, device=dev)                         # the four column maxima, cleared by one launch
+        pooled = pooled_all[0]
         gemm(Hb, H, P32, 32, P["g3_0"], P["g3_0"][3], None, netA, pooled, False, False)
         cur, nxt = netA, netB
         for i in (1, 2, 3):
-            v = small(torch.relu(pooled), P[f"w0bT_{i}"], P[f"b0_{i}"])                    # pooled half of fc_0(relu(cat[net, pooled]))
-            s = small(pooled, P[f"sbT_{i}"], None)                                        # pooled half of shortcut(cat[net, pooled])
-            gemm(cur, H, None, 0, P[f"g1_{i}"], None, v, Hb, None, True, True)
-            pooled = torch.full((B, H), neg_inf, device=dev)
-            gemm(Hb, H, cur, H, P[f"g3_{i}"], P[f"g3_{i}"][3], s, nxt if i < 3 else None, pooled, False, False)
+            # pooled halves of fc_0(relu(cat[net, pooled])) and of shortcut(cat[net, pooled]): one launch, [B, 2H]
+            vs = small(pooled, P[f"wvsT_{i}"], P[f"bvs_{i}"], relu_in_cols=H)
+            v, s = vs[:, :H], vs[:, H:]
+            gemm(cur, H, None, 0, P[f"g1_{i}"], None, v, Hb, None, True, True, gstride=2 * H)
+            pooled = pooled_all[i]
+            gemm(Hb, H, cur, H, P[f"g3_{i}"], P[f"g3_{i}"][3], s, nxt if i < 3 else None, pooled, False, False, gstride=2 * H)
             cur, nxt = nxt, cur
-        return small(F.relu(pooled), P["fc_cT"], P["fc_cb"])
+        return small(pooled, P["fc_cT"], P["fc_cb"], relu_in_cols=P["fc_cT"].shape[1])
 

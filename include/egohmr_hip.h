@@ -208,6 +208,7 @@ typedef struct {
                               (respointnet.py:35,:90) folded into the loader; then A0 == NULL, K1 == 0, relu_in0 == 0 */
   const float* lift_W4;    /* [K0][4] float32 rows (w_x, w_y, w_z, bias) of fc_pos                   */
   int hi_only;             /* 1 = the plain-f16 tier (NOT parity grade): hi halves of A0 / A1 / W only, hi halves of Y only; 0 = split-f16 (f32 grade) */
+  int group_bias_stride;   /* floats between the rows of group_bias; 0 = N (dense).  Lets two blocks' per-body vectors come out of one small GEMM */
 } ehm_linear_desc;
 int ehm_linear_split(const ehm_linear_desc* d, void* stream);
 /* float32 [rows,K] -> X2 [rows,K_padded] (zero padded), values multiplied by `scale` (1 for activations). */
@@ -221,7 +222,9 @@ int ehm_pointnet_lift(const float* pts, const float* Wpos, const float* bpos, vo
 /* Y[M,N] = act(X[M,K] . W[K,N] + bias[N]) in exact float32 on the matrix cores, for short M (batches of feature vectors): the
  * step-invariant slices of the input graph conv (models/egohmr/modulated_gcn/modulated_gcn_conv.py:39-50 on the image / scene
  * features) and the beta head's first layer (models/egohmr/egohmr.py:263-265, fc_head_beta).  K % 32 == 0, N % 32 == 0, any M;
- * X 16-byte aligned; bias may be NULL; relu != 0 applies max(., 0).  Deterministic (no atomics). */
+ * X 16-byte aligned; bias may be NULL.  relu: bit 0 applies max(., 0) to the output; relu >> 1 = number of leading output columns (a multiple of 32)
+ * whose INPUT row is rectified first - [relu(x) . Wa | x . Wb] in one launch (the pooled halves of a ResnetBlockFC's fc_0 and shortcut,
+ * models/respointnet.py:41-51).  Deterministic (no atomics). */
 int ehm_skinny_gemm_f32(const float* X, const float* W, const float* bias, float* Y, int M, int K, int N, int relu, void* stream);
 
 
@@ -271,6 +274,9 @@ typedef struct ehm_conv_x2_desc {
   int H2, W2, Ci2, stride2;
   int hi_only;               /* 0 = split-f16 arithmetic (f32 grade, the parity path).  1 = the plain-f16 tier (NOT parity grade): only the hi halves of x, W,
                                 residual are read and only hi halves written - one MFMA per product, half the bytes; the lo halves of y are don't-care  */
+  int workspace_clean;       /* 1 = the caller zeroed the first 4096 bytes of `workspace` once and nothing but ehm_conv_x2 has written to it since: the call
+                                skips its memset node (every call leaves the arrival counters zeroed - or poisoned, after a hand-off time-out: then every later
+                                stream-K conv on that workspace comes out as NaN until the caller zeroes it again).  0 = the call clears them itself */
 } ehm_conv_x2_desc;
 int64_t ehm_conv_x2_rows(int64_t pixels);
 /* Scratch of the stream-K schedule: when a conv's tile count would leave a large share of the GPU's block slots idle in its last round

@@ -22,7 +22,7 @@ namespace {
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
-constexpr int LBM = 192, LBN = 128;       // output tile; 4 waves as 2 x 2, 96 x 64 per wave (3 x 2 MFMA blocks of 32 x 32)
+constexpr int LBM = 192, LBN = 128;       // output tile; 4 waves as 2 x 2, 96 x 64 per wave (6 x 4 MFMA blocks of 16 x 16; hi-only tier: 3 x 2 of 32 x 32)
 constexpr int RK = BK;                    // floats per operand row and K tile (X2: 32 hi halves | 32 lo halves = 128 bytes)
 constexpr int LA_T = LBM * RK, LB_T = LBN * RK, LSTG = LA_T + LB_T;   // floats; one stage = 40 KiB
 

@@ -632,6 +632,68 @@ def test_conv_x2_vs_torch_fp64(dev, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
+    (5, 8, 8, 128, 256, 1, 2, True, True),      # strided 1x1 with residual, two column tiles
+    (2, 15, 15, 64, 64, 3, 1, False, True),     # 3x3 with borders, the narrow column tile
+    (18, 56, 56, 256, 128, 3, 1, True, True),   # the stream-K schedule
+])
+def test_conv_x2_hi_only_tier_vs_torch_fp64(dev, case):
+    """ehm_conv_x2_desc.hi_only = 1 (the plain-f16 tier of the encoders, BASELINE config 5): the same kernel with the hi halves of x, W and the residual
+    only and hi halves written - one MFMA per product.  NOT a parity path: checked against float64 at the precision of f16 operands."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from egohmr_amd import _lib
+    N, H, W, Ci, Co, k, stride, has_res, relu = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, H, W, Ci, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Ho, Wo, Co, generator=g) if has_res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if has_res:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    L = _lib.lib()
+
+    def to_x2(t, pixels, ch):
+        rows = int(L.ehm_conv_x2_rows(pixels))
+        src = torch.zeros(rows, ch)
+        src[:pixels] = t.reshape(pixels, ch)
+        src, dst = src.to(dev), torch.empty(rows, ch, device=dev)
+        _lib.check(L.ehm_split_pack(src.data_ptr(), dst.data_ptr(), rows, ch, ch, 1.0, None))
+        return dst
+
+    xd = to_x2(x, N * H * W, Ci)
+    rd = to_x2(res, N * Ho * Wo, Co) if has_res else None
+    K, Co_pad = k * k * Ci, (Co + 127) // 128 * 128
+    w2 = torch.zeros(Co_pad, K)
+    w2[:Co] = w.permute(0, 2, 3, 1).reshape(Co, K)
+    wd, wbuf = w2.to(dev), torch.empty(Co_pad, K, device=dev)
+    _lib.check(L.ehm_split_pack(wd.data_ptr(), wbuf.data_ptr(), Co_pad, K, K, 256.0, None))
+    bd = bias.to(dev)
+    rows_out = int(L.ehm_conv_x2_rows(N * Ho * Wo))
+    y = torch.zeros(rows_out, Co, device=dev)                     # (lo halves stay zero: the unpack below then returns the hi halves alone)
+    d = _lib.ConvX2Desc(xd.data_ptr(), xd.shape[0], wbuf.data_ptr(), bd.data_ptr(), rd.data_ptr() if has_res else None, y.data_ptr(),
+                        N, H, W, Ci, Co, k, k, stride, pad, int(relu), 256.0, None, 0)
+    d.hi_only = 1
+    need = int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    if need:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    _lib.check(L.ehm_conv_x2(C.byref(d), None), "ehm_conv_x2")
+    out = torch.empty(rows_out, Co, device=dev)
+    _lib.check(L.ehm_gcn_unpack_activations(y.data_ptr(), out.data_ptr(), rows_out, Co, 32, None))
+    torch.cuda.synchronize()
+    got = out[:N * Ho * Wo].cpu().double().reshape(N, Ho, Wo, Co)
+    err = (got - ref).abs().max().item()
+    print(f"[conv_x2 hi-only {case}] max|err| vs fp64 = {err:.3e} (|y|max = {ref.abs().max().item():.2f})")
+    assert err < 1e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
     # N, Ho, Wo, Ci (main 1x1), Ci2 (shortcut input), stride2, Co
     (3, 56, 56, 64, 64, 1, 256),       # layer 1 block 0: shortcut on the same grid
     (3, 28, 28, 128, 256, 2, 512),     # layer 2 block 0: the shortcut samples every second pixel of a 56 x 56 input

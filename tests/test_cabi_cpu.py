@@ -165,3 +165,34 @@ def test_default_library_has_no_experiment_and_no_env_switch_on_the_launch_path(
                 sites.append((os.path.basename(path), ln, st))
     assert [(f, s.split('getenv("')[1].split('"')[0]) for f, _, s in sites] == [("gcn.hip", "EHM_F16_CHAIN")], sites
     assert not os.path.exists(os.path.join(REPO, "tools", "jobs"))
+
+
+def test_conv_x2_stream_k_plans_at_the_benchmark_batch():
+    """Host logic of csrc/conv.hip::sk_plan, no GPU needed (ehm_conv_x2_workspace_bytes only plans; without a device the library assumes an MI355X: 256 CUs = 512
+    block slots).  At N = 256 images ResNet-50's layers 2 - 4 land just above a multiple of the slots; which convs are cut into K runs, and how much scratch that takes:
+      * K loops of >= 64 K tiles with about one round of tiles or less: every tile is cut (layer 3 / 4 3x3 convs, layer 4's 1x1 2048 -> 512);
+      * otherwise, one whole round or more + a partly filled one: only the tail is cut, and only where the hand-off (~14 K-tile times) pays: K loops of >= 32 K tiles;
+      * everything else runs whole tiles (0 bytes)."""
+    import ctypes as C
+    from egohmr_amd import _lib
+    L = _lib.lib()
+
+    def need(H, Ci, Co, k, stride=1, Ci2=0):
+        d = _lib.ConvX2Desc(None, 0, None, None, None, None, 256, H, H, Ci, Co, k, k, stride, k // 2, 1, 256.0, None, 0)
+        if Ci2:
+            d.x2, d.H2, d.W2, d.Ci2, d.stride2 = 1, 2 * H - 1, 2 * H - 1, Ci2, 2          # (any non-NULL pointer: planning does not touch it)
+        return int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))
+
+    flags, part = 4096, 3 * 96 * 256 * 4                      # arrival counters | partial sums per cut tile (three parts of 96 accumulators x 256 threads)
+    # every tile cut: 524 tiles x 72 K tiles (layer 3, 3x3), 264 x 144 (layer 4, 3x3), 264 x 64 (layer 4, 1x1 2048 -> 512)
+    assert need(14, 256, 256, 3) == flags + 524 * part
+    assert need(7, 512, 512, 3) == flags + 264 * part
+    assert need(7, 2048, 512, 1) == flags + 264 * part
+    # tail only: 524 tiles x 32 K tiles (layer 3, 1x1 1024 -> 256): 12 tiles behind one whole round; 1046 x 36 (layer 2, 3x3): 22 behind two rounds
+    assert need(14, 1024, 256, 1) == flags + 12 * part
+    assert need(28, 128, 128, 3) == flags + 22 * part
+    # the projection shortcut inside layer 4's first block (K = 512 + 1024: 48 K tiles, 1056 tiles): 32 behind two rounds
+    assert need(7, 512, 2048, 1, Ci2=1024) == flags + 32 * part
+    # whole tiles: short K loops (16 / 18 / 8 K tiles) lose more in the hand-off than the idle slots cost; full rounds have nothing to cut
+    for args in ((28, 512, 128, 1), (56, 64, 64, 3), (14, 256, 1024, 1), (7, 512, 2048, 1), (56, 64, 256, 1)):
+        assert need(*args) == 0, args

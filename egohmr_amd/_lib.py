@@ -194,6 +194,7 @@ PROTOTYPES = {
     "ehm_conv_x2_rows": (C.c_int64, [C.c_int64]),
     "ehm_conv_x2": (_I, [C.POINTER(ConvX2Desc), _P]),
     "ehm_conv_x2_workspace_bytes": (C.c_int64, [C.POINTER(ConvX2Desc)]),
+    "ehm_conv_x2_workspace_status": (_I, [_P, _P, _P]),
     "ehm_x2_group_mean": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ehm_conv_nhwc_split": (_I, [C.POINTER(ConvDesc), _P]),
     "ehm_nonlocal_attention": (_I, [_P, _P, _L, _I, _P]),

@@ -256,7 +256,8 @@ struct ConvX2Args {
   unsigned int zero_off2;
 };
 constexpr int kSkMaxParts = 3;
-constexpr int kSkFlagBytes = 4096;         // arrival counters of up to 1024 cut tiles at the head of the workspace
+constexpr int kSkFlagBytes = 4096;         // arrival counters of up to 1023 cut tiles at the head of the workspace ...
+constexpr int kSkPoisonWord = kSkFlagBytes / 4 - 1;   // ... and, in its last word, the sticky count of hand-off time-outs (ehm_conv_x2_workspace_status)
 constexpr int kSkHandoffKTiles = 14;   // what a cut tile's hand-off costs, in K-tile times (measured, see sk_plan)
 
 template <int NU>
@@ -724,7 +725,10 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
         // the counter goes back to zero for the next conv on this workspace (no memset node per launch: ehm_conv_x2_desc.workspace_clean); after a time-out it
         // stays poisoned - a partner may still arrive late, and a later launch must not take its count for its own
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(p.sk_flags + pc.tile, missing ? 0x80000000u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+          __hip_atomic_store(p.sk_flags + pc.tile, missing ? 0x80000000u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (missing) __hip_atomic_fetch_add(p.sk_flags + kSkPoisonWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky: the host's status call reports it and zeroes the counters
+        }
         if (missing) {
 #pragma unroll
           for (int u = 0; u < NADD; ++u) add[u] = __builtin_nanf("");
@@ -815,7 +819,8 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
           half8 hh, ll;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            if (relu) v[c] = fmaxf(v[c], 0.f);
+            // (stream-K: a poisoned tile must stay NaN through the ReLU - v_max_f32 returns its non-NaN operand)
+            if (relu) v[c] = SK ? (v[c] < 0.f ? 0.f : v[c]) : fmaxf(v[c], 0.f);
             hh[c] = (half_t)v[c];                              // (MODE.FP16_OVFL: the conversions saturate at +-65504, see the kernel's head)
             ll[c] = (half_t)(v[c] - (float)hh[c]);
           }
@@ -894,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void conv_x2_tile_kernel(ConvX2Args p) {
           half8 hh, ll;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            if (relu) v[c] = fmaxf(v[c], 0.f);
+            // (stream-K: a poisoned tile must stay NaN through the ReLU - v_max_f32 returns its non-NaN operand)
+            if (relu) v[c] = SK ? (v[c] < 0.f ? 0.f : v[c]) : fmaxf(v[c], 0.f);
             hh[c] = (half_t)v[c];                              // (MODE.FP16_OVFL: the conversions saturate at +-65504, see the kernel's head)
             ll[c] = (half_t)(v[c] - (float)hh[c]);
           }
@@ -989,7 +995,7 @@ SkPlan sk_plan(const ehm_conv_x2_desc* d, int Ho, int Wo) {
     return s;
   }
   s.on = true;
-  if (s.cut_tiles * 4 > kSkFlagBytes) { s.on = false; return s; }
+  if (s.cut_tiles > kSkPoisonWord) { s.on = false; return s; }
   s.flag_bytes = kSkFlagBytes;                 // (a fixed region at the head of the workspace: convs of different shapes share one workspace and one zeroing)
   s.bytes = s.flag_bytes + s.cut_tiles * kSkMaxParts * s.nacc * 256 * 4;
   return s;
@@ -1073,6 +1079,23 @@ extern "C" int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream) {
   else hipLaunchKernelGGL((conv_x2_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ehm_conv_x2_workspace_status(void* workspace, uint32_t* host_flag, void* stream) {
+  EHM_CHECK_ARG(workspace);
+  const unsigned int* word = (const unsigned int*)workspace + kSkPoisonWord;
+  if (host_flag) {                               // stream-ordered copy: the caller looks at *host_flag behind an event and calls again with NULL when it is non-zero
+    EHM_HIP(hipMemcpyAsync(host_flag, word, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+  }
+  unsigned int n = 0;
+  EHM_HIP(hipMemcpyAsync(&n, word, sizeof(n), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  EHM_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (n == 0) return 0;
+  EHM_HIP(hipMemsetAsync(workspace, 0, (size_t)kSkFlagBytes, (hipStream_t)stream));   // poisoned arrival counters + the count itself: the workspace is usable again
+  ehm_set_error("ehm_conv_x2: %u stream-K tile hand-off(s) on this workspace timed out since the last status call (GPU shared / preempted / under a profiler?): "
+                "those tiles - and every stream-K conv behind them - came out as NaN; the counters are zeroed again, re-run the batch", n);
+  return EHM_EIO;
 }
 
 extern "C" int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, int hi_only, void* stream) {

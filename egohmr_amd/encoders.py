@@ -71,6 +71,36 @@ class ResNet50Features(nn.Module):
         """The module call IS the HIP path (models/resnet.py:139-150 in eval mode); there is no eager route."""
         return self.current()(x)
 
+    # ------------------------------------------------------------------ stream-K hand-off time-outs (csrc/conv.hip): made loud, never waited for
+    def _sk_status_async(self, ws):
+        """Behind a trunk pass: a stream-ordered copy of the workspace's time-out count to pinned memory + an event.  An earlier pass's word
+        that has arrived is looked at first (no host wait on the product path)."""
+        if ws is None:                                     # (no conv of this pass had a stream-K plan)
+            return
+        ev = getattr(self, "_sk_event", None)
+        if ev is not None and ev.query():
+            self.check_status()
+        if getattr(self, "_sk_host", None) is None:
+            self._sk_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _lib.check(_lib.lib().ehm_conv_x2_workspace_status(ws.data_ptr(), self._sk_host.data_ptr(), _lib.stream_ptr()), "ehm_conv_x2_workspace_status")
+        self._sk_event = torch.cuda.Event()
+        self._sk_event.record()
+        self._sk_ws_checked = ws
+
+    def check_status(self):
+        """Raise if a stream-K conv of an earlier trunk pass timed out waiting for a partner block's partial sums (its tiles are NaN and the
+        workspace's counters poisoned); the workspace is zeroed again by the call, so the next pass is clean.  Waits for that pass."""
+        ev = getattr(self, "_sk_event", None)
+        if ev is None:
+            return
+        ev.synchronize()
+        self._sk_event = None
+        if int(self._sk_host[0]) != 0:
+            self._sk_host.zero_()
+            ws = self._sk_ws_checked
+            with torch.cuda.device(ws.device):
+                _lib.check(_lib.lib().ehm_conv_x2_workspace_status(ws.data_ptr(), None, _lib.stream_ptr()), "ehm_conv_x2_workspace_status")
+
     # ------------------------------------------------------------------ inference form: BatchNorm folded into the convolutions
     @torch.no_grad()
     def folded(self, x2_activations: bool = True, fuse_shortcut: bool = True):
@@ -213,6 +243,7 @@ class ResNet50Features(nn.Module):
             out = torch.empty(N, x.shape[1], device=x.device)
             _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], int(bool(self.hi_only)), _lib.stream_ptr()),
                        "ehm_x2_group_mean")
+            self._sk_status_async(sk_ws.get(str(x.device)))
             return out
 
         def run(x):

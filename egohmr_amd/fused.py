@@ -815,10 +815,13 @@ class FusedSampler:
                 self._status_event.record()
             else:
                 _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
+                m.backbone.check_status()                 # (the stream has been waited for: the trunk's stream-K time-out word is there)
         return {"sample": x_final, "pred_xstart": x0, "other_outputs": out}
 
     def check_status(self):
-        """Raise if a sampling call issued with defer_status=True flagged its chained launches (see run()).  Waits for that call."""
+        """Raise if a sampling call issued with defer_status=True flagged its chained launches (see run()), or if a stream-K conv of the ResNet-50
+        trunk timed out in a hand-off (ResNet50Features.check_status).  Waits for that call."""
+        self.model.backbone.check_status()
         ev = getattr(self, "_status_event", None)
         if ev is None:
             return

@@ -284,6 +284,13 @@ int64_t ehm_conv_x2_rows(int64_t pixels);
  * cut by a run boundary is finished by the block that started it (fixed summation order: deterministic).  0 = the conv runs whole tiles. */
 int64_t ehm_conv_x2_workspace_bytes(const ehm_conv_x2_desc* d);
 int ehm_conv_x2(const ehm_conv_x2_desc* d, void* stream);
+/* Did a stream-K tile hand-off on `workspace` time out since the last call (a partner block did not deliver its partial sums within ~1 s: GPU shared,
+ * preempted, under a profiler)?  Such a tile is written as NaN (through the ReLU as well), its arrival counter stays poisoned so that every later
+ * stream-K conv on the workspace is NaN too, and the LAST word of the workspace's first 4096 bytes counts the time-outs (sticky on the device).
+ *   host_flag != NULL : enqueue a stream-ordered copy of that count to *host_flag (pinned host memory) and return 0 - the asynchronous form;
+ *   host_flag == NULL : wait for the stream, and when the count is non-zero zero the 4096 counter bytes again (the workspace is clean) and return -5 (EIO).
+ * The torchvision convolution this replaces cannot fail (models/resnet.py:139-150); this is the hand-off protocol's own failure mode made loud. */
+int ehm_conv_x2_workspace_status(void* workspace, uint32_t* host_flag, void* stream);
 /* Y[g, c] = mean over the rows_per_group consecutive rows of group g of the X2 matrix X [groups*rows_per_group (+ padding), C]:
  * the global average pool behind the last bottleneck (models/resnet.py:148-149). */
 int ehm_x2_group_mean(const void* X, float* Y, int groups, int rows_per_group, int C, int hi_only /* 1: X was written by a hi_only call */, void* stream);

@@ -631,6 +631,58 @@ def test_conv_x2_vs_torch_fp64(dev, case):
 
 
 @pytest.mark.gpu
+def test_conv_x2_stream_k_timeout_is_nan_through_relu_and_reported(dev):
+    """A stream-K tile whose partners' partial sums cannot be trusted (arrival counter poisoned by an earlier hand-off time-out) comes out as NaN although
+    the conv ends in a ReLU (v_max_f32 would turn NaN into 0), the workspace counts it, ehm_conv_x2_workspace_status reports it once and zeroes the counters,
+    and the next call on the same workspace is right again (round-5 advisor finding: silent zero tiles for the rest of the process)."""
+    import ctypes as C
+    from egohmr_amd import _lib
+    L = _lib.lib()
+    N, H, W, Ci, Co, k = 256, 14, 14, 1024, 256, 1          # layer 3's first conv: 524 tiles on 512 slots - the 12 tiles of the tail are cut into K runs
+    g = torch.Generator(device=dev).manual_seed(3)
+    rows = int(L.ehm_conv_x2_rows(N * H * W))
+    src = torch.randn(rows, Ci, device=dev, generator=g)
+    src[rows - 1].zero_()
+    xd = torch.empty_like(src)
+    _lib.check(L.ehm_split_pack(src.data_ptr(), xd.data_ptr(), rows, Ci, Ci, 1.0, None))
+    wsrc = torch.randn(Co, Ci, device=dev, generator=g) / Ci ** 0.5
+    wbuf = torch.empty_like(wsrc)
+    _lib.check(L.ehm_split_pack(wsrc.data_ptr(), wbuf.data_ptr(), Co, Ci, Ci, 256.0, None))
+    bias = torch.randn(Co, device=dev, generator=g)
+    y = torch.empty(rows, Co, device=dev)
+    d = _lib.ConvX2Desc(xd.data_ptr(), rows, wbuf.data_ptr(), bias.data_ptr(), None, y.data_ptr(), N, H, W, Ci, Co, k, k, 1, 0, 1, 256.0, None, 0)
+    need = int(L.ehm_conv_x2_workspace_bytes(C.byref(d)))
+    assert need > 4096
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    d.workspace, d.workspace_bytes, d.workspace_clean = ws.data_ptr(), need, 1
+
+    def run():
+        _lib.check(L.ehm_conv_x2(C.byref(d), None), "ehm_conv_x2")
+        out = torch.empty(rows, Co, device=dev)
+        _lib.check(L.ehm_gcn_unpack_activations(y.data_ptr(), out.data_ptr(), rows, Co, 32, None))
+        return out[:N * H * W]
+
+    good = run()
+    assert torch.isfinite(good).all() and float(good.min()) == 0.0          # (ReLU)
+    assert L.ehm_conv_x2_workspace_status(ws.data_ptr(), None, None) == 0
+    flags = ws[:4096].view(torch.int32)
+    assert int(flags.abs().sum()) == 0                                       # the convs leave their counters zeroed
+    flags[0] = -2 ** 31                                                      # cut tile 0: poisoned, as a time-out leaves it
+    bad = run()
+    nan_rows = torch.isnan(bad).any(dim=1)
+    assert int(nan_rows.sum()) > 0 and bool(torch.isnan(bad[nan_rows]).any())   # NaN came through the ReLU epilogue
+    assert torch.equal(bad[~nan_rows], good[~nan_rows])                     # every other tile is untouched
+    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    assert L.ehm_conv_x2_workspace_status(ws.data_ptr(), host.data_ptr(), None) == 0      # asynchronous form: a copy, no verdict
+    torch.cuda.synchronize()
+    assert int(host[0]) == 1
+    assert L.ehm_conv_x2_workspace_status(ws.data_ptr(), None, None) != 0                  # reported ...
+    assert b"timed out" in L.ehm_last_error()
+    assert L.ehm_conv_x2_workspace_status(ws.data_ptr(), None, None) == 0                  # ... once; counters zeroed again
+    assert torch.equal(run(), good)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [
     (5, 8, 8, 128, 256, 1, 2, True, True),      # strided 1x1 with residual, two column tiles
     (2, 15, 15, 64, 64, 3, 1, False, True),     # 3x3 with borders, the narrow column tile

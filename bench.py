@@ -132,7 +132,7 @@ def compact_line(d):
         r = sub.get("roofline") or {}
         e = {"value": _num(sub.get("value"), 6), "ms_per_step": _num(sub.get("ms_per_step"), 6), "roofline_frac": _num(r.get("frac")),
              "encoders_ms": _num((sub.get("breakdown_ms") or {}).get("encoders_and_projections_once"))}
-        for extra in ("bodies_per_step", "body_denoising_steps_per_s", "mpjpe_vs_f32_path_mm", "gcn_precision", "guided_step_us"):
+        for extra in ("bodies_per_step", "body_denoising_steps_per_s", "mpjpe_vs_f32_path_mm", "gcn_precision", "encoder_precision", "guidance_weight", "guided_step_us"):
             if sub.get(extra) is not None:
                 e[extra] = _num(sub[extra]) if not isinstance(sub[extra], str) else sub[extra]
         subs[name] = e
@@ -259,7 +259,7 @@ def cpu_baseline(n, rs, num_scene_points, budget_s, faithful=True):
                       f"{done} of {T} steps timed ({dt:.1f} s)" + (f", extrapolated linearly to {T} steps" if faithful and done < T else "")}
 
 
-def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, world):
+def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, world, tier_compare=True):
     """One workload end to end (model, inputs, calibration, warm-up, the timed region, the profiled call, the legs): the JSON object of rank 0."""
     if args.precision_given is None and workload in WORKLOAD_PRECISION:
         args = argparse.Namespace(**{**vars(args), "precision": WORKLOAD_PRECISION[workload]})
@@ -427,7 +427,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
             del m2
             torch.cuda.empty_cache()
 
-    if args.precision == "f16" and world == 1 and legs_on is not None and workload in WORKLOAD_PRECISION:
+    # (tier_compare: an explicit switch - this leg also runs for the sub-configs, which are measured with the other legs off: two more calls of the job)
+    if args.precision == "f16" and world == 1 and tier_compare and workload in WORKLOAD_PRECISION:
         # the fp16-denoiser tier against the f32-grade run of the SAME job (same noise): what the tier costs in accuracy, next to what it buys
         j16 = res["other_outputs"]["pred_keypoints_3d"].float().clone()
         v16 = res["other_outputs"]["pred_vertices"].float().clone()
@@ -603,7 +604,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
             "data": "synthetic",
             "config": {"workload": desc, "name": workload, "items_per_gpu": B, "samples_per_item": S, "samples_in_one_loop": bool(S > 1), "collision_guided": guided, "denoising_steps": T,
                        "scene_points": N, "gcn_passes_per_step": passes, "lbs_every_step": bool(model.lbs_every_step),
-                       "gcn_precision": args.precision, "encoder_precision": model.encoder_precision, "f16x3_last_steps": k_last if args.precision == "f16x3" else None,
+                       "gcn_precision": args.precision, "encoder_precision": model.encoder_precision, "guidance_weight": w_guid if guided else None, "f16x3_last_steps": k_last if args.precision == "f16x3" else None,
                        "f16x3_last_steps_policy": str(model.f16x3_last_steps),
                        "pass_pruning": {"items_without_second_pass": int(B - st.num_masked) if model.prune_passes else 0, "of": B,
                                         "note": "exact (egohmr.py:249-254): all-visible items skip the image-masked pass; the synthetic "
@@ -710,6 +711,9 @@ def main():
             sub = measure(args, wl, nsteps, 1, False, 0.0, dev, rank, world)
             subs[wl] = {k: sub[k] for k in keep if k in sub}
             subs[wl]["gcn_precision"] = sub["config"]["gcn_precision"]
+            subs[wl]["encoder_precision"] = sub["config"]["encoder_precision"]          # (C5 names the fp16 tier: its encoders run hi-only too)
+            if sub["config"].get("guidance_weight") is not None:
+                subs[wl]["guidance_weight"] = sub["config"]["guidance_weight"]          # (C5 is timed at 0.5, not the VolSMPL default 30: see w_guid)
         out["configs"] = subs
     if rank == 0:
         emit(out)

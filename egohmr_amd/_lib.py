@@ -21,14 +21,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EHM_LIB_PATH") or os.path.join(_HERE, "libegohmr_hip.so")   # EHM_LIB_PATH: A/B a second build (experiments)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip", "prep.hip", "step.hip"]
+SOURCES = ["gcn.hip", "gcn_tile.hip", "linear.hip", "conv.hip", "stem.hip", "metrics.hip", "smpl.hip", "sampler.hip", "guidance.hip", "prep.hip", "step.hip", "eval.hip"]
 
 
 class EgoHMRHipError(RuntimeError):
     pass
 
 
-HEADERS = ["common.h", "smpl_dev.h", "gcn_dev.h", "step_dev.h", "internal.h", "gcn_loop_dev.h", "gcn_loop_host.inc"]
+class EgoHMRRangeError(EgoHMRHipError):
+    """rc = -34: an activation of the denoiser reached the f16 range and was clamped in its X2 / f16 store (ehm_gcn_stack_status).  The results are finite
+    but not parity grade; the remedy is float32 activations for that checkpoint: EgoHMR.gcn_precision = 'f32' (EgoHMR.on_saturation = 'f32' does it
+    and re-runs the call)."""
+
+
+HEADERS = ["common.h", "smpl_dev.h", "gcn_dev.h", "step_dev.h", "internal.h"]
 
 
 def build(verbose: bool = False, force: bool = False) -> str:
@@ -37,7 +43,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS (tools/stamp_*.py), -DEHM_WITH_LOOP_ENGINE (the one-launch loop experiment)
+    extra = os.environ.get("EHM_HIPCC_FLAGS", "").split()   # e.g. -DEHM_STAMPS (tools/stamp_*.py)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *extra]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "egohmr_hip.h")]
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
@@ -45,13 +51,17 @@ def build(verbose: bool = False, force: bool = False) -> str:
     objdir = os.path.join(_HERE, "build", os.path.basename(LIB_PATH) + "." + tag)
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    sources = SOURCES + (["gcn_wide.hip"] if "-DEHM_WITH_WIDE_TILE" in extra else [])     # experiment: the 96 x 64 (x 2) wave tile (docs/EXPERIMENTS.md 3.2)
+    sources = SOURCES
     for s in sources:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
             jobs.append((src, obj))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in sources]
-    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+    # every flag set links into the same LIB_PATH: the tag of the object directory the library was linked from is kept beside it, and a library
+    # linked from ANOTHER flag set (say -DEHM_STAMPS, then a default build whose objects were already up to date) is relinked, never reused
+    tag_path = LIB_PATH + ".tag"
+    linked_tag = open(tag_path).read().strip() if os.path.exists(tag_path) else None
+    if not jobs and os.path.exists(LIB_PATH) and linked_tag == tag and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
 
     def compile_one(job):
@@ -75,11 +85,13 @@ def build(verbose: bool = False, force: bool = False) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise EgoHMRHipError(f"hipcc (link) failed:\n{r.stdout}\n{r.stderr}")
+    with open(tag_path, "w") as f:
+        f.write(tag + "\n")
     return LIB_PATH
 
 
 def build_features() -> set:
-    """Optional parts the loaded library was built with (ehm_build_features): 'loop_engine', 'stamps', 'wide_tile'."""
+    """Optional parts the loaded library was built with (ehm_build_features): 'stamps'."""
     return set(lib().ehm_build_features().decode().split())
 
 
@@ -114,6 +126,13 @@ class ConvX2Desc(C.Structure):
                 ("w_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("x2", C.c_void_p), ("x2_rows", C.c_int64), ("H2", C.c_int), ("W2", C.c_int), ("Ci2", C.c_int), ("stride2", C.c_int), ("hi_only", C.c_int),
                 ("workspace_clean", C.c_int)]
+
+
+class EvalPointsDesc(C.Structure):
+    """ehm_eval_points_desc"""
+    _fields_ = [("pred", C.c_void_p), ("gt", C.c_void_p), ("pred_origin", C.c_void_p), ("gt_origin", C.c_void_p), ("mask", C.c_void_p),
+                ("per_point", C.c_void_p), ("mean", C.c_void_p), ("vis_sum", C.c_void_p), ("invis_sum", C.c_void_p),
+                ("B", C.c_int), ("S", C.c_int), ("P", C.c_int), ("pred_points", C.c_int), ("gt_points", C.c_int), ("origin_point", C.c_int)]
 
 
 class ItemPrepDesc(C.Structure):
@@ -152,7 +171,7 @@ class NonlocalParams(C.Structure):
 class SampleDesc(C.Structure):
     """ehm_sample_desc"""
     _fields_ = [("B", C.c_int), ("passes", C.c_int), ("num_steps", C.c_int), ("ddim", C.c_int), ("lbs_every_step", C.c_int),
-                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int), ("loop_engine", C.c_int), ("per_step_launches", C.c_int)]
+                ("num_scene_points", C.c_int), ("guide_denom", C.c_float), ("tau", C.c_float), ("num_masked", C.c_int), ("guide_all_points", C.c_int), ("lowprec_steps", C.c_int), ("nonlocal_ci", C.c_int), ("per_step_launches", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -164,6 +183,8 @@ PROTOTYPES = {
     "ehm_build_features": (C.c_char_p, []),
     "ehm_rot6d_to_rotmat": (_I, [_P, _P, _L, _I, _P]),
     "ehm_rot6d_to_rotmat_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
+    "ehm_rotmat_to_angle_axis": (_I, [_P, _P, _L, _P]),
+    "ehm_rotmat_to_angle_axis_bwd": (_I, [_P, _P, _P, _L, _P]),
     "ehm_smpl_create": (_I, [C.POINTER(_P), _P, _P, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I, _P]),
     "ehm_smpl_destroy": (None, [_P]),
     "ehm_smpl_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
@@ -180,7 +201,9 @@ PROTOTYPES = {
     "ehm_gcn_activation_group": (_I, [_P]),
     "ehm_gcn_pack_activations": (_I, [_P, _P, _L, _I, _I, _P]),
     "ehm_gcn_unpack_activations": (_I, [_P, _P, _L, _I, _I, _P]),
+    "ehm_gcn_pack_activations_checked": (_I, [_P, _P, _P, _L, _P]),
     "ehm_gcn_input_layer": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "ehm_gcn_input_layer_rows": (_I, [_P, _P, _P, _I, _P]),
     "ehm_gcn_hidden_layer": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "ehm_gcn_hidden_stack": (_I, [_P, C.POINTER(C.c_void_p), _L, C.POINTER(C.c_int), _P]),
     "ehm_gcn_stack_status": (_I, [_P, _P]),
@@ -206,6 +229,9 @@ PROTOTYPES = {
     "ehm_smpl_backward_rot6d": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "ehm_guidance_grad_finish": (_I, [_P, _P, _P, _I, _F, _P]),
     "ehm_nn_dist2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ehm_eval_point_errors": (_I, [C.POINTER(EvalPointsDesc), _P]),
+    "ehm_eval_procrustes": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ehm_eval_diversity": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "ehm_sample_workspace_bytes": (_L, [C.POINTER(SampleDesc), _I, _I]),
     "ehm_sample_loop": (_I, [_P, _P, C.POINTER(SampleDesc), C.POINTER(StepCoefs)] + [_P] * 18 + [_L, _P]),
     "ehm_item_prep": (_I, [C.POINTER(ItemPrepDesc), _P]),
@@ -213,7 +239,7 @@ PROTOTYPES = {
     "ehm_profile_begin": (_I, []),
     "ehm_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
 }
-PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "loop_f16x3", "loop_f16",
+PROF_CLASSES = ("input", "chain_f16x3", "chain_f16", "hidden_f32", "out_dot", "step_body", "skin_input", "guidance", "reserved_8", "reserved_9",
                 "guid_nearest", "guid_skin_bwd", "guid_posefeat_bwd", "step_fused", "guid_nearest_evals")   # EHM_PROF_* of the header (the last one is a COUNT in `launches`)
 
 _lib = None
@@ -247,6 +273,8 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().ehm_last_error()
+        if rc == -34:
+            raise EgoHMRRangeError(f"{what or 'libegohmr_hip'} (rc={rc}): {msg.decode() if msg else ''}")
         raise EgoHMRHipError(f"{what or 'libegohmr_hip'} failed (rc={rc}): {msg.decode() if msg else ''}")
 
 

@@ -8,6 +8,7 @@
 #define EHM_EINVAL (-22)
 #define EHM_ENOMEM (-12)
 #define EHM_EIO (-5)
+#define EHM_ERANGE (-34)
 
 extern "C" const char* ehm_last_error(void);
 void ehm_set_error(const char* fmt, ...);

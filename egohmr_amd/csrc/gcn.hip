@@ -264,6 +264,13 @@ __global__ __launch_bounds__(256) void gcn_input_kernel(GcnInputArgs a) {
   gcn_input_body<OUT>(T, blockIdx.x, blockIdx.y, a);
 }
 
+// the same epilogue on ready-made pre-activations [bodies * 24][2][hid] (ehm_gcn_input_layer_rows: ModulatedGCN.forward on an arbitrary input feature)
+template <int OUT>
+__global__ __launch_bounds__(256) void gcn_input_rows_kernel(GcnInputArgs a) {
+  __shared__ __attribute__((aligned(16))) float T[kJ * 256];
+  gcn_input_body<OUT, false, true>(T, (int)threadIdx.x, blockIdx.x, blockIdx.y, a, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // output conv (hid -> 6, both branches) + visibility fuse, two kernels:
 //   gcn_out_dot_kernel   HBM-bound: every activation row is read once (float4); [rows,K] x [K,12] on the exact-f32 MFMA.
@@ -409,9 +416,6 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
   for (int i = 0; i < num_hidden; ++i) EHM_CHECK_ARG(hidden[i].in_dim == hid_dim && hidden[i].out_dim == hid_dim && hidden[i].W);
   hipStream_t st = (hipStream_t)stream;
   auto* g = new ehm_gcn();
-#ifdef EHM_WITH_WIDE_TILE
-  if (const char* e = getenv("EHM_GCN_WIDE")) g->wide = atoi(e);   // (experiment build: gcn_wide.hip for the per-conv launches)
-#endif
   if (const char* e = getenv("EHM_F16_CHAIN")) g->chain = atoi(e);   // 0: one launch per hidden conv (debugging aid; bit-identical results)
   g->hid = hid_dim;
   g->num_hidden = num_hidden;
@@ -441,14 +445,12 @@ extern "C" int ehm_gcn_create(ehm_gcn** out, const float* adj, const ehm_gconv_p
         hipMemcpyAsync(g->hidden_dev, g->hidden, sizeof(LayerDev) * num_hidden, hipMemcpyHostToDevice, st) != hipSuccess)
       rc = EHM_ENOMEM;
   }
-  if (rc == 0 && hipMalloc(&g->loop_extra, EHM_LOOP_EXTRA_BYTES) != hipSuccess) rc = EHM_ENOMEM;
   if (rc == 0 && (hipMalloc(&g->chain_sticky, 64) != hipSuccess || hipMemsetAsync(g->chain_sticky, 0, 64, st) != hipSuccess)) rc = EHM_ENOMEM;
   if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = EHM_EIO;
   if (rc == 0) rc = ehm_gcn_reserve_rows(g, 2 * 256 * kJ);   // the benchmark shape; larger batches grow it on first use (ehm_gcn_reserve)
   if (rc != 0) {
     if (g->hidden_dev) (void)hipFree(g->hidden_dev);
     if (g->chain_sticky) (void)hipFree(g->chain_sticky);
-    if (g->loop_extra) (void)hipFree(g->loop_extra);
     if (g->chain_sync) (void)hipFree(g->chain_sync);
     if (g->hs) (void)hipFree(g->hs);
     (void)hipFree(g->arena);
@@ -467,7 +469,6 @@ extern "C" void ehm_gcn_destroy(ehm_gcn* h) {
   if (h->hidden_dev) (void)hipFree(h->hidden_dev);
   if (h->chain_sync) (void)hipFree(h->chain_sync);
   if (h->chain_sticky) (void)hipFree(h->chain_sticky);
-  if (h->loop_extra) (void)hipFree(h->loop_extra);
   delete h;
 }
 
@@ -481,6 +482,7 @@ int ehm_gcn_input_args(ehm_gcn* h, const float* h_img, const float* h_oth, const
   a->Y = out;
   a->B = B; a->passes = passes; a->mask_all = h->uncond_masks_all;
   a->mask_items = (passes == 2 && h->num_masked >= 0) ? h->mask_items : nullptr;
+  a->sticky = h->chain_sticky;
   a->total_vb = ehm_gcn_virtual_bodies(h, B, passes);
   a->ny = (int)ceil_div(h->hid, 256);
   return 0;
@@ -495,6 +497,25 @@ extern "C" int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* 
   if (h->precision == EHM_PREC_F32) hipLaunchKernelGGL(gcn_input_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL(gcn_input_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);   // X2 split rows
   else hipLaunchKernelGGL(gcn_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);                                        // plain f16 rows
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_input_layer_rows(ehm_gcn* h, const float* pre, float* out, int bodies, void* stream) {
+  EHM_CHECK_ARG(h && pre && out && bodies > 0);
+  GcnInputArgs a{};
+  a.L = h->input;
+  a.Y = out;
+  a.B = bodies; a.passes = 1; a.mask_all = 0;
+  a.mask_items = nullptr;
+  a.total_vb = bodies;
+  a.ny = (int)ceil_div(h->hid, 256);
+  a.sticky = h->chain_sticky;
+  a.pre = pre;
+  dim3 grid((unsigned)a.total_vb, (unsigned)a.ny);
+  if (h->precision == EHM_PREC_F32) hipLaunchKernelGGL(gcn_input_rows_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL(gcn_input_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gcn_input_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
   EHM_LAUNCH_CHECK();
   return 0;
 }
@@ -548,10 +569,16 @@ extern "C" int ehm_gcn_stack_status(ehm_gcn* h, void* stream) {
       h->chain_sync_clean = 0;            // a launch that gave up may have left tickets / counters behind
     }
   }
-  if (flag) {
+  if (flag & ~kStickySaturated) {
     ehm_set_error("ehm_gcn_hidden_stack: a chained launch since the last status call timed out waiting for a producer tile, or left tiles "
                   "unproduced (GPU shared / preempted / CU-masked?); the results of that sampling loop are invalid - re-run, or set EHM_F16_CHAIN=0");
     return EHM_EIO;
+  }
+  if (flag & kStickySaturated) {
+    ehm_set_error("ehm_gcn: an activation of the denoiser reached the f16 range (|x| >= 65504) since the last status call and was CLAMPED in its X2 / f16 "
+                  "store - the split format holds |x| <= 131008 and is f32-grade only below 65504 (nothing became inf / NaN, the results are finite but not "
+                  "parity grade).  This checkpoint needs ehm_gcn_set_precision(h, 0) (EgoHMR.gcn_precision = 'f32': float32 activations, exact-f32 MFMA)");
+    return EHM_ERANGE;
   }
   return 0;
 }

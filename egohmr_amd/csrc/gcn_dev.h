@@ -40,7 +40,6 @@ struct OutDev {
 
 
 enum { EHM_PREC_F32 = 0, EHM_PREC_F16X3 = 1, EHM_PREC_F16 = 2 };
-constexpr size_t EHM_LOOP_EXTRA_BYTES = 2048;
 
 struct ehm_gcn {
   int hid = 0;
@@ -59,14 +58,12 @@ struct ehm_gcn {
   int chain_sync_clean = 0;              // 1: the last chained launch zeroed tickets / done / finished itself (its last block does)
   int64_t chain_sync_shape = 0;          // nl * m_tiles the words were last used with (err sits right behind done[])
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
-  int wide = 0;                          // -DEHM_WITH_WIDE_TILE builds only (experiment): EHM_GCN_WIDE=1 at create -> per-conv launches of the split-f16 mode run gcn_wide.hip
   int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (f16 modes), 0 = one launch per conv (EHM_F16_CHAIN=0)
   OutDev out{};
   float* arena = nullptr;
   float* hs = nullptr;      // [hs_rows,12] responses of the output conv (gcn_out_dot_kernel -> gcn_out_mix_kernel)
   int64_t hs_rows = 0;
   int64_t reserved_rows = 0;   // rows_pad the sync words / hs scratch were sized for (ehm_gcn_reserve)
-  void* loop_extra = nullptr;       // EHM_LOOP_EXTRA_BYTES of device memory: the one-launch loop's per-segment argument block (gcn_tile.hip: LoopExtra)
   ehm_nonlocal_params nonlocal{};   // optional non-local block of the one-call loop (ehm_gcn_set_nonlocal); Ci == 0: none
 };
 
@@ -196,6 +193,8 @@ static __device__ __forceinline__ void gcn_mix2(const f32x2 (&dp)[kJ], const f32
 // one wave = one virtual body x 64 channels; 4 waves per block = 4 channel groups
 // ------------------------------------------------------------------------------------------------
 // Arguments of the hoisted input conv (gcn.hip: gcn_input_kernel; also run as part of smpl.hip's fused skinning + input-conv launch)
+constexpr unsigned int kStickySaturated = 4u;   // bit of ehm_gcn::chain_sticky: an activation reached +-65504 in an f16 / X2 store and was clamped
+
 struct GcnInputArgs {
   const float* h_img; const float* h_oth; const uint8_t* vis; const float* x; const float* Wx; const float* tvec;
   LayerDev L;
@@ -203,12 +202,16 @@ struct GcnInputArgs {
   int B, passes, mask_all;
   const int32_t* mask_items;
   int total_vb, ny;          // grid of the standalone launch: total_vb x ny blocks of 256 threads
+  unsigned int* sticky = nullptr;   // the handle's status word: bit 2 (kStickySaturated) when an f16 store of this conv clamped (OUT != 0)
+  const float* pre = nullptr;   // PRE instantiation only (ehm_gcn_input_layer_rows): the rows' pre-activations x @ [W0 | W1] as [bodies * 24][2][N]
 };
 
 // One block of the input conv: virtual body `bx`, channels 256 * by .. + 255.  T = 24 * 256 floats of LDS.  `tid` = 0..255 (the calling
 // 256 threads; a 512-thread block runs two of these side by side on two T regions), `xb_in` = the body's 144 x_t values when the caller has
 // staged them itself (the one-launch loop reads them with agent-scope loads: another block of the SAME launch wrote them), else nullptr.
-template <int OUT, bool X_LDS = false>   // OUT: 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows; X_LDS: xb_in is an LDS pointer (the caller staged x itself)
+// PRE: the conv's two GEMM results come ready-made per row from a.pre (the general form of modulated_gcn_conv.py:39-41 for an arbitrary input feature: ModulatedGCN.forward
+// standalone) instead of being assembled from the hoisted conditioning slices; everything behind them - modulation, adjacency mix, BN, ReLU, stores - is this function's.
+template <int OUT, bool X_LDS = false, bool PRE = false>   // OUT: 0 = float32 rows, 1 = X2<32> split rows, 2 = plain f16 rows; X_LDS: xb_in is an LDS pointer (the caller staged x itself)
 __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by, const GcnInputArgs& a, const float* xb_in) {
   const float* __restrict__ h_img = a.h_img; const float* __restrict__ h_oth = a.h_oth; const uint8_t* __restrict__ vis = a.vis;
   const float* __restrict__ x = a.x; const float* __restrict__ Wx = a.Wx; const float* __restrict__ tvec = a.tvec;
@@ -222,7 +225,8 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
   const int p = vb >= B ? 1 : 0, b = p ? (mask_items ? mask_items[vb - B] : vb - B) : vb;
   const int n_raw = by * 256 + tid;
   const int n = n_raw < N ? n_raw : N - 1;                        // lanes past N recompute the last channel; their stores are dropped
-  float base[2], img[2], wx[2][6];
+  float base[2] = {0.f, 0.f}, img[2] = {0.f, 0.f}, wx[2][6] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+  if constexpr (!PRE)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     base[k] = ((p == 1 && mask_all) ? 0.f : h_oth[((size_t)b * 2 + k) * N + n]) + tvec[k * N + n];   // egohmr.py:150-158 force_mask: image part only / whole condition
@@ -232,7 +236,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
   }
   // x_t of the body: wave-uniform.  Standalone launches: scalar loads from the global row.  X_LDS: 36 sixteen-byte LDS reads through an explicit
   // LDS pointer (as `xb_in ? xb_in : global row` the pointer was generic and the reads FLAT loads: aperture check per access, both wait counters)
-  const float* xb = xb_in ? xb_in : x + (size_t)b * kPoseDim;
+  const float* xb = xb_in ? xb_in : (PRE ? nullptr : x + (size_t)b * kPoseDim);
   float xr[X_LDS ? kPoseDim : 1];
   if constexpr (X_LDS) {
     typedef const f32x4 __attribute__((address_space(3))) lf32x4;
@@ -243,7 +247,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
       xr[4 * i] = v[0]; xr[4 * i + 1] = v[1]; xr[4 * i + 2] = v[2]; xr[4 * i + 3] = v[3];
     }
   }
-  const uint8_t* vb_ = vis + (size_t)b * kJ;
+  const uint8_t* vb_ = PRE ? nullptr : vis + (size_t)b * kJ;
   float h0[kJ], h1[kJ];
   const float sh = L.shift[n];
   // the channel's 24 + 24 table values from the [N][24] copies: twelve 16-byte loads instead of 48 strided dword loads (a unit's vector-memory
@@ -274,12 +278,18 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
   for (int c = 0; c < 6; ++c) wx2[c] = f32x2{wx[0][c], wx[1][c]};
 #pragma unroll
   for (int j = 0; j < kJ; ++j) {
+    f32x2 s;
+    if constexpr (PRE) {
+      const float* pr = a.pre + ((size_t)vb * kJ + j) * 2 * (size_t)N + n;
+      s = f32x2{pr[0], pr[N]};
+    } else {
     const float v = vb_[j] ? 1.f : 0.f;
-    f32x2 s = __builtin_elementwise_fma(f32x2{v, v}, img2, base2);
+    s = __builtin_elementwise_fma(f32x2{v, v}, img2, base2);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const float xv = X_LDS ? xr[X_LDS ? j * 6 + c : 0] : xb[j * 6 + c];
       s = __builtin_elementwise_fma(f32x2{xv, xv}, wx2[c], s);
+    }
     }
     h0[j] = fmaf(dj[j], s[0], sh);
     h1[j] = mj[j] * s[1];
@@ -359,6 +369,12 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     const size_t row = (size_t)vb * kJ + j;
     if (OUT != 0) {
+      if (a.sticky) {                                     // range guard of the f16 stores (see run_tiles' epilogue, gcn_tile.hip)
+        float vm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) vm = fmaxf(vm, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
+        if (vm >= 65504.f) __hip_atomic_fetch_or(a.sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       half8 hh, ll;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -385,99 +401,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int bx, int by, const G
   gcn_input_body<OUT>(T, (int)threadIdx.x, bx, by, a, nullptr);
 }
 
-// The same input conv for the 8 virtual bodies vb0 .. vb0 + 7 of ONE row tile, channels 256 * by .. + 255, by 256 threads (an item of the
-// one-launch loop, gcn_tile.hip): the channel's constants (D, M1, Wx, shift, timestep vector) are fetched ONCE, the eight bodies'
-// conditioning slices together, so that a block pays the global-load latency a few times per item instead of a dozen times per body (eight
-// calls of gcn_input_body took ~100 us in a block that has the CU's issue slots mostly to itself).  Arithmetic and operation order per
-// output are gcn_input_body's (bit-equal).  xs = the eight bodies' x_t rows [8][144] (LDS, staged by the caller); T = 24 x 256 floats.
-template <int OUT>   // 1 = X2<32> split rows, 2 = plain f16 rows, 0 = float32 rows
-__device__ __forceinline__ void gcn_input_rows8(float* T, int tid, int vb0, int by, const GcnInputArgs& a, const float* xs) {
-  const LayerDev& L = a.L;
-  const int N = L.N, B = a.B;
-  const int n_raw = by * 256 + tid;
-  const int n = n_raw < N ? n_raw : N - 1;
-  const int p = vb0 >= B ? 1 : 0;
-  const int b0 = p ? vb0 - B : vb0;                               // (no pass map in the loop: second pass of item b is virtual body B + b)
-  float dj[kJ], mj[kJ], wx[2][6], tv[2];
-  const float sh = L.shift[n];
-#pragma unroll
-  for (int j = 0; j < kJ; ++j) { dj[j] = L.D[j * N + n]; mj[j] = L.M1[j * N + n]; }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    tv[k] = a.tvec[k * N + n];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) wx[k][c] = a.Wx[(k * 6 + c) * N + n];
-  }
-  float oth[8][2], img[8][2];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      oth[i][k] = (p == 1 && a.mask_all) ? 0.f : a.h_oth[((size_t)(b0 + i) * 2 + k) * N + n];
-      img[i][k] = (p == 0) ? a.h_img[((size_t)(b0 + i) * 2 + k) * N + n] : 0.f;
-    }
-  typedef const float __attribute__((address_space(4))) cfloat;
-  const cfloat* Ac = (const cfloat*)(uintptr_t)L.Aoff;
-  const bool relu = L.relu != 0;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int nb = by * 256;
-  for (int i = 0; i < 8; ++i) {
-    const float* xb = xs + i * kPoseDim;
-    const uint8_t* vb_ = a.vis + (size_t)(b0 + i) * kJ;
-    const float base0 = oth[i][0] + tv[0], base1 = oth[i][1] + tv[1];
-    float h0[kJ], h1[kJ];
-#pragma unroll
-    for (int j = 0; j < kJ; ++j) {
-      const float v = vb_[j] ? 1.f : 0.f;
-      float s0 = fmaf(v, img[i][0], base0), s1 = fmaf(v, img[i][1], base1);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const float xv = xb[j * 6 + c];
-        s0 = fmaf(xv, wx[0][c], s0);
-        s1 = fmaf(xv, wx[1][c], s1);
-      }
-      h0[j] = fmaf(dj[j], s0, sh);
-      h1[j] = mj[j] * s1;
-    }
-    static_assert(OUT != 2, "gcn_input_rows8: the matrix-core mix of the plain-f16 mode is not built here (the loop runs split-f16)");
-#pragma unroll
-    for (int j = 0; j < kJ; ++j) {
-      float sacc = h0[j];
-#pragma unroll
-      for (int jp = 0; jp < kJ; ++jp) sacc = fmaf(Ac[j * kJ + jp], h1[jp], sacc);
-      if (relu) sacc = fmaxf(sacc, 0.f);
-      T[j * 256 + tid] = sacc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int u = tid + 256 * it, j = u >> 5, c8 = (u & 31) * 8;
-      if (nb + c8 >= N) continue;
-      const f32x4 v0 = *(const f32x4*)(T + j * 256 + c8), v1 = *(const f32x4*)(T + j * 256 + c8 + 4);
-      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      const size_t row = (size_t)(vb0 + i) * kJ + j;
-      if (OUT != 0) {
-        half8 hh, ll;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
-          hh[k] = (half_t)c;
-          ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
-        }
-        half_t* q = (half_t*)a.Y + split_off<32>(row, nb + c8, N);
-        *(u32x4*)q = __builtin_bit_cast(u32x4, hh);
-        *(u32x4*)(q + 32) = __builtin_bit_cast(u32x4, ll);
-      } else {
-        float* q = a.Y + row * (size_t)N + nb + c8;
-        *(f32x4*)q = v0;
-        *(f32x4*)(q + 4) = v1;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// ---- output conv responses of 16 rows (gcn.hip: gcn_out_dot_kernel; the one-launch loop of gcn_tile.hip calls it per row tile) --------------
+// ---- output conv responses of 16 rows (gcn.hip: gcn_out_dot_kernel) --------------
 constexpr int OUT_ROWS_PER_BLOCK = 16;
 // [rows, K] x [K, 12] on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32: 16 rows x 16 columns, 12 used).  256 threads = 4 waves split K; a
 // wave's lane (row = l&15, q = l>>4) streams float4 X[row][kw + 16 i + 4 q ..+3] - the k order inside an MFMA step is a
@@ -566,56 +490,5 @@ __device__ __forceinline__ void gcn_out_dot_rows16(const float* __restrict__ X, 
   if (tid < 16 * 12) {
     const int rr = tid / 12, cc = tid % 12;
     if (r0 + rr < rows) hs[(r0 + rr) * 12 + cc] = (part[0][rr][cc] + part[1][rr][cc]) + (part[2][rr][cc] + part[3][rr][cc]);
-  }
-}
-
-// The same 16 rows by ONE wave (no LDS, no barrier): the four K quarters one after the other, each with the two accumulator chains of
-// gcn_out_dot_rows16, combined as (q0 + q1) + (q2 + q3) - the same sums in the same order, so the responses are bit-equal to the four-wave
-// form.  A wave of the one-launch loop's OUT item owns three such row groups; K % 128 == 0.
-template <bool HALF_IN, int AUX>
-__device__ __forceinline__ void gcn_out_dot_rows16_wave(const float* __restrict__ X, const OutDev& O, float* __restrict__ hs, int64_t r0, int64_t rows, int lane) {
-  const int K = O.K, row = lane & 15, q = lane >> 4, kq = K / 4;
-  const int64_t r = r0 + row < rows ? r0 + row : rows - 1;
-  typedef unsigned int u32x4_od __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rsX = ehm_buffer_rsrc_4g(X);
-  f32x4 part[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const unsigned int vox = (unsigned int)((r * K + (size_t)w * kq + 8 * q) * (HALF_IN ? 2 : 4));
-    const float* wr = O.Wt + (size_t)(row < 12 ? row : 0) * K + (size_t)w * kq + 8 * q;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int k = 0; k + 32 <= kq; k += 32) {
-      float xv[8];
-      if (HALF_IN) {
-        const half8 hv = __builtin_bit_cast(half8, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 2, AUX));
-#pragma unroll
-        for (int c = 0; c < 8; ++c) xv[c] = (float)hv[c];
-      } else {
-        const f32x4 x0 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4, AUX));
-        const f32x4 x1 = __builtin_bit_cast(f32x4, (u32x4_od)__builtin_amdgcn_raw_buffer_load_b128(rsX, vox, k * 4 + 16, AUX));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { xv[c] = x0[c]; xv[4 + c] = x1[c]; }
-      }
-      f32x4 w0 = *(const f32x4*)(wr + k), w1 = *(const f32x4*)(wr + k + 4);
-      if (row >= 12) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
-#pragma unroll
-      for (int c = 0; c < 4; c += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c], w0[c], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c + 1], w0[c + 1], acc2, 0, 0, 0);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[4 + c], w1[c], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[5 + c], w1[c + 1], acc2, 0, 0, 0);
-      }
-    }
-    part[w] = acc + acc2;
-  }
-  // C layout of the 16x16 tile: column (output channel) = lane & 15, row = 4 * (lane >> 4) + reg
-  if (row < 12) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (r0 + 4 * q + c < rows) hs[(r0 + 4 * q + c) * 12 + row] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
   }
 }

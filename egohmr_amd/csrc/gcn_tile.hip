@@ -68,9 +68,7 @@ struct Frags {
 // only three SGPRs per tile stay live across the K loop / the epilogue.
 struct Tile {
   int layer, m_tile, n_tile;
-  int kind, step;       // one-launch loop only (MODE 2): K_* below, step of the segment
 };
-enum { K_HIDDEN = 0, K_INPUT = 1, K_OUT = 2, K_BODY = 3, K_SKIP = 4 };
 // What the epilogue and the operand DMA need to know about a tile's conv.
 struct TileIO {
   const float* X;       // activation matrix of the conv's input (rows of `rowf` floats)
@@ -89,7 +87,8 @@ struct ChainArgs {
   unsigned int* tickets;    // [8]
   unsigned int* done;       // [nl][m_tiles]
   unsigned int* err;        // this launch: a wait timed out / a tile was never produced (results invalid)
-  unsigned int* sticky;     // never cleared by a launch: accumulates err over a whole sampling loop (ehm_gcn_stack_status)
+  unsigned int* sticky;     // never cleared by a launch: accumulates err over a whole sampling loop (ehm_gcn_stack_status): bit 0 = a wait timed out / a tile is
+                            // missing, bit 2 (kStickySaturated) = an activation reached the f16 range in an epilogue store and was clamped
   unsigned int* finished;   // blocks that ran out of tickets; the last one audits done[nl-1][*]
   int nq;                   // queues = XCDs
 };
@@ -100,6 +99,7 @@ struct OneArgs {
   const void* Res;
   void* Y;
   int m_tiles, out_f32;
+  unsigned int* sticky;     // the handle's status word (ehm_gcn_stack_status): bit 2 = an f16 store saturated
 };
 
 template <int P>
@@ -113,39 +113,13 @@ __device__ __forceinline__ const float* layer_weights(const LayerDev& L) {
 // channels - the activation tile is staged once for both channel halves, 56 KiB instead of 80 KiB of operands per K tile and CU; with
 // one MFMA per product the K loop is bound by LDS bandwidth (writes + fragment reads), see DESIGN.md 3.2.
 
-#ifdef EHM_WITH_LOOP_ENGINE
-#include "gcn_loop_dev.h"
-#else
-// MODE 2 of run_tiles (the one-launch sampling loop) is an experiment that the default build leaves out (gcn_loop_dev.h): the engine's
-// `if constexpr (LOOP)` branches only need these names to parse
-struct LoopArgs;
-template <bool TILES> __device__ unsigned long long loop_decode(unsigned int, unsigned int, unsigned int, const LoopArgs*);
-template <bool TILES> __device__ unsigned int loop_period_items(const LoopArgs*, unsigned int);
-template <int P, int NW> __device__ void loop_item_input(float*, const LoopArgs*, int, int, int, unsigned long long* = nullptr);
-#define LSTAT_DECL do { } while (0)
-#define LSTAT_T() 0ull
-#define LSTAT_ADD(i, v) do { } while (0)
-#define LSTAT_FLUSH() do { } while (0)
-#endif
-
-template <class A>
-__device__ __forceinline__ const ChainArgs& chain_view(const A& a) {
-  if constexpr (std::is_same<A, LoopArgs>::value) return a.c;
-  else return a;
-}
-
-// MODE 0: one tile per block, one conv per launch; 1: chained convs of one step; 2: the one-launch sampling loop (LoopArgs).
+// MODE 0: one tile per block, one conv per launch; 1: chained convs of one step.  (The one-launch sampling loop that was MODE 2 in rounds 4 - 5 - bit-equal,
+// 12 % slower - is recorded in docs/EXPERIMENTS.md 3.7 and lives in the history: git show c4b8e19:egohmr_amd/csrc/gcn_loop_dev.h.)
 template <int P, int MODE, int NW, class Args>
-__device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
-  constexpr bool CHAIN = MODE >= 1;
-  constexpr bool LOOP = MODE == 2;
-#ifdef EHM_P3_MFMA32
-  constexpr bool M16 = false;        // the split-f16 mode on v_mfma_f32_32x32x16_f16 as in rounds 2 - 4 (same-box A/B of the two forms)
-#else
-  constexpr bool M16 = P == 3;       // split-f16 mode: v_mfma_f32_16x16x32_f16 (see "16 x 16 x 32" below)
-#endif
+__device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
+  constexpr bool CHAIN = MODE == 1;
+  constexpr bool M16 = P == 3;       // split-f16 mode: v_mfma_f32_16x16x32_f16 (see "16 x 16 x 32" below); plain f16: v_mfma_f32_32x32x16_f16
   static_assert(NW == 4 || (NW == 8 && P == 1 && CHAIN), "the 8-wave tile exists for the chained f16 kernel (f16x3 is power-bound: 8 waves measured 150 vs 152 us)");
-  const auto& a = [&]() -> const auto& { if constexpr (MODE >= 1) return chain_view(a_); else return a_; }();
   // MODE.FP16_OVFL = 1 for the life of the wave: every f32 -> f16 conversion of the epilogue clamps to +-65504 instead of producing inf
   // (hwreg MODE = 1, bit 23).  The explicit clamps this replaces were 144 v_med3_f32 + their canonicalising v_max_f32 per wave and tile,
   // in an epilogue during which the block's matrix pipes idle.
@@ -382,31 +356,17 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
   // ---- chained launch: tickets, dependencies
   unsigned int q = 0, ipl = 0, total = 0;
   volatile unsigned int* slot = (volatile unsigned int*)(lds + ((KT - 2) & 1) * STG);   // dead LDS between barrier(KT-2) and the next tile's DMA
-  unsigned int l_period = 0;                 // MODE 2: items per period of my queue (loop_decode)
-  auto unpack = [&](unsigned long long v, Tile& o) {
-    o.kind = (int)(v & 7u); o.layer = (int)((v >> 3) & 31u); o.n_tile = (int)((v >> 8) & 0xfffu); o.m_tile = (int)((v >> 20) & 0xfffffu);
-    o.step = (int)(v >> 40);
-  };
-  auto decode = [&](unsigned int t, Tile& o) {      // (MODE 2: a real call - never between a tile's head and its epilogue, see pk_next)
-    if constexpr (LOOP) {
-      const unsigned long long v = loop_decode<true>(t, q, l_period, &a_);
-      o.kind = (int)(v & 7u); o.layer = (int)((v >> 3) & 31u); o.n_tile = (int)((v >> 8) & 0xfffu); o.m_tile = (int)((v >> 20) & 0xfffffu);
-      o.step = (int)(v >> 40);
-    } else if constexpr (CHAIN) {
+  auto decode = [&](unsigned int t, Tile& o) {
+    if constexpr (CHAIN) {
       const int layer = (int)(t / ipl), r = (int)(t % ipl);
       o.m_tile = (int)q + a.nq * (r / a.n_tiles);
       o.n_tile = r % a.n_tiles;
       o.layer = layer;
-      o.kind = K_HIDDEN; o.step = 0;
     }
   };
   // what a conv tile waits for: a monotone counter and the value it must have reached (nullptr: nothing)
   auto dep_of = [&](const Tile& t, unsigned int& target) -> const unsigned int* {
-    if constexpr (LOOP) {
-      if (t.layer == 0) { target = (unsigned int)(t.step + 1) * (unsigned int)a_.ny; return a_.in_done + t.m_tile; }
-      target = (unsigned int)(t.step + 1) * (unsigned int)a.n_tiles;
-      return a.done + (size_t)(t.layer - 1) * a.m_tiles + t.m_tile;
-    } else if constexpr (CHAIN) {
+    if constexpr (CHAIN) {
       target = (unsigned int)a.n_tiles;
       return t.layer > 0 ? a.done + (size_t)(t.layer - 1) * a.m_tiles + t.m_tile : nullptr;
     } else {
@@ -421,32 +381,23 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         __builtin_amdgcn_s_sleep(4);
         ++spins;
         if (spins > (1 << 22) || ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-          if (LOOP && spins > (1 << 22)) {
-            if ((__hip_atomic_fetch_or(a.err, 0x2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x2u) == 0u) {   // first to give up: leave a note (EHM_LOOP_DEBUG)
-              a.err[3] = (unsigned int)(f - a.tickets); a.err[4] = target; a.err[5] = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              a.err[6] = (unsigned int)blockIdx.x; a.err[7] = q;
-            }
-          }
           __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_or(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
     }
   };
-  LSTAT_DECL;
   auto poll_deps = [&](const Tile& t) {       // (whole block; ends with a barrier)
     if constexpr (CHAIN) {
       unsigned int target = 0;
       const unsigned int* f = dep_of(t, target);
-      [[maybe_unused]] const unsigned long long lt0 = LSTAT_T();
       if (f != nullptr && tid == 0) {
         // never hang the device: give up after ~1 s (or at once when somebody else already has) and flag the launch - and the whole
         // loop - as failed
         wait_counter(f, target);
       }
       __syncthreads();
-      LSTAT_ADD(1, LSTAT_T() - lt0);
     }
   };
   auto publish = [&](const Tile& t) {
@@ -454,27 +405,9 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       if (tid == 0) __hip_atomic_fetch_add(&a.done[(size_t)t.layer * a.m_tiles + t.m_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  auto fetch_ticket = [&]() -> unsigned int {          // (whole block; LDS must be idle)
-    unsigned int t = 0;
-    if constexpr (CHAIN) {
-      __syncthreads();
-      if (tid == 0) slot[0] = __hip_atomic_fetch_add(&a.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      t = __builtin_amdgcn_readfirstlane(slot[0]);
-      __syncthreads();
-    }
-    return t;
-  };
-
   Tile cur{}, nxt{};
   unsigned int t_cur = 0;
-  if constexpr (LOOP) {
-    q = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (unsigned int)a.nq;   // HW_REG_XCC_ID[3:0] -> my queue
-    l_period = loop_period_items<true>(&a_, q);
-    if (tid == 0) wait_counter(a_.alive + q, 1u);     // my XCD's item blocks are resident (else: flagged, never a hang)
-    total = l_period * (unsigned int)(a_.nsteps + 1);
-    t_cur = l_period ? fetch_ticket() : 0u;
-  } else if constexpr (CHAIN) {
+  if constexpr (CHAIN) {
     q = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (unsigned int)a.nq;   // HW_REG_XCC_ID[3:0] -> my queue
     const int cm = (a.m_tiles - (int)q + a.nq - 1) / a.nq;                          // row tiles of this queue: q, q + nq, ...
     ipl = (unsigned int)((cm > 0 ? cm : 0) * a.n_tiles);
@@ -491,31 +424,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
 
   bool pending_publish = false;     // the previous tile's stores are issued but its counter is not bumped yet
   Tile prev{};
-  for (;;) {        // (MODE 2 only loops: [items that are not conv tiles]* -> a pipelined run of conv tiles -> ...)
-  if constexpr (LOOP) {
-    bool finished = false;
-    for (;;) {
-      if (t_cur >= total) { finished = true; break; }
-      [[maybe_unused]] const unsigned long long lt0 = LSTAT_T();
-      decode(t_cur, cur);
-      if (cur.kind == K_HIDDEN) break;
-      if (cur.kind == K_INPUT) {
-        [[maybe_unused]] const unsigned long long lt1 = LSTAT_T();
-        loop_item_input<P, NW>(lds, &a_, cur.step, cur.m_tile, cur.n_tile);
-        LSTAT_ADD(2, LSTAT_T() - lt1); LSTAT_ADD(3, 1);
-      } else {
-        LSTAT_ADD(9, 1);                            // (lead-in / drain of the staggered schedule)
-      }
-      t_cur = fetch_ticket();
-      LSTAT_ADD(8, LSTAT_T() - lt0);
-    }
-    if (finished) break;
-    LSTAT_ADD(11, 1);
-    pending_publish = false;
-    __syncthreads();
-  }
   if (!CHAIN || t_cur < total) {
-    if constexpr (CHAIN && !LOOP) decode(t_cur, cur);
+    if constexpr (CHAIN) decode(t_cur, cur);
     set_tile_ptrs(cur);
     issue_b_early();
     poll_deps(cur);
@@ -552,13 +462,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     TSTAMP(5);
     thread_consts();
     unsigned int t_next = 0xffffffffu;
-    unsigned long long pk_next = (unsigned long long)K_SKIP;   // MODE 2: the next ticket decoded HERE, while no accumulator / fragment is live (loop_decode is a call)
     if constexpr (CHAIN)
-      if (tid == 0) {
-        t_next = __hip_atomic_fetch_add(&a.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if constexpr (LOOP)
-          if (t_next < total) pk_next = loop_decode<true>(t_next, q, l_period, &a_);
-      }
+      if (tid == 0) t_next = __hip_atomic_fetch_add(&a.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned int dep_seen = 0;
     zero_acc();
     Frags<P> f0, f1;
@@ -703,13 +608,12 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     if constexpr (CHAIN) {
       if (tid == 0 && t_next < total) {        // were the producers of my NEXT tile complete already?
         Tile tn;
-        if constexpr (LOOP) unpack(pk_next, tn);
-        else decode(t_next, tn);
+        decode(t_next, tn);
         // one relaxed read, no waiting: a next tile that depends on the tile I am still computing (next layer, same rows) simply reads
         // an incomplete counter and takes the late path; nobody ever WAITS while holding an unpublished tile, so no cycle can form
         unsigned int target = 0;
         const unsigned int* f = dep_of(tn, target);
-        dep_seen = tn.kind != K_HIDDEN ? 0u : ((f == nullptr || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) ? 1u : 0u);
+        dep_seen = (f == nullptr || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) ? 1u : 0u;
       }
     }
     if constexpr (M16) {
@@ -727,7 +631,6 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       if constexpr (CHAIN)
         if (tid == 0) {                                           // stage 0 is dead from here on
           slot[0] = t_next; slot[1] = dep_seen;
-          if constexpr (LOOP) { slot[2] = (unsigned int)pk_next; slot[3] = (unsigned int)(pk_next >> 32); }
         }
       ldA(I0{}, 1);
       mm(I1{}, I1{});
@@ -744,7 +647,6 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       if constexpr (CHAIN)
         if (tid == 0) {                                           // stage `buf` is dead from here on
           slot[0] = t_next; slot[1] = dep_seen;
-          if constexpr (LOOP) { slot[2] = (unsigned int)pk_next; slot[3] = (unsigned int)(pk_next >> 32); }
         }
       read_frags(f0, buf ^ 1, 0);
       mfmas(f_last);
@@ -761,9 +663,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     unsigned int nt = 0xffffffffu, ready = 0;
     if constexpr (M16) tile16(I1{}, 1, KT - 1, 2);            // last K tile (stage 1): first half + barrier; its second half runs under the table loads below
     else phases_before_barrier((KT - 1) & 1);
-    unsigned int pk_lo = 0, pk_hi = 0;
     if constexpr (CHAIN) { nt = slot[0]; ready = slot[1]; }
-    if constexpr (LOOP) { pk_lo = slot[2]; pk_hi = slot[3]; }
     {
       Frags<P>& fm = f_last;
       const __amdgpu_buffer_rsrc_t dsB = ehm_buffer_rsrc(io.Ds);
@@ -819,17 +719,12 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();                        // everybody has read the slot (and, long ago, its last fragments): all LDS is dead
       if (have_next) {
-        if constexpr (LOOP) unpack(((unsigned long long)__builtin_amdgcn_readfirstlane(pk_hi) << 32) | __builtin_amdgcn_readfirstlane(pk_lo), nxt);
-        else decode(nt, nxt);
-        if (LOOP && nxt.kind != K_HIDDEN) {   // the next ticket is not a conv tile: this run of the tile pipeline ends here
-          have_next = false;
-        } else {
-          set_tile_ptrs(nxt);
-          issue_b_early();
-          if (ready) {                        // stage 0 now; stage 1's pieces serve as the epilogue's scratch first
-            issue_a0();
-            a_issued = true;
-          }
+        decode(nt, nxt);
+        set_tile_ptrs(nxt);
+        issue_b_early();
+        if (ready) {                        // stage 0 now; stage 1's pieces serve as the epilogue's scratch first
+          issue_a0();
+          a_issued = true;
         }
       }
     }
@@ -989,6 +884,10 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
     TSTAMP(7);
     const int rbase = STG + wave * 256 + (lr & 7) * 32 + (M16 ? (c8 ^ (16 * ((lr & 3) >> 1))) : c8);   // item it: + piece 2 it + (lr >> 3)
     auto roff = [&](int it) { return rbase + ((lr >> 3) ? poff(2 * it + 1) : poff(2 * it)); };
+    // range guard: the f16 conversions below SATURATE (MODE.FP16_OVFL) - |v| >= 65504 clamps the hi half (the X2 value is then good to ~1e-4
+    // relative only, beyond 131008 it is lost; plain f16 rows lose it at once).  Nothing becomes inf / NaN, so nothing downstream would notice:
+    // the tile's largest |v| (one v_max3_f32 per two stored values) raises bit 2 of the handle's status word instead
+    float vmax = 0.f;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (P == 3) { if (p == 1) load_res_pass(1); }
@@ -1024,6 +923,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
             for (int c = 0; c < 8; ++c) v[c] += (float)rh[c];
           }
         }
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) vmax = fmaxf(vmax, fmaxf(fabsf(v[c]), fabsf(v[c + 1])));
         const unsigned int vo = item_vrow(p, it) * orow + col_out;
         if (out_f32) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]}), yB, vo, 0, kStoreAux);
@@ -1040,6 +941,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         }
       }
     }
+    if (!out_f32 && vmax >= 65504.f) __hip_atomic_fetch_or(a.sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // stage 1's activation pieces are free again: fetch them for the next tile
     if constexpr (CHAIN) {
       if (a_issued) issue_late();
@@ -1054,12 +956,10 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have reached L2
         __syncthreads();
         publish(prev);
-        t_cur = nt;                                            // (MODE 2: the outer loop goes on with this ticket)
+        t_cur = nt;
         break;
       }
-      LSTAT_ADD(10, 1);
       if (!a_issued) {                                        // producers were not complete yet (or the next tile is in a later layer)
-        LSTAT_ADD(12, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         publish(prev);
@@ -1073,12 +973,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
       t_cur = nt;
     }
   }
-  if constexpr (!LOOP) break;
-  }   // for (;;)
 
-  if constexpr (LOOP) {
-    LSTAT_FLUSH();                                  // (the audit of a loop launch is the item kernel's: its last block checks body_done)
-  } else if constexpr (CHAIN) {
+  if constexpr (CHAIN) {
     // audit + reset: the last block to run out of tickets checks that every row tile of the last conv was produced by all its channel
     // tiles (a queue whose XCD received no block - CU masking - would otherwise go unnoticed), then zeroes the tickets and counters
     // for the NEXT launch on this handle (stream order): no memset node between the steps of a sampling loop.
@@ -1094,7 +990,7 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a_) {
         ok = ok && __hip_atomic_load(&a.done[(size_t)(a.nl - 1) * a.m_tiles + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)a.n_tiles;
       if (!ok) {
         __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(a.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       for (int i = tid; i < a.nl * a.m_tiles; i += 64 * NW) a.done[i] = 0u;
@@ -1117,19 +1013,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void gcn_hidden_chain_ker
 }
 
 // float32 [rows, K] <-> plain f16 [rows, K]
-__global__ void pack_half_kernel(const float* __restrict__ X, half_t* __restrict__ Y, size_t n, float scale) {
+__global__ void pack_half_kernel(const float* __restrict__ X, half_t* __restrict__ Y, size_t n, float scale, unsigned int* sticky = nullptr) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) Y[i] = (half_t)fminf(fmaxf(X[i] * scale, -65504.f), 65504.f);
+  if (i >= n) return;
+  const float v = X[i] * scale;
+  Y[i] = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
+  if (sticky && fabsf(v) >= 65504.f) __hip_atomic_fetch_or(sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void unpack_half_kernel(const half_t* __restrict__ X, float* __restrict__ Y, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) Y[i] = (float)X[i];
 }
 template <int G>
-__global__ void pack_x2_kernel(const float* __restrict__ X, half_t* __restrict__ Y, int64_t rows, int K) {
+__global__ void pack_x2_kernel(const float* __restrict__ X, half_t* __restrict__ Y, int64_t rows, int K, unsigned int* sticky = nullptr) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * K) return;
   split_store<G>(Y, i / K, (int)(i % K), K, X[i]);
+  if (sticky && fabsf(X[i]) >= 65504.f) __hip_atomic_fetch_or(sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int G>
 __global__ void unpack_x2_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int64_t rows, int K) {
@@ -1156,16 +1056,13 @@ extern "C" int ehm_dbg_set(void* p) { unsigned long long* q = (unsigned long lon
 #endif
 
 void ehm_pack_half(const float* X, void* Y, size_t n, float scale, hipStream_t st) {
-  hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)ceil_div((int64_t)n, 256)), dim3(256), 0, st, X, (half_t*)Y, n, scale);
+  hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)ceil_div((int64_t)n, 256)), dim3(256), 0, st, X, (half_t*)Y, n, scale, (unsigned int*)nullptr);
 }
 
 // One conv per launch (ehm_gcn_hidden_layer in the f16 modes).
 int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
                             hipStream_t st) {
   if (!shape_ok(h, rows_pad)) return EHM_EINVAL;
-#ifdef EHM_WITH_WIDE_TILE
-  if (h->wide && h->precision == EHM_PREC_F16X3 && h->hid % 128 == 0) return ehm_gcn_wide_layer_impl(h, layer, X, residual, out, rows_pad, out_f32, st);
-#endif
   OneArgs a;
   a.L = h->hidden[layer];
   a.X = X;
@@ -1173,6 +1070,7 @@ int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const vo
   a.Y = out;
   a.m_tiles = (int)(rows_pad / 192);
   a.out_f32 = out_f32 ? 1 : 0;
+  a.sticky = h->chain_sticky;
   const int blocks = a.m_tiles * (h->hid / 64);
   if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL(gcn_hidden_tile_kernel<3>, dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gcn_hidden_tile_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
@@ -1238,15 +1136,21 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   return 0;
 }
 
-#ifdef EHM_WITH_LOOP_ENGINE
-#include "gcn_loop_host.inc"
-#endif
-
 extern "C" int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, int group, void* stream) {
   EHM_CHECK_ARG(X && X2 && rows > 0 && K > 0 && K % 32 == 0 && (group == 0 || group == 32));
   const dim3 grid((unsigned)ceil_div(rows * K, 256));
-  if (group == 0) hipLaunchKernelGGL(pack_half_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, (size_t)rows * K, 1.f);
-  else hipLaunchKernelGGL(pack_x2_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K);
+  if (group == 0) hipLaunchKernelGGL(pack_half_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, (size_t)rows * K, 1.f, (unsigned int*)nullptr);
+  else hipLaunchKernelGGL(pack_x2_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K, (unsigned int*)nullptr);
+  EHM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ehm_gcn_pack_activations_checked(ehm_gcn* h, const float* X, void* X2, int64_t rows, void* stream) {
+  EHM_CHECK_ARG(h && X && X2 && rows > 0 && h->precision != EHM_PREC_F32);
+  const int K = h->hid;
+  const dim3 grid((unsigned)ceil_div(rows * K, 256));
+  if (h->precision == EHM_PREC_F16) hipLaunchKernelGGL(pack_half_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, (size_t)rows * K, 1.f, h->chain_sticky);
+  else hipLaunchKernelGGL(pack_x2_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, rows, K, h->chain_sticky);
   EHM_LAUNCH_CHECK();
   return 0;
 }

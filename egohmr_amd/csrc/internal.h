@@ -52,28 +52,7 @@ int ehm_num_cus();   // multiProcessorCount of the current device (cached)
 // gcn_tile.hip (f16 matrix-core hidden convs: 'f16x3' split operands and plain 'f16')
 int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
                             hipStream_t st);
-#ifdef EHM_WITH_WIDE_TILE
-int ehm_gcn_wide_layer_impl(const ehm_gcn* h, int layer, const void* X, const void* residual, void* out, int64_t rows_pad, bool out_f32,
-                            hipStream_t st);   // gcn_wide.hip (experiment)
-#endif
 int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, hipStream_t st);
-#ifdef EHM_WITH_LOOP_ENGINE
-// the one-launch sampling loop (gcn_loop_host.inc, experiment): launch description filled by sampler.hip
-struct ehm_loop_launch {
-  void* bufs[3];                 // activation ping-pong [passes * B * 24, hid]
-  int B, passes, nsteps;
-  const struct GcnInputArgs* in; // x = loop state [B,144], tvec = first step of the segment, Y = bufs[0]
-  const void* step_body;         // StepBodyArgs (step_dev.h): vis, x, noise (first step's draw), x_next = state, x0, ddim, passes, B, betas, mean, std, Rws, joints, pose6d, jstride
-  const ehm_step_coefs* coefs;   // DEVICE [nsteps]
-  const void* smpl_dev;          // SmplDev
-  float* A_steps; void* pf_steps; int64_t pf_bytes_per_step;
-  float* trace;                  // [nsteps,B,144] or nullptr
-  float* x_final;                // destination of the last step's x_{t-1}
-  int lbs_every_step, last_is_final;
-};
-int ehm_gcn_tile_loop_impl(ehm_gcn* h, const ehm_loop_launch* L, hipStream_t st);
-int ehm_upload_step_coefs(const ehm_step_coefs* host, ehm_step_coefs* dev, int n, hipStream_t st);
-#endif
 void ehm_pack_half(const float* X, void* Y, size_t n, float scale, hipStream_t st);
 // gcn.hip
 int ehm_gcn_reserve_rows(ehm_gcn* h, int64_t rows_pad);   // sync words + output-conv scratch for up to rows_pad rows (allocates: not inside a capture)

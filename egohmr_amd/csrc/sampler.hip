@@ -28,14 +28,8 @@ extern "C" const char* ehm_last_error(void) { return g_err; }
 extern "C" const char* ehm_target_arch(void) { return "gfx950"; }
 extern "C" const char* ehm_build_features(void) {
   return ""
-#ifdef EHM_WITH_LOOP_ENGINE
-         "loop_engine "
-#endif
 #ifdef EHM_STAMPS
          "stamps "
-#endif
-#ifdef EHM_WITH_WIDE_TILE
-         "wide_tile "
 #endif
       ;
 }
@@ -154,7 +148,7 @@ extern "C" int ehm_ddim_step(const float* x, const float* x0, const float* noise
 
 // ------------------------------------------------------------------------------------------------ whole loop
 namespace {
-constexpr int kLoopSegment = 128;      // steps per launch of the one-launch loop (bounds the per-step transform / fragment storage)
+constexpr int kSkinSegment = 128;      // steps per deferred skinning launch (bounds the per-step transform / fragment slots)
 struct Workspace {
   float* X[3];      // activation ping-pong [rows_pad, hid]
   float* x_cur;     // [B,144]
@@ -171,14 +165,13 @@ struct Workspace {
   void* g_scratch;     // bbox / selection / dA / dpose-feature (guidance.hip)
   float* nl_qkv;       // non-local block: [rows, 3 Ci] theta | phi | g
   float* nl_y;         //                  [rows, Ci]   attention output
-  // one-launch loop (gcn_tile.hip): a segment of up to loop_seg steps leaves these behind for ONE skinning launch
-  ehm_step_coefs* loop_coefs;   // [loop_seg] device copy of the segment's rows of `steps`
-  float* loop_A;                // [loop_seg, B, 24, 12]
-  void* loop_pf;                // [loop_seg, ceil(B/32), 14, 2, 64] x 16 B
+  // deferred skinning: up to skin_seg steps leave these behind for ONE pose + ONE skinning launch
+  float* loop_A;                // [skin_seg, B, 24, 12]
+  void* loop_pf;                // [skin_seg, ceil(B/32), 14, 2, 64] x 16 B
   float* loop_verts;            // [B, V, 3]   vertices of the segment's intermediate steps (computed like the final ones, not consumed)
   float* loop_joints;           // [B, J, 3]
   float* loop_x0;               // [skin_seg, B, 144]  x0 of the pending steps (their poses are computed in front of the skinning launch, step.hip)
-  int loop_seg, skin_seg;
+  int skin_seg;
   int64_t rows, rows_pad;
   int64_t total_bytes;
 };
@@ -215,18 +208,13 @@ Workspace carve(const ehm_sample_desc* d, int hid, int V, int n_joints, char* ba
   }
   // deferred skinning: with lbs_every_step the steps leave their transforms / blend fragments in per-step slots and ONE skinning launch per
   // `skin_seg` steps computes their vertices (the same arithmetic; 14 us per step instead of a 25-30 us launch inside every step)
-  const bool engine = d->loop_engine && d->B % 8 == 0 && d->num_masked < 0 && d->nonlocal_ci == 0;
-  if (d->B >= ehm_skin_min_bodies() && (d->lbs_every_step || engine)) {
-    w.skin_seg = d->num_steps < kLoopSegment ? d->num_steps : kLoopSegment;
+  if (d->B >= ehm_skin_min_bodies() && d->lbs_every_step) {
+    w.skin_seg = d->num_steps < kSkinSegment ? d->num_steps : kSkinSegment;
     w.loop_A = take((int64_t)w.skin_seg * d->B * kJ * 12);
     w.loop_pf = take((int64_t)w.skin_seg * (ehm_skin_pf_bytes_per_step(d->B) / 4));
     w.loop_verts = take((int64_t)d->B * V * 3);
     w.loop_joints = take((int64_t)d->B * n_joints * 3);
     w.loop_x0 = take((int64_t)w.skin_seg * d->B * kPoseDim);
-    if (engine) {
-      w.loop_seg = w.skin_seg;
-      w.loop_coefs = (ehm_step_coefs*)take(round_up(w.loop_seg, 64) * (int64_t)(sizeof(ehm_step_coefs) / 4));   // (uploaded in chunks of 64 rows)
-    }
   }
   w.total_bytes = off;
   return w;
@@ -249,12 +237,6 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   EHM_CHECK_ARG(d->passes == 1 || ehm_gcn_virtual_bodies(gcn, d->B, 2) == d->B + (d->num_masked >= 0 ? d->num_masked : d->B));   // desc and ehm_gcn_set_pass_map agree
   const int hid = ehm_gcn_hid(gcn), nh = ehm_gcn_num_hidden(gcn), V = ehm_smpl_num_verts(smpl);
   EHM_CHECK_ARG(nh % 2 == 0);
-#ifndef EHM_WITH_LOOP_ENGINE
-  if (d->loop_engine) {
-    ehm_set_error("ehm_sample_desc.loop_engine = 1, but this library was built without -DEHM_WITH_LOOP_ENGINE (the one-launch loop is an experiment, docs/EXPERIMENTS.md 3.7)");
-    return EHM_EINVAL;
-  }
-#endif
   bool any_guided = false;
   for (int k = 0; k < d->num_steps; ++k) any_guided |= steps[k].grad_scale != 0.f;
   EHM_CHECK_ARG(!any_guided || (scene && d->num_scene_points > 0 && !d->ddim));
@@ -282,56 +264,6 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
     ~PrecisionGuard() { if (armed) ehm_gcn_set_precision(g, prec); }
   } guard{gcn, base_prec, lowprec > 0};
   auto prec_of = [&](int k) { return (lowprec > 0 && k < lowprec) ? 2 : base_prec; };
-  // ---- the one-launch loop (gcn_tile.hip: gcn_loop_kernel): runs of consecutive UNGUIDED steps of one precision as ONE persistent launch
-  // (input conv, hidden convs, output responses, per-body step chained per 8-body group with counters; a group runs ahead into the next
-  // step while others finish this one) + ONE skinning launch for the run.  Guided steps and ineligible shapes take the per-step launches below.
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);
-#ifdef EHM_WITH_LOOP_ENGINE
-  const bool engine_ok = w.loop_seg > 0 && cap == hipStreamCaptureStatusNone && base_prec != 0 && nlp->Ci == 0 && nh >= 2 &&
-                         ehm_gcn_mask_slot(gcn, d->passes) == nullptr && ehm_gcn_chain_enabled(gcn) && ehm_smpl_has_mfma_skin(smpl);
-  auto run_segment = [&](int k0, int k1) -> int {
-    const int ns = k1 - k0;
-    const bool final_seg = k1 == d->num_steps;
-    if (lowprec > 0) ehm_gcn_set_precision(gcn, prec_of(k0));
-    int r = ehm_upload_step_coefs(steps + k0, w.loop_coefs, ns, st);      // (through kernel arguments: captured at launch)
-    if (r != 0) return r;
-    const int64_t pf_bytes = ehm_skin_pf_bytes_per_step(B);
-    if (B % 32 != 0) EHM_HIP(hipMemsetAsync(w.loop_pf, 0, (size_t)ns * pf_bytes, st));       // padding bodies of every step's last 32-body tile
-    GcnInputArgs in;
-    r = ehm_gcn_input_args(gcn, h_img, h_oth, vis, w.x_cur, Wx, tvecs + (int64_t)k0 * 2 * hid, w.X[0], B, d->passes, &in);
-    if (r != 0) return r;
-    StepBodyArgs sb{};
-    sb.vis = vis; sb.x = w.x_cur; sb.noise = noise + (int64_t)(1 + k0) * n; sb.grad = nullptr; sb.x_next = w.x_cur; sb.x0 = x0_final;
-    sb.ddim = d->ddim; sb.passes = d->passes; sb.B = B; sb.do_pose = 1; sb.mask_slot = nullptr;
-    sb.betas = betas; sb.mean = mean; sb.std_ = std_; sb.Rws = R; sb.Aws = w.loop_A; sb.joints = joints; sb.pose6d = pose6d;
-    sb.jstride = (kJ + ehm_smpl_num_extra(smpl)) * 3;
-    sb.pf = (sk_half8*)w.loop_pf; sb.trace = nullptr;
-    SmplDev sd;
-    ehm_smpl_dev(smpl, &sd);
-    ehm_loop_launch L{};
-    for (int i = 0; i < 3; ++i) L.bufs[i] = w.X[i];
-    L.B = B; L.passes = d->passes; L.nsteps = ns; L.in = &in; L.step_body = &sb; L.coefs = w.loop_coefs; L.smpl_dev = &sd;
-    L.A_steps = w.loop_A; L.pf_steps = w.loop_pf; L.pf_bytes_per_step = pf_bytes;
-    L.trace = trace ? trace + (int64_t)k0 * n : nullptr;
-    L.x_final = final_seg ? x_final : w.x_cur;
-    L.lbs_every_step = d->lbs_every_step; L.last_is_final = final_seg ? 1 : 0;
-    {
-      const int p = prec_of(k0);
-      EhmProfScope ps(p == 1 ? EHM_PROF_LOOP_F16X3 : EHM_PROF_LOOP_F16, st);
-      r = ehm_gcn_tile_loop_impl(gcn, &L, st);
-    }
-    if (r != 0) return r;
-    if (d->lbs_every_step)
-      r = ehm_skin_steps_impl(smpl, w.loop_A, w.loop_pf, ns, final_seg ? ns - 1 : -1, B, verts, joints, w.loop_verts, w.loop_joints, st);
-    else if (final_seg)
-      r = ehm_skin_steps_impl(smpl, w.loop_A + (int64_t)(ns - 1) * B * kJ * 12, (const char*)w.loop_pf + (int64_t)(ns - 1) * pf_bytes, 1, 0, B, verts, joints,
-                              w.loop_verts, w.loop_joints, st);
-    return r;
-  };
-#else
-  (void)cap;
-#endif
   // ---- deferred skinning of the per-step launches (see carve): slots filled since the last skinning launch
   // (a body model with dense skinning weights has no MFMA fragments: its steps keep the VALU skinning launch of ehm_step_body_impl - the workspace
   //  was sized without looking at the handle, the slots simply stay unused)
@@ -360,18 +292,6 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   bool input_done = false;          // step k's input conv already ran inside step k-1's skinning launch
   for (int k = 0; k < d->num_steps && rc == 0; ++k) {
     const ehm_step_coefs& c = steps[k];
-#ifdef EHM_WITH_LOOP_ENGINE
-    if (engine_ok && !input_done && c.grad_scale == 0.f && prec_of(k) == 1) {      // (the loop kernels are built for the split-f16 mode)
-      int e = k;
-      while (e < d->num_steps && e - k < w.loop_seg && steps[e].grad_scale == 0.f && prec_of(e) == prec_of(k)) ++e;
-      if (e - k >= 2) {
-        rc = flush_skin(false);
-        if (rc == 0) rc = run_segment(k, e);
-        k = e - 1;
-        continue;
-      }
-    }
-#endif
     if (lowprec > 0) ehm_gcn_set_precision(gcn, prec_of(k));   // host-side kernel choice only; same X2 buffers
     const bool last = k == d->num_steps - 1;
     if (trace) EHM_HIP(hipMemcpyAsync(trace + (int64_t)k * n, w.x_cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -122,27 +122,21 @@ class Stage2Driver:
         jvis = inside(perspective_projection(g["joints"], zero, focal, center))                  # [B,24]
         vvis = inside(perspective_projection(g["vertices"], zero, focal, center))                # [B,V]
         S = self.S
-        gj, gja, gva = g["joints"].unsqueeze(1), g["joints_align"].unsqueeze(1), g["vertices_align"].unsqueeze(1)
-        per = {
-            "g_mpjpe": torch.sqrt(((p["joints_full"] - gj) ** 2).sum(-1)),                      # [B,S,24]  :399
-            "mpjpe": torch.sqrt(((p["joints_align"] - gja) ** 2).sum(-1)),                      # :409
-            "v2v": torch.sqrt(((p["vertices_align"] - gva) ** 2).sum(-1)),                      # [B,S,V]   :441
-        }
-        hat = M.similarity_align(p["joints_align"].reshape(-1, 24, 3).double(), gja.expand(-1, S, -1, -1).reshape(-1, 24, 3).double())
-        per["pa_mpjpe"] = torch.sqrt(((hat - gja.expand(-1, S, -1, -1).reshape(-1, 24, 3).double()) ** 2).sum(-1)).reshape(B, S, 24).float()   # :418-431
+        # :399-449 as four launches (csrc/eval.hip): per-point error, its mean and its sums over the visible / invisible points; PA-MPJPE's similarity
+        # transform (utils/pose_utils.py:10-66) in float64 inside the kernel - the reference copies to the host and loops numpy SVDs per sample
         res = {}
-        for k, v in per.items():
-            mask = vvis if k == "v2v" else jvis
-            res[k] = v.mean(-1)                                                                 # [B,S]
-            res[k + "_vis_sum"] = (v * mask.unsqueeze(1)).sum(-1)
-            res[k + "_invis_sum"] = (v * (~mask).unsqueeze(1)).sum(-1)
-        res["std_joints"] = M.std_diversity(p["joints_align"]) if S > 1 else torch.full((B,), float("nan"), device=dev)
-        res["std_joints_vis"] = M.std_diversity_masked(p["joints_align"], jvis) if S > 1 else res["std_joints"]
-        res["std_joints_invis"] = M.std_diversity_masked(p["joints_align"], ~jvis) if S > 1 else res["std_joints"]
-        if S > 1:
-            res["apd_joints"] = M.apd_diversity(p["joints_align"])
-            res["apd_joints_vis"] = M.apd_diversity(p["joints_align"], jvis)
-            res["apd_joints_invis"] = M.apd_diversity(p["joints_align"], ~jvis)
+        for k, r in (("g_mpjpe", M.point_errors(p["joints_full"], g["joints"], points=24, mask=jvis)),                       # :399
+                     ("mpjpe", M.point_errors(p["joints_align"], g["joints_align"], points=24, mask=jvis)),                  # :409
+                     ("v2v", M.point_errors(p["vertices_align"], g["vertices_align"], mask=vvis)),                           # :441
+                     ("pa_mpjpe", M.procrustes(p["joints_align"][:, :, :24].contiguous(), g["joints_align"][:, :24].contiguous(), mask=jvis))):   # :418-431
+            res[k], res[k + "_vis_sum"], res[k + "_invis_sum"] = r["mean"], r["vis_sum"], r["invis_sum"]                     # [B,S] each
+        if S > 1:                                                                               # :453-494: (std, apd) per joint selection, one launch each
+            ja = p["joints_align"][:, :, :24].contiguous()
+            res["std_joints"], res["apd_joints"] = M.diversity(ja)
+            res["std_joints_vis"], res["apd_joints_vis"] = M.diversity(ja, jvis)
+            res["std_joints_invis"], res["apd_joints_invis"] = M.diversity(ja, jvis, invert=True)
+        else:
+            res["std_joints"] = res["std_joints_vis"] = res["std_joints_invis"] = torch.full((B,), float("nan"), device=dev)
         if self.eval_contact:                                                                   # :496-505
             scene = batch["scene_pcd_verts_full"].unsqueeze(1).expand(-1, S, -1, -1).reshape(B * S, -1, 3)
             res["contact"] = M.contact_score(p["vertices_full"].reshape(B * S, -1, 3), scene).reshape(B, S).float()

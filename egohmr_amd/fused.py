@@ -37,7 +37,6 @@ class FusedSampler:
         self._sched_cache = {}          # schedule_key -> calibration info (calibrate_schedule)
         self.schedule_info = None       # the calibration the most recent 'auto' run used (None: ran all-f16x3 / explicit k)
         self.last_lowprec = 0
-        self.last_engine = False
         self.last_trace = None
 
     @property
@@ -56,32 +55,8 @@ class FusedSampler:
             self._free()
             m = self.model
             dm = m.diffusion_model
-            keep = []
-
-            def params(gc, bn):
-                def t(x):
-                    x = _lib.f32(x, m.device)
-                    keep.append(x)
-                    return x.data_ptr()
-                p = _lib.GConvParams()
-                p.W, p.M, p.adj2, p.bias = t(gc.W), t(gc.M), t(gc.adj2), t(gc.bias)
-                if bn is not None:
-                    p.bn_weight, p.bn_bias, p.bn_mean, p.bn_var = t(bn.weight), t(bn.bias), t(bn.running_mean), t(bn.running_var)
-                p.in_dim, p.out_dim = gc.in_features, gc.out_features
-                return p
-
             gi = dm.gconv_input[0]
-            inp = params(gi.gconv, gi.bn)
-            hidden = []
-            for blk in dm.gconv_layers:
-                hidden += [params(blk.gconv1.gconv, blk.gconv1.bn), params(blk.gconv2.gconv, blk.gconv2.bn)]
-            outp = params(dm.gconv_output, None)
-            arr = (_lib.GConvParams * len(hidden))(*hidden)
-            adj = _lib.f32(dm.adj, m.device)
-            h = C.c_void_p()
-            with torch.cuda.device(m.device):
-                _lib.check(_lib.lib().ehm_gcn_create(C.byref(h), _lib.ptr(adj), C.byref(inp), arr, len(hidden), C.byref(outp), dm.hid_dim,
-                                                     _lib.stream_ptr()), "ehm_gcn_create")
+            h, self._gcn_keep = dm.create_native_handle(m.device)             # (ModulatedGCN owns the parameter marshalling: ehm_gcn_create)
             self._gcn, self._gcn_key = h, key
             # fold InputProcess (Linear 6->512) into the x_t slice of the input conv: x @ (Wp^T W_k[2694:3206]) + bp W_k[...]
             W = gi.gconv.W.detach().double()                                            # [2, 3718, hid]
@@ -362,53 +337,14 @@ class FusedSampler:
         self.last_hidden = feat[:rows]
         return x0
 
-    @torch.no_grad()
     def _non_local(self, X, rows, rows_pad):
-        """NONLocalBlock2D on the joint axis (modulated_gcn.py:104-110): [theta|phi|g] as ONE 1x1-conv GEMM and W + BatchNorm(eval,
-        folded) + residual as another, both on ehm_conv_nhwc_split (rows = N, H = W = 1); the 24 x 24 softmax attention per body
-        in ehm_nonlocal_attention."""
-        m, L = self.model, _lib.lib()
-        nl = m.diffusion_model.non_local
-        hid, ci = m.diffusion_model.hid_dim, nl.inter_channels
-        self._nonlocal_packed()
-        (wq, sq, bq), (wo, so, bo) = self._nl_packed
-        s = _lib.stream_ptr()
-        qkv = torch.empty(rows, 3 * ci, device=m.device)
-        d = _lib.ConvDesc(X.data_ptr(), wq.data_ptr(), bq.data_ptr(), None, qkv.data_ptr(), rows, 1, 1, hid, 3 * ci, 1, 1, 1, 0, 0, sq)
-        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
-        y = torch.empty(rows, ci, device=m.device)
-        _lib.check(L.ehm_nonlocal_attention(qkv.data_ptr(), y.data_ptr(), rows // 24, ci, s), "ehm_nonlocal_attention")
-        Z = torch.zeros(rows_pad, hid, device=m.device)
-        d = _lib.ConvDesc(y.data_ptr(), wo.data_ptr(), bo.data_ptr(), X.data_ptr(), Z.data_ptr(), rows, 1, 1, ci, hid, 1, 1, 1, 0, 0, so)
-        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
-        return Z
+        """NONLocalBlock2D on the joint axis (modulated_gcn.py:104-110): ModulatedGCN.non_local_native."""
+        return self.model.diffusion_model.non_local_native(X, rows, rows_pad)
 
     def _nonlocal_packed(self):
-        """The non-local block's two 1x1-conv GEMMs in ehm_conv_nhwc_split's operand format: ([theta | phi | g] weights, scale, bias),
-        (W.0 with BatchNorm(eval) folded, scale, bias); re-packed when a parameter of the block changes."""
-        import math
-        m, L = self.model, _lib.lib()
-        nl = m.diffusion_model.non_local
-        key = tuple((p.data_ptr(), p._version) for p in list(nl.parameters()) + list(nl.buffers()))
-        if getattr(self, "_nl_key", None) != key:
-            def pack(w2, bias):                                   # [Co, K] float32 -> X2 split weights for the conv kernel
-                Co, K = w2.shape
-                Co_pad = (Co + 127) // 128 * 128
-                wp = torch.zeros(Co_pad, K, device=m.device)
-                wp[:Co] = w2
-                amax = float(wp.abs().max())
-                scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
-                buf = torch.empty(Co_pad, K, device=m.device)
-                with torch.cuda.device(m.device):
-                    _lib.check(L.ehm_split_pack(wp.data_ptr(), buf.data_ptr(), Co_pad, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
-                return buf, scale, bias.float().contiguous()
-            wqkv = torch.cat([nl.theta.weight, nl.phi.weight, nl.g.weight], 0).flatten(1).float()
-            bqkv = torch.cat([nl.theta.bias, nl.phi.bias, nl.g.bias], 0)
-            bn = nl.W[1]
-            sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
-            ww = (nl.W[0].weight.flatten(1).double() * sc[:, None]).float()
-            bw = ((nl.W[0].bias.double() - bn.running_mean.double()) * sc + bn.bias.double()).float()
-            self._nl_packed, self._nl_key = (pack(wqkv.detach(), bqkv.detach()), pack(ww.detach(), bw.detach())), key
+        dm = self.model.diffusion_model
+        self._nl_packed = dm.nonlocal_packed()
+        self._nl_key = dm._nl_key
         return self._nl_packed
 
     # ------------------------------------------------------------------ guidance pieces
@@ -683,8 +619,20 @@ class FusedSampler:
             defer_status=False, lowprec=None):
         """p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:391-508 / :618-718) in one native call.
         Returns the reference's dict(sample, pred_xstart, other_outputs)."""
-        with _lib.on_device(self.model.device):
-            return self._run_on_device(diffusion, batch, noise_stack, ddim, guided, cond_grad_weight, trace, prepared, denom_items, defer_status, lowprec)
+        m = self.model
+        with _lib.on_device(m.device):
+            try:
+                return self._run_on_device(diffusion, batch, noise_stack, ddim, guided, cond_grad_weight, trace, prepared, denom_items, defer_status, lowprec)
+            except _lib.EgoHMRRangeError:
+                # an activation left the f16 range and was clamped (status bit 2 of the handle, raised by the conv kernels' stores): never silent.
+                # on_saturation = 'f32': this checkpoint gets float32 activations from now on (exact-f32 MFMA path, ~3x slower) and the call runs again
+                if m.on_saturation != "f32" or m.gcn_precision == "f32":
+                    raise
+                import warnings
+                warnings.warn("egohmr_amd: a denoiser activation reached the f16 range (|x| >= 65504) and was clamped in the split-f16 / f16 path; "
+                              "EgoHMR.on_saturation = 'f32': switching this model to gcn_precision = 'f32' and re-running the call", RuntimeWarning)
+                m.gcn_precision = "f32"
+                return self._run_on_device(diffusion, batch, noise_stack, ddim, guided, cond_grad_weight, trace, prepared, denom_items, False, None)
 
     def _run_on_device(self, diffusion, batch, noise_stack, ddim, guided, cond_grad_weight, trace, prepared, denom_items, defer_status, lowprec):
         m, L = self.model, _lib.lib()
@@ -717,20 +665,8 @@ class FusedSampler:
                 self.schedule_info = self._sched_cache.get(skey)
             lowprec = self.lowprec_steps(T, n_guided, ddim, key=skey)
         self.last_lowprec = int(lowprec)                  # leading steps of THIS call on plain f16 operands
-        # the one-launch loop (ehm_sample_desc.loop_engine, docs/EXPERIMENTS.md 3.7) runs every item through both passes; exact pass pruning only pays
-        # more than it when a sizeable share of the items has every joint visible
-        engine = (bool(m.loop_engine) and not nonlocal_ci and B % 8 == 0 and B >= 24 and m.gcn_precision == "f16x3"
-                  and not (passes == 2 and m.prune_passes and st.num_masked < m.loop_engine_min_masked * B))
-        if m.loop_engine and "loop_engine" not in _lib.build_features():
-            raise _lib.EgoHMRHipError("EgoHMR.loop_engine = True needs a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_LOOP_ENGINE "
-                                      "(the one-launch loop is an experiment that the default build leaves out, docs/EXPERIMENTS.md 3.7)")
-        self.last_engine = bool(engine)                   # (runs of >= 2 unguided steps of this call go through the one-launch loop)
-        if engine:
-            _lib.check(L.ehm_gcn_set_pass_map(self.gcn(), None, None, -1), "ehm_gcn_set_pass_map")
-            num_masked = -1
-        else:
-            _, num_masked = self._apply_pass_map(st, passes)
-        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim), loop_engine=int(engine), per_step_launches=int(bool(m.per_step_launches)),
+        _, num_masked = self._apply_pass_map(st, passes)
+        desc = _lib.SampleDesc(B=B, passes=passes, num_steps=T, ddim=int(ddim), per_step_launches=int(bool(m.per_step_launches)),
                                lbs_every_step=int(m.lbs_every_step), num_scene_points=st.scene.shape[1] if any_guided else 0,
                                guide_denom=self.guide_denom(denom_items or B), tau=m.collision_tau, num_masked=num_masked,
                                guide_all_points=int(bool(m.guide_all_points)), lowprec_steps=int(lowprec), nonlocal_ci=int(nonlocal_ci))

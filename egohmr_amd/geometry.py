@@ -1,8 +1,10 @@
 """Rotation-representation helpers with the reference's names (utils/geometry.py).
 
 ``rot6d_to_rotmat`` runs the gfx950 kernel (csrc/smpl.hip: rot6d_kernel) - it is on the hot path
-(utils/geometry.py:47-66, called at models/egohmr/egohmr.py:260 and :529).  The remaining helpers
-are off the per-step path and are thin torch expressions kept for API completeness.
+(utils/geometry.py:47-66, called at models/egohmr/egohmr.py:260 and :529); ``rotation_matrix_to_angle_axis``
+(utils/konia_transform.py:316-340, the collision models' ``full_pose`` feed) runs csrc/eval.hip's kernel with a
+hand-written VJP.  The remaining helpers (a slice, the training-side aa_to_rotmat, the output garnish
+perspective_projection outside the fused packer) are thin torch expressions kept for API completeness.
 """
 from __future__ import annotations
 
@@ -75,45 +77,33 @@ def perspective_projection(points, translation, focal_length, camera_center=None
     return torch.stack((u, v), dim=-1)
 
 
-def _safe_div(num, den, eps=1.0e-6):
-    den = den.clone()
-    den[den.abs() < eps] += eps
-    den[den.abs() < eps] += eps       # applied twice, as utils/konia_transform.py:343-347 does
-    return num / den
+class _RotmatToAngleAxis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R):
+        R = _lib.f32(R).reshape(-1, 3, 3)
+        n = R.shape[0]
+        aa = torch.empty(n, 3, device=R.device, dtype=torch.float32)
+        with _lib.on_device(R.device):
+            _lib.check(_lib.lib().ehm_rotmat_to_angle_axis(_lib.ptr(R), _lib.ptr(aa), n, _lib.stream_ptr()), "ehm_rotmat_to_angle_axis")
+        ctx.save_for_backward(R)
+        return aa
+
+    @staticmethod
+    def backward(ctx, gaa):
+        (R,) = ctx.saved_tensors
+        gaa = _lib.f32(gaa)
+        gR = torch.empty_like(R)
+        with _lib.on_device(R.device):
+            _lib.check(_lib.lib().ehm_rotmat_to_angle_axis_bwd(_lib.ptr(R), _lib.ptr(gaa), _lib.ptr(gR), R.shape[0], _lib.stream_ptr()), "ehm_rotmat_to_angle_axis_bwd")
+        return gR
 
 
 def rotation_matrix_to_angle_axis(rotation_matrix: torch.Tensor) -> torch.Tensor:
-    """utils/konia_transform.py:316-340 (-> rotation_matrix_to_quaternion :349-443, quaternion_to_angle_axis :560-630).
-    Only feeds ``full_pose`` of COAP-style collision models (egohmr.py:495,540); the build's proxy does not consume it,
-    so this stays a torch expression off the per-step path."""
+    """utils/konia_transform.py:316-340 (-> rotation_matrix_to_quaternion :349-443, quaternion_to_angle_axis :560-630) on the HIP kernel
+    ehm_rotmat_to_angle_axis (csrc/eval.hip), autograd-capable (ehm_rotmat_to_angle_axis_bwd: the VJP through the branch the forward took).
+    Feeds ``full_pose`` of COAP-style collision models (egohmr.py:495, :540) under torch.enable_grad(); (*, 3, 3) -> (*, 3)."""
     if rotation_matrix.shape[-2:] != (3, 3):
         raise ValueError(f"Input size must be a (*, 3, 3) tensor. Got {rotation_matrix.shape}")
-    m = rotation_matrix.reshape(*rotation_matrix.shape[:-2], 9)
-    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.chunk(m, 9, dim=-1)
-    trace = m00 + m11 + m22
-    eps = 1.0e-6
-
-    def branch(lead, w_num, x_num, y_num, z_num, order):
-        sq = torch.sqrt(lead.clamp_min(eps)) * 2.0
-        parts = {"lead": 0.25 * sq, "w": _safe_div(w_num, sq) if w_num is not None else None,
-                 "x": _safe_div(x_num, sq) if x_num is not None else None, "y": _safe_div(y_num, sq) if y_num is not None else None,
-                 "z": _safe_div(z_num, sq) if z_num is not None else None}
-        return torch.cat([parts["lead"] if o == order else parts[o] for o in "wxyz"], dim=-1)
-
-    q_pos = branch(trace + 1.0, None, m21 - m12, m02 - m20, m10 - m01, "w")
-    q_1 = branch(1.0 + m00 - m11 - m22, m21 - m12, None, m01 + m10, m02 + m20, "x")
-    q_2 = branch(1.0 + m11 - m00 - m22, m02 - m20, m01 + m10, None, m12 + m21, "y")
-    q_3 = branch(1.0 + m22 - m00 - m11, m10 - m01, m02 + m20, m12 + m21, None, "z")
-    q = torch.where(trace > 0.0, q_pos, torch.where((m00 > m11) & (m00 > m22), q_1, torch.where(m11 > m22, q_2, q_3)))
-    cos_t, q1, q2, q3 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-    s2 = q1 * q1 + q2 * q2 + q3 * q3
-    sn = torch.sqrt(s2.clamp_min(eps))
-
-    def safe_atan2(y, x):
-        y = y.clone()
-        y[(y.abs() < eps) & (x.abs() < eps)] += eps
-        return torch.atan2(y, x)
-
-    two_theta = 2.0 * torch.where(cos_t < 0.0, safe_atan2(-sn, -cos_t), safe_atan2(sn, cos_t))
-    k = torch.where(s2 > 0.0, _safe_div(two_theta, sn, eps), 2.0 * torch.ones_like(sn))
-    return torch.stack((q1 * k, q2 * k, q3 * k), dim=-1)
+    if not rotation_matrix.is_cuda:
+        raise _lib.EgoHMRHipError("rotation_matrix_to_angle_axis runs on the HIP kernel (csrc/eval.hip); the CPU restatement is oracle/geometry.py")
+    return _RotmatToAngleAxis.apply(rotation_matrix).reshape(*rotation_matrix.shape[:-2], 3)

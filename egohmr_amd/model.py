@@ -111,8 +111,178 @@ class ModulatedGCN(nn.Module):
         if self.nonlocal_layer:                                     # modulated_gcn.py:93-94, reference parameter names
             self.non_local = _NonLocalBlock(hid_dim)
 
+    # ------------------------------------------------------------------ native handle (ehm_gcn_create) - shared with FusedSampler.gcn()
+    def create_native_handle(self, device):
+        """ehm_gcn_create on this module's parameters -> (handle, tensors that must stay alive while it lives).  The caller destroys it."""
+        import ctypes as C
+        keep = []
+
+        def params(gc, bn):
+            def t(x):
+                x = _lib.f32(x, device)
+                keep.append(x)
+                return x.data_ptr()
+            p = _lib.GConvParams()
+            p.W, p.M, p.adj2, p.bias = t(gc.W), t(gc.M), t(gc.adj2), t(gc.bias)
+            if bn is not None:
+                p.bn_weight, p.bn_bias, p.bn_mean, p.bn_var = t(bn.weight), t(bn.bias), t(bn.running_mean), t(bn.running_var)
+            p.in_dim, p.out_dim = gc.in_features, gc.out_features
+            return p
+
+        gi = self.gconv_input[0]
+        inp = params(gi.gconv, gi.bn)
+        hidden = []
+        for blk in self.gconv_layers:
+            hidden += [params(blk.gconv1.gconv, blk.gconv1.bn), params(blk.gconv2.gconv, blk.gconv2.bn)]
+        outp = params(self.gconv_output, None)
+        arr = (_lib.GConvParams * len(hidden))(*hidden)
+        adj = _lib.f32(self.adj, device)
+        keep.append(adj)
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().ehm_gcn_create(C.byref(h), _lib.ptr(adj), C.byref(inp), arr, len(hidden), C.byref(outp), self.hid_dim,
+                                                 _lib.stream_ptr()), "ehm_gcn_create")
+        return h, keep
+
+    # ------------------------------------------------------------------ the optional non-local block (modulated_gcn.py:93-94, :104-110)
+    def nonlocal_packed(self):
+        """The non-local block's two 1x1-conv GEMMs in ehm_conv_nhwc_split's operand format: ([theta | phi | g] weights, scale, bias),
+        (W.0 with BatchNorm(eval) folded, scale, bias); re-packed when a parameter of the block changes."""
+        import math
+        L = _lib.lib()
+        nl = self.non_local
+        device = nl.theta.weight.device
+        key = tuple((p.data_ptr(), p._version) for p in list(nl.parameters()) + list(nl.buffers()))
+        if getattr(self, "_nl_key", None) != key:
+            def pack(w2, bias):                                   # [Co, K] float32 -> X2 split weights for the conv kernel
+                Co, K = w2.shape
+                Co_pad = (Co + 127) // 128 * 128
+                wp = torch.zeros(Co_pad, K, device=device)
+                wp[:Co] = w2
+                amax = float(wp.abs().max())
+                scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
+                buf = torch.empty(Co_pad, K, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(L.ehm_split_pack(wp.data_ptr(), buf.data_ptr(), Co_pad, K, K, scale, _lib.stream_ptr()), "ehm_split_pack")
+                return buf, scale, bias.float().contiguous()
+            wqkv = torch.cat([nl.theta.weight, nl.phi.weight, nl.g.weight], 0).flatten(1).float()
+            bqkv = torch.cat([nl.theta.bias, nl.phi.bias, nl.g.bias], 0)
+            bn = nl.W[1]
+            sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            ww = (nl.W[0].weight.flatten(1).double() * sc[:, None]).float()
+            bw = ((nl.W[0].bias.double() - bn.running_mean.double()) * sc + bn.bias.double()).float()
+            self._nl_packed, self._nl_key = (pack(wqkv.detach(), bqkv.detach()), pack(ww.detach(), bw.detach())), key
+        return self._nl_packed
+
+    @torch.no_grad()
+    def non_local_native(self, X, rows, rows_pad):
+        """NONLocalBlock2D on the joint axis (modulated_gcn.py:104-110): [theta|phi|g] as ONE 1x1-conv GEMM and W + BatchNorm(eval,
+        folded) + residual as another, both on ehm_conv_nhwc_split (rows = N, H = W = 1); the 24 x 24 softmax attention per body
+        in ehm_nonlocal_attention.  X: float32 [rows_pad, hid] -> the same."""
+        import ctypes as C
+        L = _lib.lib()
+        nl = self.non_local
+        hid, ci = self.hid_dim, nl.inter_channels
+        (wq, sq, bq), (wo, so, bo) = self.nonlocal_packed()
+        s = _lib.stream_ptr()
+        qkv = torch.empty(rows, 3 * ci, device=X.device)
+        d = _lib.ConvDesc(X.data_ptr(), wq.data_ptr(), bq.data_ptr(), None, qkv.data_ptr(), rows, 1, 1, hid, 3 * ci, 1, 1, 1, 0, 0, sq)
+        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
+        y = torch.empty(rows, ci, device=X.device)
+        _lib.check(L.ehm_nonlocal_attention(qkv.data_ptr(), y.data_ptr(), rows // 24, ci, s), "ehm_nonlocal_attention")
+        Z = torch.zeros(rows_pad, hid, device=X.device)
+        d = _lib.ConvDesc(y.data_ptr(), wo.data_ptr(), bo.data_ptr(), X.data_ptr(), Z.data_ptr(), rows, 1, 1, ci, hid, 1, 1, 1, 0, 0, so)
+        _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
+        return Z
+
+    # ------------------------------------------------------------------ ModulatedGCN.forward on its own (modulated_gcn.py:99-116)
+    precision = "f16x3"      # arithmetic of the standalone call: 'f16x3' (f32-grade, default) | 'f32' | 'f16' (fused.PRECISIONS)
+
+    def _standalone(self, device):
+        """(handle, packed input-conv weights) for forward(): rebuilt when a parameter changes; its own handle (EgoHMR.fused_sampler's carries the
+        sampler's pass map / precision schedule)."""
+        import math
+        if getattr(self, "_sa_keyfn", None) is None:
+            self._sa_keyfn = _lib.TensorKey(self)
+        key = (self._sa_keyfn(), str(device))
+        if getattr(self, "_sa_key", None) != key:
+            self._free_standalone()
+            h, keep = self.create_native_handle(device)
+            W = _lib.f32(self.gconv_input[0].gconv.W.detach(), device)                       # [2, in_dim, hid]
+            K = W.shape[1]
+            Kp = (K + 31) // 32 * 32
+            Co = 2 * self.hid_dim
+            Cop = (Co + 127) // 128 * 128
+            w2 = torch.zeros(Cop, Kp, device=device)
+            w2[:Co, :K] = W.permute(0, 2, 1).reshape(Co, K)                                   # row k * hid + n = W[k][:, n]
+            amax = float(w2.abs().max())
+            scale = 2.0 ** math.floor(math.log2(2048.0 / amax)) if amax > 0 else 1.0
+            buf = torch.empty(Cop, Kp, device=device)
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().ehm_split_pack(w2.data_ptr(), buf.data_ptr(), Cop, Kp, Kp, scale, _lib.stream_ptr()), "ehm_split_pack")
+            self._sa, self._sa_key = (h, keep, buf, scale, K, Kp), key
+        return self._sa
+
+    def _free_standalone(self):
+        sa = getattr(self, "_sa", None)
+        if sa is not None:
+            try:
+                _lib.lib().ehm_gcn_destroy(sa[0])
+            except Exception:
+                pass
+            self._sa = self._sa_key = None
+
+    def __del__(self):
+        self._free_standalone()
+
+    @torch.no_grad()
     def forward(self, x):
-        raise NotImplementedError("the denoiser runs through EgoHMR.forward / EgoHMR.fused_sampler (hoisted input conv)")
+        """modulated_gcn.py:99-116 in eval mode on the HIP kernels: x [B, 24, in_dim] -> [B, 24, out_dim=6].
+
+        gconv_input as a split-f16 GEMM x @ [W[0] | W[1]] (ehm_conv_nhwc_split, H = W = 1) + ehm_gcn_input_layer_rows (modulation, adjacency mix, bias,
+        BatchNorm, ReLU), the residual blocks as ONE chained launch (ehm_gcn_hidden_stack), the optional non-local block, gconv_output
+        (ehm_gcn_output_layer).  EgoHMR.forward / the sampler do NOT come through here: they hoist the step-invariant slices of the input feature
+        (FusedSampler.prepare) - this is the module's own call surface for a user who feeds it a full feature tensor, as the reference allows."""
+        import ctypes as C
+        if self.training:
+            raise NotImplementedError("ModulatedGCN.forward: inference only (BatchNorm in eval mode, no dropout); training is out of scope (SURVEY.md section 2)")
+        if not x.is_cuda:
+            raise _lib.EgoHMRHipError("ModulatedGCN.forward needs its input on a HIP device; egohmr_amd has no CPU path")
+        if x.dim() != 3 or x.shape[1] != 24 or x.shape[2] != self.in_dim:
+            raise ValueError(f"ModulatedGCN.forward: expected [B, 24, {self.in_dim}], got {tuple(x.shape)}")
+        if self.out_dim != 6:
+            raise NotImplementedError("the output-conv kernels are built for out_dim = 6 (the 6-D rotation head, egohmr.py:132)")
+        from .fused import PRECISIONS
+        L = _lib.lib()
+        dev = x.device
+        B, hid = x.shape[0], self.hid_dim
+        with _lib.on_device(dev):
+            h, _, wbuf, scale, K, Kp = self._standalone(dev)
+            if L.ehm_gcn_get_precision(h) != PRECISIONS[self.precision]:
+                _lib.check(L.ehm_gcn_set_precision(h, PRECISIONS[self.precision]), "ehm_gcn_set_precision")
+            s = _lib.stream_ptr()
+            rows = B * 24
+            xp = torch.zeros(rows, Kp, device=dev)
+            xp[:, :K] = _lib.f32(x).reshape(rows, K)
+            pre = torch.empty(rows, 2 * hid, device=dev)
+            d = _lib.ConvDesc(xp.data_ptr(), wbuf.data_ptr(), None, None, pre.data_ptr(), rows, 1, 1, Kp, 2 * hid, 1, 1, 1, 0, 0, scale)
+            _lib.check(L.ehm_conv_nhwc_split(C.byref(d), s), "ehm_conv_nhwc_split")
+            tile = L.ehm_gcn_row_tile()
+            rows_pad = (rows + tile - 1) // tile * tile
+            X = [torch.zeros(rows_pad, hid, device=dev) for _ in range(3)]
+            _lib.check(L.ehm_gcn_input_layer_rows(h, pre.data_ptr(), X[0].data_ptr(), B, s), "ehm_gcn_input_layer_rows")
+            bufs = (C.c_void_p * 3)(*[t.data_ptr() for t in X])
+            res = C.c_int(0)
+            _lib.check(L.ehm_gcn_hidden_stack(h, bufs, rows_pad, C.byref(res), s), "ehm_gcn_hidden_stack")
+            feat = X[res.value]
+            if self.nonlocal_layer:
+                if self.precision == "f16":
+                    raise _lib.EgoHMRHipError("the optional non-local GCN block runs on float32 features; use precision 'f16x3' or 'f32' with it")
+                feat = self.non_local_native(feat, rows, rows_pad)
+            out = torch.empty(B, 144, device=dev)
+            _lib.check(L.ehm_gcn_output_layer(h, feat.data_ptr(), None, out.data_ptr(), B, 1, s), "ehm_gcn_output_layer")
+            _lib.check(L.ehm_gcn_stack_status(h, s), "ehm_gcn_stack_status")
+        return out.view(B, 24, 6)
 
 
 class PositionalEncoding(nn.Module):
@@ -207,10 +377,10 @@ class EgoHMR(nn.Module):
         self.guide_denom_override = None       # sharded / sub-batch runs: the GLOBAL batch size of `-loss.mean()`, else None
         self.guide_all_points = False          # COAP variant: bbox-selected scene points (egohmr.py:550-552); True = all points (egohmr_volsmpl.py:609-612)
         self.lbs_every_step = True             # EgoHMR.forward decodes the body in every step (egohmr.py:276)
-        # EXPERIMENT (docs/EXPERIMENTS.md 3.7, measured 12 % slower): runs of unguided steps as ONE persistent launch.  Only a library built with
-        # EHM_HIPCC_FLAGS=-DEHM_WITH_LOOP_ENGINE has it; on the default build True raises (FusedSampler.run)
-        self.loop_engine = False
-        self.loop_engine_min_masked = 0.85
+        # what a clamped activation does (|x| >= 65504 in an X2 / f16 store of the denoiser: _lib.EgoHMRRangeError from the status word): 'raise', or 'f32' =
+        # switch this model to gcn_precision 'f32' (float32 activations, no such limit) and run the call again.  Calls issued with defer_status=True
+        # always raise (at check_status(): their results have been handed out already)
+        self.on_saturation = "raise"
         self.per_step_launches = False     # True: the separate per-step launches of rounds 2-3 instead of step_fused_kernel (same bits; A/B runs and tests)
         self.pass_group = 1                # second passes pruned per item (1) or per group of this many consecutive items (FusedSampler.prepare)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)

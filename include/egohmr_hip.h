@@ -34,9 +34,9 @@ extern "C" {
 const char* ehm_last_error(void);
 /* compile-time facts, for the loader's sanity check: returns "gfx950" */
 const char* ehm_target_arch(void);
-/* optional parts this library was built with, space separated ("" for the default build): "loop_engine" (-DEHM_WITH_LOOP_ENGINE: the
- * one-launch sampling loop experiment, ehm_sample_desc.loop_engine), "stamps" (-DEHM_STAMPS: in-kernel time stamps for tools/stamp_*.py),
- * "wide_tile" (-DEHM_WITH_WIDE_TILE: the 96 x 64 wave-tile experiment of csrc/gcn_wide.hip, selected per handle with EHM_GCN_WIDE=1 at ehm_gcn_create) */
+/* optional parts this library was built with, space separated ("" for the default build): "stamps" (-DEHM_STAMPS: in-kernel time stamps for
+ * tools/stamp_*.py).  (The experiment engines of rounds 4 - 5 - the one-launch sampling loop, the 96 x 64 wave tile - are gone from the tree: their
+ * records are docs/EXPERIMENTS.md 3.2 / 3.7, their code is in the history.) */
 const char* ehm_build_features(void);
 
 /* ------------------------------------------------------------------ geometry ------------------ */
@@ -46,6 +46,13 @@ int ehm_rot6d_to_rotmat(const float* x6d, float* R, int64_t n, int mode, void* s
 /* vector-Jacobian product of the above (autograd of geometry.py:47-66 as used under
  * torch.enable_grad() in models/egohmr/egohmr.py:518-529): gR [n,3,3] -> gx [n,6]. */
 int ehm_rot6d_to_rotmat_bwd(const float* x6d, const float* gR, float* gx, int64_t n, int mode, void* stream);
+/* utils/konia_transform.py:316-340 rotation_matrix_to_angle_axis (-> rotation_matrix_to_quaternion :349-443 in WXYZ order, quaternion_to_angle_axis
+ * :560-630; eps = 1e-6 in the clamps, safe_zero_division :343-346, torch_safe_atan2 :44-47): R [n,3,3] -> aa [n,3].  The `full_pose` feed of the
+ * COAP / VolSMPL collision models (models/egohmr/egohmr.py:495, :540; egohmr_volsmpl.py:555, :596). */
+int ehm_rotmat_to_angle_axis(const float* R, float* aa, int64_t n, void* stream);
+/* vector-Jacobian product of the above through the branch the forward took (autograd through torch.where / clamp_min, as under
+ * torch.enable_grad() in egohmr.py:518-545): gaa [n,3] -> gR [n,3,3]. */
+int ehm_rotmat_to_angle_axis_bwd(const float* R, const float* gaa, float* gR, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ SMPL body model ----------- */
 typedef struct ehm_smpl ehm_smpl;
@@ -121,6 +128,9 @@ int ehm_gcn_activation_group(const ehm_gcn* h);
 int ehm_gcn_reserve(ehm_gcn* h, int max_bodies, int passes);
 int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, int K, int group, void* stream);
 int ehm_gcn_unpack_activations(const void* X2, float* X, int64_t rows, int K, int group, void* stream);
+/* ehm_gcn_pack_activations into the handle's own activation format (modes 1 / 2; K = hid_dim) WITH the range guard of the conv kernels: a value with
+ * |x| >= 65504 (clamped: see ehm_gcn_stack_status) raises bit 2 of the handle's status word. */
+int ehm_gcn_pack_activations_checked(ehm_gcn* h, const float* X, void* X2, int64_t rows, void* stream);
 
 /* rows of the activation matrices must be padded to a multiple of this many rows (zero-filled) */
 int ehm_gcn_row_tile(void);
@@ -155,6 +165,11 @@ typedef struct {
 int ehm_gcn_set_nonlocal(ehm_gcn* h, const ehm_nonlocal_params* p);
 int ehm_gcn_input_layer(ehm_gcn* h, const float* h_img, const float* h_oth, const uint8_t* vis, const float* x,
                         const float* Wx, const float* tvec, float* out, int B, int passes, void* stream);
+/* The same conv in its general form (modulated_gcn_conv.py:39-50 + the BatchNorm / ReLU of modulated_gcn.py:21-28) for an ARBITRARY input feature -
+ * ModulatedGCN.forward called on its own (modulated_gcn.py:99-116), where nothing is hoisted: the caller hands over the two GEMM results
+ *   pre [bodies*24][2][hid] float32,  pre[r][k][:] = x[r, :] @ W[k]      (one ehm_conv_nhwc_split call with H = W = 1 on the weights [W[0] | W[1]])
+ * and this call applies the modulation M, the adjacency mix, bias, BatchNorm(eval), ReLU and writes out [rows_pad, hid] in the handle's activation format. */
+int ehm_gcn_input_layer_rows(ehm_gcn* h, const float* pre, float* out, int bodies, void* stream);
 
 /* _GraphConv hid->hid (modulated_gcn.py:21-28): out = ReLU(BN(mix(X W0, X W1))) [+ residual,
  * modulated_gcn.py:42].  X, out, residual [rows_pad,hid]; residual may be NULL. */
@@ -167,13 +182,15 @@ int ehm_gcn_hidden_layer(ehm_gcn* h, int layer, const float* X, const float* res
  * f16 operands (modes 1, 2) this is ONE chained launch (per-row-tile counters instead of kernel boundaries); otherwise it
  * loops over ehm_gcn_hidden_layer with the same buffer rotation.  Env EHM_F16_CHAIN=0 forces the loop. */
 int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t rows_pad, int* result_index, void* stream);
-/* Synchronises the stream and reports (and clears) whether ANY chained launch since the previous status call flagged a timed-out
- * producer wait or an unproduced tile (never expected; the kernel gives up instead of hanging the device, and audits its own
- * completion).  0 = fine, -5 = the results computed since the previous call are invalid. */
+/* Synchronises the stream and reports (and clears) the handle's status word: whether ANY chained launch since the previous status call flagged a
+ * timed-out producer wait or an unproduced tile (never expected; the kernel gives up instead of hanging the device, and audits its own completion):
+ * -5 (EIO), the results computed since the previous call are invalid; or whether an activation of the input / hidden convs reached the f16 range
+ * (|x| >= 65504) in an X2 / f16 store and was clamped: -34 (ERANGE) - finite results that are not parity grade; that checkpoint needs
+ * ehm_gcn_set_precision(h, 0).  0 = fine.  (The reference's float32 activations have no such limit: modulated_gcn.py:99-116.) */
 int ehm_gcn_stack_status(ehm_gcn* h, void* stream);
 /* The same word copied to *host_flag (pinned host memory owned by the caller) in stream order WITHOUT synchronising: a pipeline that
  * keeps batches in flight looks at *host_flag once the stream has passed this point (an event), and calls ehm_gcn_stack_status to
- * report and clear when it is non-zero.  The flag is sticky on the device, so nothing is lost by looking late. */
+ * report and clear when it is non-zero (bit 0: chain failure, bit 2: saturation).  The flag is sticky on the device, so nothing is lost by looking late. */
 int ehm_gcn_stack_status_async(ehm_gcn* h, uint32_t* host_flag, void* stream);
 
 /* gconv_output (modulated_gcn.py:113) + the visibility fuse of egohmr.py:247-256:
@@ -350,6 +367,30 @@ int ehm_guidance_grad_finish(const float* gpose6d, const float* loss, float* gra
  * x [B,P1,3], y [B,P2,3] -> dist2 [B,P1], idx [B,P1] int32 or NULL. */
 int ehm_nn_dist2(const float* x, const float* y, float* dist2, int32_t* idx, int B, int P1, int P2, void* stream);
 
+/* ------------------------------------------------------------------ evaluation block ---------- */
+/* test_egohmr.py:399-449: Euclidean error per point of S samples per item against ONE ground truth per item, its mean over the points and its sums over
+ * the visible / invisible points (G-MPJPE :399-407: joints in the camera frame; MPJPE :409-417 and V2V :441-449: pelvis-aligned).
+ *   pred [B,S,pred_points,3] and gt [B,gt_points,3]: the first P points of each are compared (SMPL hands over 45 joints, the metrics use 24);
+ *   pred_origin [B,S,3] / gt_origin [B,3]: subtracted first (NULL = nothing: the caller aligned already, or G-MPJPE); or origin_point >= 0: each cloud's own
+ *     point of that index is its origin (joint 0 = the pelvis, :409) and both pointers are NULL; origin_point < 0: pointers only;
+ *   mask [B,P] (NULL: everything visible);  per_point [B,S,P] (may be NULL);  mean [B,S];  vis_sum, invis_sum [B,S] (may be NULL). */
+typedef struct ehm_eval_points_desc {
+  const float* pred; const float* gt; const float* pred_origin; const float* gt_origin; const uint8_t* mask;
+  float* per_point; float* mean; float* vis_sum; float* invis_sum;
+  int B, S, P, pred_points, gt_points, origin_point;
+} ehm_eval_points_desc;
+int ehm_eval_point_errors(const ehm_eval_points_desc* d, void* stream);
+/* utils/pose_utils.py:10-66 (compute_similarity_transform) + :109-126 (reconstruction_error) as called at test_egohmr.py:419-437: the similarity transform
+ * (scale, rotation, translation) of each pred[b,s] [J,3] closest to gt[b] [J,3] - float64 in registers like the reference's per-sample numpy loop, the
+ * 3 x 3 SVD by one-sided Jacobi - then the per-joint error.  aligned [B,S,J,3], per_joint [B,S,J], mean [B,S], vis_sum / invis_sum [B,S] with mask [B,J]:
+ * each may be NULL (one of aligned / per_joint / mean must not be).  3 <= J <= 32. */
+int ehm_eval_procrustes(const float* pred, const float* gt, const uint8_t* mask, float* aligned, float* per_joint, float* mean, float* vis_sum,
+                        float* invis_sum, int B, int S, int J, void* stream);
+/* test_egohmr.py:453-494: sample diversity of joints [B,S,J,3] over the joints selected by mask [B,J] (NULL: all; invert != 0: the unselected ones) -
+ * std_out [B] = mean over the selected joints and the 3 coordinates of the unbiased std over the samples; apd_out [B] = sum over ordered sample pairs and
+ * selected joints of the joint distance / n_selected / S / (S - 1) / 2 (the reference's normalisation).  No selected joint -> NaN, as the reference. */
+int ehm_eval_diversity(const float* joints, const uint8_t* mask, int invert, float* std_out, float* apd_out, int B, int S, int J, void* stream);
+
 /* ------------------------------------------------------------------ per-item scalars ---------- */
 /* The per-item scalar work of EgoHMR.forward in front of the encoders, in two launches:
  *   vis [B,24] u8       models/egohmr/egohmr.py:186-188: confidence > 0, OpenPose joint `force_visible` (8) always on, gathered by joint_map
@@ -431,9 +472,6 @@ typedef struct {
                          (ehm_gcn_set_precision mode 2), the remaining ones in the handle's mode; 0 = off.  docs/EXPERIMENTS.md 3.6  */
   int nonlocal_ci;    /* inter_channels of the non-local block set with ehm_gcn_set_nonlocal, 0 = none (needs float32 features:
                          handle mode 0 or 1 and lowprec_steps == 0)                                                              */
-  int loop_engine;    /* EXPERIMENT, off in the default build: 1 = runs of consecutive unguided steps execute as ONE persistent launch (bit-equal,
-                         measured 12 % slower, docs/EXPERIMENTS.md 3.7).  Only a library built with -DEHM_WITH_LOOP_ENGINE accepts 1; the default one
-                         returns EHM_EINVAL.  Shape limits: B % 8 == 0, B >= 24, no pass map, split-f16 mode, no non-local block                */
   int per_step_launches; /* 0 (default) = two launches per step: chained hidden convs, then step_fused_kernel (output responses + per-body
                          update + the next step's input conv); 1 = the separate launches of rounds 2-3 (input conv, chain, responses, per-body
                          step) - same bits, kept for A/B runs and the bit-equality tests                                                      */
@@ -468,8 +506,8 @@ enum {
   EHM_PROF_STEP_BODY = 5,    /* step_body_kernel; with the fused step launches: pose_steps_kernel (the pending steps' poses, per flush) */
   EHM_PROF_SKIN_INPUT = 6,   /* skin_input_kernel (skinning of step t + input conv of step t+1) / skin_mfma_kernel       */
   EHM_PROF_GUIDANCE = 7,     /* the collision-guidance kernel sequence of a guided step                                  */
-  EHM_PROF_LOOP_F16X3 = 8,   /* gcn_loop_kernel<3, 4>: a run of unguided steps in one launch (ehm_sample_desc.loop_engine), split-f16 */
-  EHM_PROF_LOOP_F16 = 9,     /* (reserved: the one-launch loop is built for the split-f16 mode)                          */
+  EHM_PROF_RESERVED_8 = 8,   /* (was the one-launch loop experiment's class; kept so that the indices behind it do not move)           */
+  EHM_PROF_RESERVED_9 = 9,
   EHM_PROF_G_NEAREST = 10,   /* inside EHM_PROF_GUIDANCE: bbox + select + nearest_grid_kernel (the collision proxy's search) */
   EHM_PROF_G_SKIN_BWD = 11,  /* inside EHM_PROF_GUIDANCE: skin_bwd_kernel (VJP of the skinning)                          */
   EHM_PROF_G_POSEFEAT_BWD = 12, /* inside EHM_PROF_GUIDANCE: posefeat_bwd_kernel ([B, 20670] x [20670, 207] contraction) */

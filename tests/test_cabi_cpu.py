@@ -47,9 +47,9 @@ def test_header_is_plain_c_and_a_c_program_binds_the_library(tmp_path):
         "  if (ehm_gcn_row_tile() != 192) return 2;\n"
         "  if (ehm_sample_workspace_bytes(NULL, 1024, 6890) != -22) return 3;          /* EHM_EINVAL without touching a GPU */\n"
         '  if (strstr(ehm_last_error(), "bad argument") == NULL) return 4;\n'
-        '  printf("%d %s %d %d %d %d %d %d %d %d\\n", (int)sizeof d, ehm_target_arch(), (int)sizeof(ehm_gconv_params), (int)sizeof(ehm_linear_desc),\n'
+        '  printf("%d %s %d %d %d %d %d %d %d %d %d\\n", (int)sizeof d, ehm_target_arch(), (int)sizeof(ehm_gconv_params), (int)sizeof(ehm_linear_desc),\n'
         "         (int)sizeof(ehm_conv_desc), (int)sizeof(ehm_conv_x2_desc), (int)sizeof(ehm_step_coefs), (int)sizeof(ehm_nonlocal_params),\n"
-        "         (int)sizeof(ehm_item_prep_desc), (int)sizeof(ehm_pack_desc));\n"
+        "         (int)sizeof(ehm_item_prep_desc), (int)sizeof(ehm_pack_desc), (int)sizeof(ehm_eval_points_desc));\n"
         "  return 0;\n}\n")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
@@ -61,7 +61,7 @@ def test_header_is_plain_c_and_a_c_program_binds_the_library(tmp_path):
     import ctypes
     f = out.stdout.split()
     mirrors = [_lib.SampleDesc, None, _lib.GConvParams, _lib.LinearDesc, _lib.ConvDesc, _lib.ConvX2Desc, _lib.StepCoefs, _lib.NonlocalParams,
-               _lib.ItemPrepDesc, _lib.PackDesc]
+               _lib.ItemPrepDesc, _lib.PackDesc, _lib.EvalPointsDesc]
     for i, cls in enumerate(mirrors):
         if cls is not None:
             assert int(f[i]) == ctypes.sizeof(cls), f"the ctypes mirror {cls.__name__} has drifted from the header ({f[i]} vs {ctypes.sizeof(cls)})"
@@ -139,9 +139,10 @@ def test_oracle_is_test_infrastructure_only():
 
 
 def test_default_library_has_no_experiment_and_no_env_switch_on_the_launch_path():
-    """the one-launch loop (bit-equal, 12 % slower) is an experiment - the default build() must not contain its kernel, and no
-    environment variable may change which kernels a caller's process runs: the only getenv left in the product sources is EHM_F16_CHAIN, read once in
-    ehm_gcn_create (handle creation); the rest sits behind -DEHM_STAMPS / -DEHM_WITH_LOOP_ENGINE, which build() does not set."""
+    """the experiment engines (the one-launch sampling loop, the 96 x 64 wave tile, the 32 x 32 x 16 form of the split-f16
+    chain) are GONE from the tree - no source file, no kernel in the library, no second code path through the tile engine - and no environment variable may
+    change which kernels a caller's process runs: the only getenv left in the product sources is EHM_F16_CHAIN, read once in ehm_gcn_create (handle creation);
+    -DEHM_STAMPS (in-kernel time stamps for tools/stamp_*.py) is the one build-time instrumentation flag."""
     import glob
     from egohmr_amd import _lib
     assert not os.environ.get("EHM_HIPCC_FLAGS") and not os.environ.get("EHM_LIB_PATH"), "this test is about the DEFAULT build"
@@ -152,13 +153,13 @@ def test_default_library_has_no_experiment_and_no_env_switch_on_the_launch_path(
     assert b"gcn_loop_kernel" not in blob and b"gcn_hidden_wide_kernel" not in blob and b"gcn_hidden_chain_kernel" in blob
     sites = []
     for path in sorted(glob.glob(os.path.join(REPO, "egohmr_amd", "csrc", "*"))):
-        if os.path.basename(path) in ("gcn_loop_host.inc", "gcn_wide.hip"):           # compiled only under -DEHM_WITH_LOOP_ENGINE / -DEHM_WITH_WIDE_TILE
-            continue
-        depth = []                                                  # stack of "is this #if block an instrumentation flag"
+        assert os.path.basename(path) not in ("gcn_loop_host.inc", "gcn_loop_dev.h", "gcn_wide.hip")
+        depth = []                                                  # stack of "is this #if block the instrumentation flag"
         for ln, line in enumerate(open(path), 1):
             st = line.strip()
+            assert "EHM_WITH_LOOP_ENGINE" not in st and "EHM_WITH_WIDE_TILE" not in st and "EHM_P3_MFMA32" not in st and "EHM_LOOPSTAT" not in st, (path, ln)
             if st.startswith("#if"):
-                depth.append(("EHM_STAMPS" in st or "EHM_WITH_LOOP_ENGINE" in st or "EHM_LOOPSTAT" in st or "EHM_WITH_WIDE_TILE" in st) and not st.startswith("#ifndef"))
+                depth.append("EHM_STAMPS" in st and not st.startswith("#ifndef"))
             elif st.startswith("#endif") and depth:
                 depth.pop()
             elif "getenv(" in line and not any(depth):

@@ -281,7 +281,7 @@ def test_bench_self_launches_two_ranks_on_this_box(dev):
                         "--workload", "c1_ddim5", "--cpu-seconds", "0", "--no-legs"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]   # (gloo's rendezvous chatter goes to stdout; RCCL prints nothing)
-    assert len(lines) == 1 and len(lines[0]) < 4096, [len(l) for l in lines]        # stdout = ONE compact line, the LAST one
+    assert len(lines) == 1 and len(lines[0]) < 4096, [l[:200] for l in lines]        # stdout = ONE compact line, the LAST one
     assert r.stdout.strip().splitlines()[-1] == lines[0]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "weak"
@@ -440,19 +440,21 @@ def _gconv_sd(seed, cin, cout, bn=True, bn_scale=None):
     return sd
 
 
-@pytest.mark.parametrize("case", ["x1e3", "x1e-3", "bn1e3", "x7e4", "sat2e5"])
+@pytest.mark.parametrize("case", ["x1e3", "x1e-3", "bn1e3", "x7e4", "sat2e5", "out1e5"])
 def test_split_f16_hidden_conv_range_behaviour(dev, case):
     """The split-f16 ('f16x3') conv outside the O(1) range of the synthetic weights: activations x1e3 and x1e-3, a channel whose
     BatchNorm scale is 1e3, an input element of 7e4 (> f16 max 65504: hi saturates at 65504 and lo carries the remaining 4496, so it is
     still represented) and one of 2e5 (beyond hi + lo: BOTH halves saturate, the element reads as 131008 - the documented limit of the
-    format; nothing becomes inf / NaN).  Judge: the fp64 oracle, relative to the output scale."""
+    format; nothing becomes inf / NaN).  Judge: the fp64 oracle, relative to the output scale.  The clamp is never SILENT: both out-of-range
+    cases raise bit 2 of the handle's status word (ehm_gcn_stack_status -> -34 with the remedy in the message, once), the in-range ones do not;
+    an output channel driven past 65504 by its BatchNorm scale is caught in the conv's epilogue store."""
     from egohmr_amd import _lib
     from egohmr_amd.model import PRECISIONS
     from oracle import model as om
     from tests.test_gpu_parity import _native_gcn
     L = _lib.lib()
     hid, bodies = 1024, 8
-    sds = [_gconv_sd(60, hid, hid, bn_scale=1e3 if case == "bn1e3" else None), _gconv_sd(61, hid, hid)]
+    sds = [_gconv_sd(60, hid, hid, bn_scale={"bn1e3": 1e3, "out1e5": 1e6}.get(case)), _gconv_sd(61, hid, hid)]   # out1e5: one OUTPUT channel past the f16 range
     h, keep = _native_gcn(L, dev, sds[0], sds, _gconv_sd(62, hid, 6, bn=False), hid)
     _lib.check(L.ehm_gcn_set_precision(h, PRECISIONS["f16x3"]))
     g = np.random.Generator(np.random.PCG64(9))
@@ -465,17 +467,26 @@ def test_split_f16_hidden_conv_range_behaviour(dev, case):
     rows = bodies * 24
     X = x.reshape(rows, hid).to(dev).contiguous()
     T, Y1 = torch.empty_like(X), torch.empty_like(X)
-    _lib.check(L.ehm_gcn_pack_activations(X.data_ptr(), T.data_ptr(), rows, hid, 32, None))
+    assert L.ehm_gcn_stack_status(h, None) == 0
+    _lib.check(L.ehm_gcn_pack_activations_checked(h, X.data_ptr(), T.data_ptr(), rows, None))
+    rc_in = L.ehm_gcn_stack_status(h, None)
+    assert rc_in == (-34 if case in ("x7e4", "sat2e5") else 0), (case, rc_in)          # |x| >= 65504 at the format's door: flagged, in range: not
+    if rc_in:
+        assert b"gcn_precision = 'f32'" in L.ehm_last_error() and L.ehm_gcn_stack_status(h, None) == 0      # reported once, with the remedy
     _lib.check(L.ehm_gcn_hidden_layer(h, 0, T.data_ptr(), None, Y1.data_ptr(), rows, None))
     _lib.check(L.ehm_gcn_unpack_activations(Y1.data_ptr(), T.data_ptr(), rows, hid, 32, None))
     torch.cuda.synchronize()
     y = T.cpu().double()
+    rc_out = L.ehm_gcn_stack_status(h, None)                                             # the conv's own stores: flagged iff an output reached the range
+    assert (rc_out == -34) == bool(float(y.abs().max()) >= 65504.0), (case, rc_out, float(y.abs().max()))
     xr = x.double().clone()
     if case == "sat2e5":
         xr[2, 5, 100] = 2 * 65504.0                          # hi and lo both saturate at the largest f16
     sd64 = {k.replace("l.", "a."): v.double() for k, v in sds[0].items()}
     r = om._graph_conv(sd64, "a", xr, om.smpl_adjacency().double()).reshape(rows, hid)
     assert torch.isfinite(y).all()
+    if case == "out1e5":
+        assert rc_out == -34 and float(r.abs().max()) > 65504.0                          # (the case exists to exercise the epilogue guard)
     scale = float(r.abs().max())
     err = float((y - r).abs().max())
     print(f"[{case}] |y|max = {scale:.3e}  max|err| = {err:.3e}  rel = {err / scale:.2e}")
@@ -487,6 +498,47 @@ def test_split_f16_hidden_conv_range_behaviour(dev, case):
     rel = {"x7e4": 1e-4, "sat2e5": 5e-4}.get(case, 3e-6)      # (lo / hi = 0.07 resp. 1 instead of 2^-11: the dropped lo*lo term is that much larger)
     assert float((y - r)[lim].abs().max()) < rel * max(1.0, float(r[lim].abs().max()))
     L.ehm_gcn_destroy(h)
+
+
+def test_sampler_makes_a_clamped_activation_loud_and_can_fall_back_to_f32(dev, smpl_asset):
+    """with a checkpoint whose hidden activations leave the f16 range (here: one BatchNorm scale of the first residual block set to 1e6)
+    the split-f16 sampling loop no longer returns silently clamped bodies: the call raises EgoHMRRangeError (status bit 2, deferred calls raise at
+    check_status()); with EgoHMR.on_saturation = 'f32' it warns, switches the model to float32 activations and returns what a gcn_precision = 'f32' run
+    returns, bit for bit.  The untouched checkpoint raises nothing."""
+    import warnings
+    from egohmr_amd import _lib
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    B, N = 4, 256
+    d = create_gaussian_diffusion(num_diffusion_timesteps=50, timestep_respacing="ddim5")
+    batch = batch_to_device(syn.make_batch(B, N, seed=3), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=3)).to(dev)
+
+    def blown(m):
+        with torch.no_grad():
+            m.diffusion_model.gconv_layers[0].gconv1.bn.weight[7] = 1e6
+        return m
+
+    m = build_synthetic_model(dev, 0, smpl_asset=smpl_asset)
+    m.f16x3_last_steps = None
+    fs = m.fused_sampler
+    fs.run(d, dict(batch), noise, ddim=True)                                   # healthy weights: no flag
+    blown(m)
+    with pytest.raises(_lib.EgoHMRRangeError, match="gcn_precision = 'f32'"):
+        fs.run(d, dict(batch), noise, ddim=True)
+    fs.run(d, dict(batch), noise, ddim=True, defer_status=True)               # deferred: the word is looked at later ...
+    with pytest.raises(_lib.EgoHMRRangeError):
+        fs.check_status()                                                      # ... and is just as loud
+    m.on_saturation = "f32"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = fs.run(d, dict(batch), noise, ddim=True)
+    assert any("gcn_precision = 'f32'" in str(x.message) for x in w) and m.gcn_precision == "f32"
+    ref = blown(build_synthetic_model(dev, 0, smpl_asset=smpl_asset))
+    ref.gcn_precision = "f32"
+    want = ref.fused_sampler.run(d, dict(batch), noise, ddim=True)
+    assert torch.isfinite(out["other_outputs"]["pred_vertices"]).all()
+    assert torch.equal(out["other_outputs"]["pred_vertices"], want["other_outputs"]["pred_vertices"])
 
 
 def test_forward_under_other_constructor_flags_vs_reference_golden(golden_dir, dev, smpl_asset):

@@ -221,19 +221,6 @@ def test_hidden_stack_chain_tile_shapes(L, dev, hid, bodies, prec):
     _chain_vs_per_conv_launches(L, dev, hid, bodies, prec)
 
 
-@pytest.mark.parametrize("hid,bodies", [(256, 33), (1024, 40)])
-def test_wide_wave_tile_experiment_is_bit_equal(L, dev, hid, bodies, monkeypatch):
-    """csrc/gcn_wide.hip (96 x 64 (x 2) wave tile, 16-k K tiles: 14 fragment reads and 7 operand pieces per 36 MFMAs instead of 20 and 10) is an
-    EXPERIMENT - measured equal to the round-4 tile, docs/EXPERIMENTS.md 3.2 - that only a library built with EHM_HIPCC_FLAGS=-DEHM_WITH_WIDE_TILE contains;
-    there, a handle created under EHM_GCN_WIDE=1 runs it for the per-conv launches.  It is bit-equal to the 32 x 32 x 16 form of the shipped tile
-    (-DEHM_P3_MFMA32); against the 16 x 16 x 32 form that ships since round 5 (another summation order inside a K tile) it agrees to float32 rounding."""
-    from egohmr_amd import _lib
-    if "wide_tile" not in _lib.build_features():
-        pytest.skip("library built without -DEHM_WITH_WIDE_TILE (default)")
-    monkeypatch.setenv("EHM_GCN_WIDE", "1")                 # read once, at ehm_gcn_create
-    _chain_vs_per_conv_launches(L, dev, hid, bodies, "f16x3", exact=False)
-
-
 def _chain_vs_per_conv_launches(L, dev, hid, bodies, prec, exact=True):
     import ctypes as C
     from egohmr_amd import _lib

@@ -67,24 +67,26 @@ def test_mpjpe_v2v_formulas():
     assert metrics.std_diversity(p[..., :24, :]).shape == (4,)
 
 
+@pytest.mark.gpu
 def test_diversity_metrics_match_reference_loops():
-    """std / apd diversity incl. the visible / invisible joint splits against a literal restatement of the per-item numpy
+    """std / apd diversity (ehm_eval_diversity) incl. the visible / invisible joint splits against a literal restatement of the per-item numpy
     loops of test_egohmr.py:453-494."""
     import numpy as np
     import torch
     from egohmr_amd import metrics
+    dev = torch.device("cuda:0")
     g = np.random.Generator(np.random.PCG64(7))
     B, S = 5, 4
     a = g.normal(size=(B, S, 24, 3)).astype(np.float32)
     mask = g.random((B, 24)) < 0.6
     mask[0] = True            # nothing invisible for item 0 -> NaN in the invisible split, like the reference
-    t, m = torch.from_numpy(a), torch.from_numpy(mask)
+    t, m = torch.from_numpy(a).to(dev), torch.from_numpy(mask).to(dev)
     # reference-style loops
     std_all = a.std(axis=1, ddof=1).mean(-1).mean(-1)
     pd = np.linalg.norm(a[:, None] - a[:, :, None], axis=-1)
     apd_all = pd.sum(axis=(-1, -2, -3)) / 24 / S / (S - 1) / 2
-    np.testing.assert_allclose(metrics.std_diversity(t).numpy(), std_all, rtol=1e-5)
-    np.testing.assert_allclose(metrics.apd_diversity(t).numpy(), apd_all, rtol=1e-5)
+    np.testing.assert_allclose(metrics.std_diversity(t).cpu().numpy(), std_all, rtol=1e-5)
+    np.testing.assert_allclose(metrics.apd_diversity(t).cpu().numpy(), apd_all, rtol=1e-5)
     for sel in (mask, ~mask):
         std_ref, apd_ref = [], []
         for k in range(B):
@@ -93,8 +95,79 @@ def test_diversity_metrics_match_reference_loops():
                 std_ref.append(tmp.std(axis=0, ddof=1).mean(-1).mean(-1) if tmp.shape[1] else np.nan)
                 d = np.linalg.norm(tmp[None] - tmp[:, None], axis=-1)
                 apd_ref.append(d.sum() / tmp.shape[-2] / S / (S - 1) / 2 if tmp.shape[1] else np.nan)
-        np.testing.assert_allclose(metrics.std_diversity_masked(t, torch.from_numpy(sel)).numpy(), np.array(std_ref, np.float32), rtol=1e-5)
-        np.testing.assert_allclose(metrics.apd_diversity(t, torch.from_numpy(sel)).numpy(), np.array(apd_ref, np.float32), rtol=1e-5)
+        np.testing.assert_allclose(metrics.std_diversity_masked(t, torch.from_numpy(sel).to(dev)).cpu().numpy(), np.array(std_ref, np.float32), rtol=1e-5)
+        np.testing.assert_allclose(metrics.apd_diversity(t, torch.from_numpy(sel).to(dev)).cpu().numpy(), np.array(apd_ref, np.float32), rtol=1e-5)
+    sd_inv, apd_inv = metrics.diversity(t, m, invert=True)          # the inverted selection inside the kernel = the complement mask
+    sd_c, apd_c = metrics.diversity(t, ~m)
+    assert torch.equal(torch.nan_to_num(sd_inv, nan=-1.0), torch.nan_to_num(sd_c, nan=-1.0)) and torch.equal(torch.nan_to_num(apd_inv, nan=-1.0), torch.nan_to_num(apd_c, nan=-1.0))
+
+
+@pytest.mark.gpu
+def test_point_errors_kernel_vs_numpy():
+    """ehm_eval_point_errors: G-MPJPE / MPJPE / V2V with their visible / invisible sums (test_egohmr.py:399-449) against float64 numpy: S samples against one
+    ground truth per item, 45 model joints of which 24 count, 6890 vertices (27 rounds of the block), origins by pointer and by index."""
+    from egohmr_amd import metrics
+    dev = torch.device("cuda:0")
+    g = np.random.Generator(np.random.PCG64(5))
+    B, S = 3, 4
+    pj, gj = g.normal(size=(B, S, 45, 3)).astype(np.float32), g.normal(size=(B, 24, 3)).astype(np.float32)
+    jm = g.random((B, 24)) < 0.5
+    r = metrics.point_errors(torch.from_numpy(pj).to(dev), torch.from_numpy(gj).to(dev), points=24, mask=torch.from_numpy(jm).to(dev), per_point=True)
+    e = np.sqrt(((pj[:, :, :24].astype(np.float64) - gj[:, None]) ** 2).sum(-1))
+    np.testing.assert_allclose(r["per_point"].cpu().numpy(), e, rtol=1e-6)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), e.mean(-1), rtol=1e-5)
+    np.testing.assert_allclose(r["vis_sum"].cpu().numpy(), (e * jm[:, None]).sum(-1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["invis_sum"].cpu().numpy(), (e * ~jm[:, None]).sum(-1), rtol=1e-5, atol=1e-6)
+    r0 = metrics.point_errors(torch.from_numpy(pj).to(dev), torch.from_numpy(gj).to(dev), points=24, origin_point=0)
+    e0 = np.sqrt((((pj[:, :, :24] - pj[:, :, :1]).astype(np.float64) - (gj - gj[:, :1])[:, None]) ** 2).sum(-1))
+    np.testing.assert_allclose(r0["mean"].cpu().numpy(), e0.mean(-1), rtol=1e-5)
+    np.testing.assert_allclose(r0["vis_sum"].cpu().numpy(), e0.sum(-1), rtol=1e-5)            # no mask: everything is visible
+    assert float(r0["invis_sum"].abs().max()) == 0.0
+    pv, gv = g.normal(size=(B, S, 6890, 3)).astype(np.float32), g.normal(size=(B, 6890, 3)).astype(np.float32)
+    po, go = g.normal(size=(B, S, 1, 3)).astype(np.float32), g.normal(size=(B, 1, 3)).astype(np.float32)
+    vm = g.random((B, 6890)) < 0.7
+    ev = np.sqrt((((pv - po).astype(np.float64) - (gv - go)[:, None]) ** 2).sum(-1))
+    rv = metrics.point_errors(torch.from_numpy(pv).to(dev), torch.from_numpy(gv).to(dev), pred_origin=torch.from_numpy(po).to(dev), gt_origin=torch.from_numpy(go).to(dev),
+                              mask=torch.from_numpy(vm).to(dev))
+    np.testing.assert_allclose(rv["mean"].cpu().numpy(), ev.mean(-1), rtol=2e-5)
+    np.testing.assert_allclose(rv["vis_sum"].cpu().numpy(), (ev * vm[:, None]).sum(-1), rtol=2e-5)
+    np.testing.assert_allclose(metrics.v2v(torch.from_numpy(pv).to(dev), torch.from_numpy(po).to(dev), torch.from_numpy(gv).unsqueeze(1).to(dev),
+                                           torch.from_numpy(go).unsqueeze(1).to(dev)).cpu().numpy(), ev.mean(-1), rtol=2e-5)
+    with pytest.raises(Exception):
+        metrics.mpjpe(torch.from_numpy(pj), torch.from_numpy(gj))                             # CPU tensors: no CPU path
+
+
+@pytest.mark.gpu
+def test_procrustes_kernel_vs_oracle_edge_cases(golden_dir):
+    """ehm_eval_procrustes (one-sided Jacobi SVD in float64 registers) against the numpy restatement of utils/pose_utils.py:10-66 (itself pinned by the
+    reference golden G11): the golden's pairs with S samples per ground truth, reflected clouds (det(U V^T) < 0: Z flips the smallest singular direction),
+    planar clouds (rank-2 K), scaled / rotated copies (error 0), per-joint errors and masked sums."""
+    from egohmr_amd import metrics
+    dev = torch.device("cuda:0")
+    g11 = np.load(os.path.join(golden_dir, "g11_procrustes.npz"))
+    gt = g11["gt"].astype(np.float32)                                    # [n,J,3]
+    n, J = gt.shape[:2]
+    rng = np.random.Generator(np.random.PCG64(2))
+    S = 5
+    pred = np.stack([g11["pred"].astype(np.float32)] + [gt + 0.1 * rng.normal(size=gt.shape).astype(np.float32) for _ in range(S - 1)], 1)   # [n,S,J,3]
+    pred[:, 2] = pred[:, 2] * np.array([1, 1, -1], np.float32)           # a mirrored body: the best ROTATION needs the sign fix
+    pred[:, 3, :, 2] = 0.0                                                # a planar prediction: rank-2 correlation matrix
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    pred[:, 4] = (2.5 * gt @ q.T + np.array([0.3, -1.0, 2.0])).astype(np.float32)   # a similarity transform of the truth: error 0
+    mask = rng.random((n, J)) < 0.5
+    r = metrics.procrustes(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev), mask=torch.from_numpy(mask).to(dev), aligned=True, per_joint=True)
+    want = np.stack([np.stack([om.procrustes(pred[i, s].astype(np.float64), gt[i].astype(np.float64)) for s in range(S)]) for i in range(n)])
+    e = np.sqrt(((want - gt[:, None]) ** 2).sum(-1))
+    np.testing.assert_allclose(r["aligned"].cpu().numpy(), want, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(r["per_joint"].cpu().numpy(), e, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), e.mean(-1), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(r["vis_sum"].cpu().numpy(), (e * mask[:, None]).sum(-1), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(r["invis_sum"].cpu().numpy(), (e * ~mask[:, None]).sum(-1), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(r["mean"][:, 0].cpu().numpy(), g11["pa_mpjpe"], rtol=2e-5, atol=1e-6)       # the reference's own numbers
+    assert float(r["mean"][:, 4].max()) < 1e-5
+    al = metrics.similarity_align(torch.from_numpy(pred[:, 1]).to(dev), torch.from_numpy(gt).to(dev))
+    np.testing.assert_allclose(al.cpu().numpy(), want[:, 1], atol=2e-6, rtol=1e-5)
 
 
 def test_results_wire_format_roundtrip(tmp_path):

@@ -129,18 +129,31 @@ def main(argv=None) -> int:
     info = fs.calibrate_schedule(d, batch, ddim=ddim, force=True)
     rows = {}
 
-    def loop(prec, lowprec):
+    saturated = []                       # loops of this checkpoint in which a denoiser activation reached the f16 range (status bit 2: _lib.EgoHMRRangeError)
+
+    def loop(prec, lowprec, name=None):
         model.gcn_precision = prec
         try:
-            return fs.run(d, batch, noise, ddim=ddim, lowprec=lowprec)["other_outputs"]["pred_vertices"].clone()
+            try:
+                return fs.run(d, batch, noise, ddim=ddim, lowprec=lowprec)["other_outputs"]["pred_vertices"].clone()
+            except _lib.EgoHMRRangeError:
+                saturated.append(name or prec)
+                return None
         finally:
             model.gcn_precision = "f16x3"
 
+    from egohmr_amd import _lib
     ref = loop("f32", 0)
     for name, prec, low in (("f16x3", "f16x3", 0), (f"scheduled(k={info['k']})", "f16x3", T - info["k"]), ("f16", "f16", 0)):
-        v = loop(prec, low)
+        v = loop(prec, low, name)
+        if v is None:                                   # clamped activations: the loop's result was refused, not compared
+            rows[name] = {"max_vertex_dist_m": float("inf"), "mean_v2v_m": float("inf"), "saturated": True}
+            continue
         dv = (v - ref).norm(dim=-1)
         rows[name] = {"max_vertex_dist_m": float(dv.max()), "mean_v2v_m": float(dv.mean())}
+    put("precision", "activations_inside_f16_range", not [n for n in saturated if n != "f16"],
+        ("no X2 / f16 store of the denoiser clamped" if not saturated else f"clamped in: {saturated}") +
+        " (|x| >= 65504 raises status bit 2; remedy: EgoHMR.gcn_precision = 'f32' for this checkpoint, or EgoHMR.on_saturation = 'f32')")
     put("precision", "f16x3_within_1e-4_of_f32", rows["f16x3"]["max_vertex_dist_m"] < 1e-4, json.dumps(rows["f16x3"]))
     put("precision", "scheduled_within_1e-4_of_f32", rows[f"scheduled(k={info['k']})"]["max_vertex_dist_m"] < 1e-4, json.dumps(rows[f"scheduled(k={info['k']})"]))
     put("precision", "f16_reported_only", True, json.dumps(rows["f16"]), hard=False)

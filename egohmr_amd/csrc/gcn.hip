@@ -484,6 +484,7 @@ int ehm_gcn_input_args(ehm_gcn* h, const float* h_img, const float* h_oth, const
   a->mask_items = (passes == 2 && h->num_masked >= 0) ? h->mask_items : nullptr;
   a->sticky = h->chain_sticky;
   a->total_vb = ehm_gcn_virtual_bodies(h, B, passes);
+  h->valid_rows = (int64_t)a->total_vb * kJ;
   a->ny = (int)ceil_div(h->hid, 256);
   return 0;
 }
@@ -511,6 +512,7 @@ extern "C" int ehm_gcn_input_layer_rows(ehm_gcn* h, const float* pre, float* out
   a.total_vb = bodies;
   a.ny = (int)ceil_div(h->hid, 256);
   a.sticky = h->chain_sticky;
+  h->valid_rows = (int64_t)bodies * kJ;
   a.pre = pre;
   dim3 grid((unsigned)a.total_vb, (unsigned)a.ny);
   if (h->precision == EHM_PREC_F32) hipLaunchKernelGGL(gcn_input_rows_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -53,6 +53,8 @@ struct ehm_gcn {
   LayerDev hidden[16]{};
   LayerDev* hidden_dev = nullptr;        // device copy of hidden[] for the chained kernel (gcn_tile.hip)
   unsigned int* chain_sync = nullptr;    // tickets[8] | done[nl][m_tiles] | err | finished, zeroed before every chained launch
+  int64_t valid_rows = 0;                // rows the last input conv / checked pack produced (0: unknown = all): what the epilogues' range guard looks at - the
+                                         // tile padding behind them holds don't-care values (float32 rows of a last conv re-read as X2 halves, uninitialised scratch)
   unsigned int* chain_sticky = nullptr;  // one word, zeroed at create / by ehm_gcn_stack_status: accumulates the launches' err flags
   size_t chain_sync_words = 0;
   int chain_sync_clean = 0;              // 1: the last chained launch zeroed tickets / done / finished itself (its last block does)

@@ -91,6 +91,7 @@ struct ChainArgs {
                             // missing, bit 2 (kStickySaturated) = an activation reached the f16 range in an epilogue store and was clamped
   unsigned int* finished;   // blocks that ran out of tickets; the last one audits done[nl-1][*]
   int nq;                   // queues = XCDs
+  unsigned int rows_valid;  // rows in front of the tile padding (range guard of the epilogue stores)
 };
 
 struct OneArgs {
@@ -100,6 +101,7 @@ struct OneArgs {
   void* Y;
   int m_tiles, out_f32;
   unsigned int* sticky;     // the handle's status word (ehm_gcn_stack_status): bit 2 = an f16 store saturated
+  unsigned int rows_valid;  // rows in front of the tile padding: the range guard looks at these only (padding rows hold don't-care values)
 };
 
 template <int P>
@@ -888,6 +890,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
     // relative only, beyond 131008 it is lost; plain f16 rows lose it at once).  Nothing becomes inf / NaN, so nothing downstream would notice:
     // the tile's largest |v| (one v_max3_f32 per two stored values) raises bit 2 of the handle's status word instead
     float vmax = 0.f;
+    const unsigned int wave_row0 = (unsigned int)cur.m_tile * 192u + 96u * (unsigned int)wm;
+    const unsigned int valid_wave_rows = a.rows_valid > wave_row0 ? a.rows_valid - wave_row0 : 0u;   // rows of this wave's 96 that are real
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (P == 3) { if (p == 1) load_res_pass(1); }
@@ -923,8 +927,11 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
             for (int c = 0; c < 8; ++c) v[c] += (float)rh[c];
           }
         }
-#pragma unroll
-        for (int c = 0; c < 8; c += 2) vmax = fmaxf(vmax, fmaxf(fabsf(v[c]), fabsf(v[c + 1])));
+        {
+          float im = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          im = fmaxf(im, fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+          vmax = fmaxf(vmax, item_vrow(p, it) < valid_wave_rows ? im : 0.f);      // (padding rows carry don't-care values: not looked at)
+        }
         const unsigned int vo = item_vrow(p, it) * orow + col_out;
         if (out_f32) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]}), yB, vo, 0, kStoreAux);
@@ -1071,6 +1078,7 @@ int ehm_gcn_tile_layer_impl(const ehm_gcn* h, int layer, const void* X, const vo
   a.m_tiles = (int)(rows_pad / 192);
   a.out_f32 = out_f32 ? 1 : 0;
   a.sticky = h->chain_sticky;
+  a.rows_valid = (unsigned int)(h->valid_rows > 0 && h->valid_rows < rows_pad ? h->valid_rows : rows_pad);
   const int blocks = a.m_tiles * (h->hid / 64);
   if (h->precision == EHM_PREC_F16X3) hipLaunchKernelGGL(gcn_hidden_tile_kernel<3>, dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gcn_hidden_tile_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
@@ -1120,6 +1128,7 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   a.err = h->chain_sync + h->chain_err_off;
   a.finished = a.err + 1;
   a.sticky = h->chain_sticky;
+  a.rows_valid = (unsigned int)(h->valid_rows > 0 && h->valid_rows < rows_pad ? h->valid_rows : rows_pad);
   const int total = nl * m_tiles * n_tiles;
   int blocks = (wide ? 1 : 2) * ehm_num_cus();         // what is co-resident (80 KiB LDS per 4-wave block, 112 KiB per 8-wave block)
 #ifdef EHM_STAMPS
@@ -1147,6 +1156,7 @@ extern "C" int ehm_gcn_pack_activations(const float* X, void* X2, int64_t rows, 
 
 extern "C" int ehm_gcn_pack_activations_checked(ehm_gcn* h, const float* X, void* X2, int64_t rows, void* stream) {
   EHM_CHECK_ARG(h && X && X2 && rows > 0 && h->precision != EHM_PREC_F32);
+  h->valid_rows = rows;
   const int K = h->hid;
   const dim3 grid((unsigned)ceil_div(rows * K, 256));
   if (h->precision == EHM_PREC_F16) hipLaunchKernelGGL(pack_half_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (half_t*)X2, (size_t)rows * K, 1.f, h->chain_sticky);

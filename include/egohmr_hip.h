@@ -186,7 +186,8 @@ int ehm_gcn_hidden_stack(ehm_gcn* h, float* const bufs[3], int64_t rows_pad, int
  * timed-out producer wait or an unproduced tile (never expected; the kernel gives up instead of hanging the device, and audits its own completion):
  * -5 (EIO), the results computed since the previous call are invalid; or whether an activation of the input / hidden convs reached the f16 range
  * (|x| >= 65504) in an X2 / f16 store and was clamped: -34 (ERANGE) - finite results that are not parity grade; that checkpoint needs
- * ehm_gcn_set_precision(h, 0).  0 = fine.  (The reference's float32 activations have no such limit: modulated_gcn.py:99-116.) */
+ * ehm_gcn_set_precision(h, 0).  0 = fine.  (The reference's float32 activations have no such limit: modulated_gcn.py:99-116.)  The guard covers the
+ * rows the handle's last ehm_gcn_input_layer / _rows / ehm_gcn_pack_activations_checked call produced; the tile padding behind them is don't-care. */
 int ehm_gcn_stack_status(ehm_gcn* h, void* stream);
 /* The same word copied to *host_flag (pinned host memory owned by the caller) in stream order WITHOUT synchronising: a pipeline that
  * keeps batches in flight looks at *host_flag once the stream has passed this point (an event), and calls ehm_gcn_stack_status to

@@ -375,7 +375,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
         float vm = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; k += 2) vm = fmaxf(vm, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
-        if (vm >= 65504.f) __hip_atomic_fetch_or(a.sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (vm >= 65504.f && vm <= 3.0e38f) __hip_atomic_fetch_or(a.sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (finite only: inf / NaN inputs have their own rule)
       }
       half8 hh, ll;
 #pragma unroll

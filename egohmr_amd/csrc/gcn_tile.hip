@@ -948,7 +948,8 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
         }
       }
     }
-    if (!out_f32 && vmax >= 65504.f) __hip_atomic_fetch_or(a.sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (finite values only: an item whose INPUT was inf / NaN is made loud by the NaN rule of the output packer, for that item alone)
+    if (!out_f32 && vmax >= 65504.f && vmax <= 3.0e38f) __hip_atomic_fetch_or(a.sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // stage 1's activation pieces are free again: fetch them for the next tile
     if constexpr (CHAIN) {
       if (a_issued) issue_late();
@@ -1025,7 +1026,7 @@ __global__ void pack_half_kernel(const float* __restrict__ X, half_t* __restrict
   if (i >= n) return;
   const float v = X[i] * scale;
   Y[i] = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
-  if (sticky && fabsf(v) >= 65504.f) __hip_atomic_fetch_or(sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (sticky && fabsf(v) >= 65504.f && fabsf(v) <= 3.0e38f) __hip_atomic_fetch_or(sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void unpack_half_kernel(const half_t* __restrict__ X, float* __restrict__ Y, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1036,7 +1037,7 @@ __global__ void pack_x2_kernel(const float* __restrict__ X, half_t* __restrict__
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * K) return;
   split_store<G>(Y, i / K, (int)(i % K), K, X[i]);
-  if (sticky && fabsf(X[i]) >= 65504.f) __hip_atomic_fetch_or(sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (sticky && fabsf(X[i]) >= 65504.f && fabsf(X[i]) <= 3.0e38f) __hip_atomic_fetch_or(sticky, kStickySaturated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int G>
 __global__ void unpack_x2_kernel(const half_t* __restrict__ X, float* __restrict__ Y, int64_t rows, int K) {

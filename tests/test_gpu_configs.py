@@ -495,7 +495,7 @@ def test_split_f16_hidden_conv_range_behaviour(dev, case):
     # Beyond |x| = 65504 the hi half is saturated and lo is no longer 2^-11 of it, so the dropped lo*lo product shows: the element is
     # still represented, but its products are only good to ~1e-4 relative (documented limit of the format; activations of the
     # denoiser are O(1..100))
-    rel = {"x7e4": 1e-4, "sat2e5": 5e-4}.get(case, 3e-6)      # (lo / hi = 0.07 resp. 1 instead of 2^-11: the dropped lo*lo term is that much larger)
+    rel = {"x7e4": 1e-4, "sat2e5": 5e-4, "out1e5": 2e-5}.get(case, 3e-6)   # (out1e5: the 1e6 BatchNorm scale multiplies the f32 rounding of its channel)      # (lo / hi = 0.07 resp. 1 instead of 2^-11: the dropped lo*lo term is that much larger)
     assert float((y - r)[lim].abs().max()) < rel * max(1.0, float(r[lim].abs().max()))
     L.ehm_gcn_destroy(h)
 

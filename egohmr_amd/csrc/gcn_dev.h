@@ -60,6 +60,7 @@ struct ehm_gcn {
   int chain_sync_clean = 0;              // 1: the last chained launch zeroed tickets / done / finished itself (its last block does)
   int64_t chain_sync_shape = 0;          // nl * m_tiles the words were last used with (err sits right behind done[])
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
+  int chain_stagger = 0;                 // ehm_gcn_set_chain_stagger: start offset of a CU's second chain block, in units of 8128 cycles
   int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (f16 modes), 0 = one launch per conv (EHM_F16_CHAIN=0)
   OutDev out{};
   float* arena = nullptr;
@@ -332,8 +333,8 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
     for (int r = 0; r < 12; ++r) {                               // D row = (r&3) + 8 (r>>2) + 4 half = joint; r >> 2 == 3 is padding
       const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
       const float va = relu ? fmaxf(DA[r], 0.f) : DA[r], vb = relu ? fmaxf(DB[r], 0.f) : DB[r];
-      T[j * 256 + cA] = va;
-      T[j * 256 + cA + 32] = vb;
+      T[j * 256 + cA] = fmaf(DA[r], 0.f, va);                       // (non-finite stays NaN through the ReLU and the saturating store: see below)
+      T[j * 256 + cA + 32] = fmaf(DB[r], 0.f, vb);
     }
   } else {
     typedef const float __attribute__((address_space(4))) cfloat;
@@ -354,9 +355,15 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
     }
 #pragma unroll
     for (int jj = 0; jj < kJ / 2; ++jj) {
-      if (relu) { sacc[jj][0] = fmaxf(sacc[jj][0], 0.f); sacc[jj][1] = fmaxf(sacc[jj][1], 0.f); }
-      T[(2 * jj) * 256 + tid] = sacc[jj][0];
-      T[(2 * jj + 1) * 256 + tid] = sacc[jj][1];
+      // An inf / NaN in the body's x_t (a non-finite noise draw: the item's outputs are NaN by the packer's rule) must not come out of the saturating
+      // f16 stores below as a FINITE +-65504: the hidden convs would turn that into large finite activations and raise the range guard for an item that
+      // is already accounted for.  v + 0 * v_pre_relu is v for finite values and NaN otherwise (f16 modes only; one FMA per value); the first hidden
+      // conv's ReLU then maps the NaN rows to 0.
+      f32x2 o = sacc[jj];
+      if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
+      if constexpr (OUT != 0) o = __builtin_elementwise_fma(sacc[jj], f32x2{0.f, 0.f}, o);
+      T[(2 * jj) * 256 + tid] = o[0];
+      T[(2 * jj + 1) * 256 + tid] = o[1];
     }
   }
   __syncthreads();
@@ -380,7 +387,7 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
       half8 hh, ll;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float c = fminf(fmaxf(v[k], -65504.f), 65504.f);
+        const float c = fmaf(v[k], 0.f, fminf(fmaxf(v[k], -65504.f), 65504.f));   // (+ 0 * v: inf / NaN stay NaN - the clamp alone would store +-65504)
         hh[k] = (half_t)c;
         ll[k] = (half_t)fminf(fmaxf(v[k] - (float)hh[k], -65504.f), 65504.f);
       }

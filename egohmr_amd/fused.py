@@ -76,6 +76,7 @@ class FusedSampler:
                                            W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :], W_img_cat=W_img_cat, W_oth_cat=W_oth_cat,
                                            k_oth=k_oth)
         _lib.check(_lib.lib().ehm_gcn_set_uncond_mode(self._gcn, 0 if self.model.only_mask_img_cond else 1), "ehm_gcn_set_uncond_mode")
+        _lib.check(_lib.lib().ehm_gcn_set_chain_stagger(self._gcn, int(self.model.chain_stagger)), "ehm_gcn_set_chain_stagger")
         mode = PRECISIONS[self.model.gcn_precision]
         if _lib.lib().ehm_gcn_get_precision(self._gcn) != mode:
             _lib.check(_lib.lib().ehm_gcn_set_precision(self._gcn, mode), "ehm_gcn_set_precision")
@@ -196,6 +197,12 @@ class FusedSampler:
             scene_feats = m.scene_enc(scene)
         oth[:, :n_scene].copy_(scene_feats)                                            # :220-221 [scene | transl | cam] (the rest was written by ehm_item_prep)
         h_img, h_oth, betas = self._project(img_feats.contiguous(), oth, n_other)
+        # items with a non-finite input (flags[0] == 0: their outputs are NaN by the packer's rule) get ZERO conditioning: the encoders' saturating f16 stores
+        # have turned their inf / NaN into large FINITE features, which would drive the denoiser's activations to the f16 range and raise its range guard
+        # (status bit 2) for an item that is already accounted for
+        bad = (flags[0] == 0).view(B, 1, 1)
+        h_img.masked_fill_(bad, 0.0)
+        h_oth.masked_fill_(bad, 0.0)
         count_ready.synchronize()
         num_masked = int(self._count_host[0])
         mask_slot, mask_items = maps[:B], maps[B:B + num_masked]

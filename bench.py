@@ -285,8 +285,6 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     sens = dict(num_diffusion_timesteps=n) if args.weights == "sensitive" else None
     model = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=sens, volsmpl=volsmpl)
     model.lbs_every_step = not args.no_lbs_every_step
-    if args.chain_stagger is not None:
-        model.chain_stagger = int(args.chain_stagger)
     model.gcn_precision = args.precision
     if args.precision_given is None and workload in WORKLOAD_PRECISION:
         model.encoder_precision = "f16"
@@ -674,7 +672,6 @@ def main():
     ap.add_argument("--f16x3-last-steps", type=int, default=None,
                     help="explicit k instead of the calibration (e.g. the k a previous run printed): no calibration launches, so that under rocprofv3 "
                          "every launch of a chain kernel is a full-size one and the kernel-stats average equals roofline.avg_launch_ms * 8")
-    ap.add_argument("--chain-stagger", type=int, default=None, help="EgoHMR.chain_stagger for this run (A/B of the chain kernel's block phase offset)")
     ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (all-f16x3, f32, f16, other weight set)")
     ap.add_argument("--no-configs", action="store_true", help="default workload only: do not append BASELINE configs 2 and 3 (configs.c2_ddim10 / configs.c3_guided)")
     ap.add_argument("--launch-check", action="store_true", help="only initialise the ranks, report the world size, exit (works without a GPU: gloo)")

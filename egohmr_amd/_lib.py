@@ -194,7 +194,6 @@ PROTOTYPES = {
     "ehm_gcn_row_tile": (_I, []),
     "ehm_gcn_set_precision": (_I, [_P, _I]),
     "ehm_gcn_get_precision": (_I, [_P]),
-    "ehm_gcn_set_chain_stagger": (_I, [_P, _I]),
     "ehm_gcn_set_uncond_mode": (_I, [_P, _I]),
     "ehm_gcn_set_pass_map": (_I, [_P, _P, _P, _I]),
     "ehm_gcn_set_nonlocal": (_I, [_P, C.POINTER(NonlocalParams)]),

@@ -685,11 +685,6 @@ extern "C" int ehm_gcn_set_precision(ehm_gcn* h, int mode) {
   h->precision = mode;
   return 0;
 }
-extern "C" int ehm_gcn_set_chain_stagger(ehm_gcn* h, int units) {
-  EHM_CHECK_ARG(h && units >= 0 && units <= 64);
-  h->chain_stagger = units;
-  return 0;
-}
 extern "C" int ehm_gcn_get_precision(const ehm_gcn* h) { return h ? h->precision : EHM_EINVAL; }
 extern "C" int ehm_gcn_set_uncond_mode(ehm_gcn* h, int masks_whole_condition) {
   EHM_CHECK_ARG(h && (masks_whole_condition == 0 || masks_whole_condition == 1));

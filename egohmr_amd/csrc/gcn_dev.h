@@ -60,7 +60,6 @@ struct ehm_gcn {
   int chain_sync_clean = 0;              // 1: the last chained launch zeroed tickets / done / finished itself (its last block does)
   int64_t chain_sync_shape = 0;          // nl * m_tiles the words were last used with (err sits right behind done[])
   size_t chain_err_off = 0;              // word offset of err in chain_sync for the last launch
-  int chain_stagger = 0;                 // ehm_gcn_set_chain_stagger: start offset of a CU's second chain block, in units of 8128 cycles
   int chain = 1;                         // ehm_gcn_hidden_stack: 1 = all hidden convs in one chained launch (f16 modes), 0 = one launch per conv (EHM_F16_CHAIN=0)
   OutDev out{};
   float* arena = nullptr;
@@ -318,8 +317,9 @@ __device__ __forceinline__ void gcn_input_body(float* T, int tid, int bx, int by
         const int kp = 16 * s3 + 2 * e, kq = kp + 8;             // < 24: h1[k], else h0[k - 24]
         const float p0 = kp < kJ ? h1[kp] : h0[kp - kJ], p1 = kp + 1 < kJ ? h1[kp + 1] : h0[kp + 1 - kJ];
         const float q0 = kq < kJ ? h1[kq] : h0[kq - kJ], q1 = kq + 1 < kJ ? h1[kq + 1] : h0[kq + 1 - kJ];
-        const half2_t hp = {(half_t)fminf(fmaxf(p0, -65504.f), 65504.f), (half_t)fminf(fmaxf(p1, -65504.f), 65504.f)};
-        const half2_t hq = {(half_t)fminf(fmaxf(q0, -65504.f), 65504.f), (half_t)fminf(fmaxf(q1, -65504.f), 65504.f)};
+        // (+ 0 * v: an inf / NaN operand stays NaN through the clamp, see the range-guard note at the float path's store below)
+        const half2_t hp = {(half_t)fmaf(p0, 0.f, fminf(fmaxf(p0, -65504.f), 65504.f)), (half_t)fmaf(p1, 0.f, fminf(fmaxf(p1, -65504.f), 65504.f))};
+        const half2_t hq = {(half_t)fmaf(q0, 0.f, fminf(fmaxf(q0, -65504.f), 65504.f)), (half_t)fmaf(q1, 0.f, fminf(fmaxf(q1, -65504.f), 65504.f))};
         const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, hp), __builtin_bit_cast(unsigned int, hq), false, false);
         Pw[e] = sw[0];
         Qw[e] = sw[1];

@@ -92,7 +92,6 @@ struct ChainArgs {
   unsigned int* finished;   // blocks that ran out of tickets; the last one audits done[nl-1][*]
   int nq;                   // queues = XCDs
   unsigned int rows_valid;  // rows in front of the tile padding (range guard of the epilogue stores)
-  int stagger;              // > 0: the block in the ODD workgroup slot of its CU starts `stagger` x 8128 cycles late (ehm_gcn_set_chain_stagger)
 };
 
 struct OneArgs {
@@ -412,12 +411,6 @@ __device__ __forceinline__ void run_tiles(float* lds, const Args& a) {
   unsigned int t_cur = 0;
   if constexpr (CHAIN) {
     q = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (unsigned int)a.nq;   // HW_REG_XCC_ID[3:0] -> my queue
-    // Phase offset of the two co-resident blocks of a CU.  All blocks of a launch start together, so both blocks of a CU run their K loops - and then
-    // their epilogues - at the same time: the matrix pipe idles while BOTH waves of a SIMD are in an epilogue (stamps: tile 98.4 k cycles for 2 x 36.9 k
-    // MFMA cycles per SIMD).  The block in the odd workgroup slot (HW_REG_HW_ID.TG_ID) sleeps for about half a tile first, so that one wave's epilogue
-    // falls under its partner's K loop.
-    if (a.stagger > 0 && ((__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1u) != 0u))
-      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     const int cm = (a.m_tiles - (int)q + a.nq - 1) / a.nq;                          // row tiles of this queue: q, q + nq, ...
     ipl = (unsigned int)((cm > 0 ? cm : 0) * a.n_tiles);
     total = ipl * (unsigned int)a.nl;
@@ -1143,7 +1136,6 @@ int ehm_gcn_tile_chain_impl(ehm_gcn* h, void* const bufs[3], int64_t rows_pad, h
   if (const char* e = getenv("EHM_CHAIN_BLOCKS")) blocks = atoi(e);   // stamp builds only: e.g. one block per CU to time a tile without a co-resident partner
 #endif
   if (blocks > total) blocks = total;
-  a.stagger = h->chain_stagger;
   a.nq = ehm_num_cus() / 32;
   if (a.nq < 1) a.nq = 1;
   if (a.nq > 8) a.nq = 8;

@@ -76,7 +76,6 @@ class FusedSampler:
                                            W_oth=gi.gconv.W.detach()[:, a:b, :], W_t=W[:, c:d, :], W_img_cat=W_img_cat, W_oth_cat=W_oth_cat,
                                            k_oth=k_oth)
         _lib.check(_lib.lib().ehm_gcn_set_uncond_mode(self._gcn, 0 if self.model.only_mask_img_cond else 1), "ehm_gcn_set_uncond_mode")
-        _lib.check(_lib.lib().ehm_gcn_set_chain_stagger(self._gcn, int(self.model.chain_stagger)), "ehm_gcn_set_chain_stagger")
         mode = PRECISIONS[self.model.gcn_precision]
         if _lib.lib().ehm_gcn_get_precision(self._gcn) != mode:
             _lib.check(_lib.lib().ehm_gcn_set_precision(self._gcn, mode), "ehm_gcn_set_precision")

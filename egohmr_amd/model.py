@@ -381,7 +381,6 @@ class EgoHMR(nn.Module):
         # switch this model to gcn_precision 'f32' (float32 activations, no such limit) and run the call again.  Calls issued with defer_status=True
         # always raise (at check_status(): their results have been handed out already)
         self.on_saturation = "raise"
-        self.chain_stagger = 0                 # scheduling knob of the chained hidden-conv launches (ehm_gcn_set_chain_stagger; no effect on results)
         self.per_step_launches = False     # True: the separate per-step launches of rounds 2-3 instead of step_fused_kernel (same bits; A/B runs and tests)
         self.pass_group = 1                # second passes pruned per item (1) or per group of this many consecutive items (FusedSampler.prepare)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)

@@ -120,9 +120,6 @@ void ehm_gcn_destroy(ehm_gcn* h);
  * [rows_pad,hid] throughout.  ehm_gcn_output_layer reads what the handle's mode produces.  ehm_gcn_pack/unpack_activations convert float32 <-> the mode's format (tests, interop). */
 int ehm_gcn_set_precision(ehm_gcn* h, int mode);
 int ehm_gcn_get_precision(const ehm_gcn* h);
-/* Scheduling knob of the chained launches (no effect on results): the block that lands in the odd workgroup slot of a CU starts `units` x 8128 shader cycles
- * late, so that the two co-resident blocks of a CU do not run their epilogues at the same time.  0 = off.  0 <= units <= 64. */
-int ehm_gcn_set_chain_stagger(ehm_gcn* h, int units);
 /* group = ehm_gcn_activation_group(h): 32 = X2 split format (mode 1), 0 = plain f16 (mode 2); pass it to pack / unpack */
 int ehm_gcn_activation_group(const ehm_gcn* h);
 /* Size the handle's internal scratch (chained-launch counters, output-conv responses) for batches of up to max_bodies bodies x

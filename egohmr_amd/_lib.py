@@ -229,8 +229,6 @@ PROTOTYPES = {
     "ehm_smpl_backward_rot6d": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "ehm_guidance_grad_finish": (_I, [_P, _P, _P, _I, _F, _P]),
     "ehm_nn_dist2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "ehm_nn_grid_workspace_bytes": (C.c_int64, [_I, _I]),
-    "ehm_nn_dist2_grid": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, C.c_int64, _P, _P]),
     "ehm_eval_point_errors": (_I, [C.POINTER(EvalPointsDesc), _P]),
     "ehm_eval_procrustes": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ehm_eval_diversity": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P]),

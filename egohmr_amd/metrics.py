@@ -15,12 +15,8 @@ import torch
 from . import _lib
 
 
-GRID_MIN_POINTS = 1024      # reference clouds of at least this many points are searched on the uniform grid (ehm_nn_dist2_grid); smaller ones by brute force
-
-
-def nn_dist2(x: torch.Tensor, y: torch.Tensor, return_idx: bool = False, method: str = "auto", count_evals: bool = False):
-    """Squared distance from every x[b,i] to its nearest y[b,:] (pytorch3d knn_points K=1 'dists').  method: 'auto' | 'grid' | 'brute' - the two kernels
-    return the same bits (csrc/metrics.hip).  count_evals (grid only): also return the number of distance evaluations (a measurement aid)."""
+def nn_dist2(x: torch.Tensor, y: torch.Tensor, return_idx: bool = False):
+    """Squared distance from every x[b,i] to its nearest y[b,:] (pytorch3d knn_points K=1 'dists')."""
     x, y = _lib.f32(x), _lib.f32(y)
     assert x.dim() == 3 and y.dim() == 3 and x.shape[0] == y.shape[0] and x.shape[2] == y.shape[2] == 3
     if not x.is_cuda:
@@ -28,21 +24,9 @@ def nn_dist2(x: torch.Tensor, y: torch.Tensor, return_idx: bool = False, method:
     B, P1, P2 = x.shape[0], x.shape[1], y.shape[1]
     d = torch.empty(B, P1, device=x.device, dtype=torch.float32)
     idx = torch.empty(B, P1, device=x.device, dtype=torch.int32) if return_idx else None
-    grid = method == "grid" or (method == "auto" and P2 >= GRID_MIN_POINTS)
-    evals = None
-    with _lib.on_device(x.device):
-        L = _lib.lib()
-        if grid:
-            ws = torch.empty(int(L.ehm_nn_grid_workspace_bytes(B, P2)), dtype=torch.uint8, device=x.device)
-            evals = torch.zeros(1, dtype=torch.int64, device=x.device) if count_evals else None
-            _lib.check(L.ehm_nn_dist2_grid(_lib.ptr(x), _lib.ptr(y), _lib.ptr(d), _lib.ptr(idx), B, P1, P2, ws.data_ptr(), ws.numel(),
-                                           evals.data_ptr() if evals is not None else None, _lib.stream_ptr()), "ehm_nn_dist2_grid")
-        else:
-            _lib.check(L.ehm_nn_dist2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(d), _lib.ptr(idx), B, P1, P2, _lib.stream_ptr()), "ehm_nn_dist2")
-    out = (d, idx) if return_idx else d
-    if count_evals:
-        return out, (int(evals) if evals is not None else B * P1 * P2)
-    return out
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ehm_nn_dist2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(d), _lib.ptr(idx), B, P1, P2, _lib.stream_ptr()), "ehm_nn_dist2")
+    return (d, idx) if return_idx else d
 
 
 def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,

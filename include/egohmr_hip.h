@@ -367,13 +367,6 @@ int ehm_guidance_grad_finish(const float* gpose6d, const float* loss, float* gra
  * test_egohmr.py:496-505): for every x[b,i] the SQUARED distance to its nearest y[b,:] and (optionally) its index.
  * x [B,P1,3], y [B,P2,3] -> dist2 [B,P1], idx [B,P1] int32 or NULL. */
 int ehm_nn_dist2(const float* x, const float* y, float* dist2, int32_t* idx, int B, int P1, int P2, void* stream);
-/* The same search - same results, bit for bit; ties go to the smallest index in both - on a uniform grid over each reference cloud y[b] (built by the call:
- * bounding box, counting sort into ~4-point cells, <= 32768 cells), queries walking shells of cells until no unvisited cell can hold a closer point.  For the
- * contact score's shape (6890 body vertices against 20 000 scene points, test_egohmr.py:496-505) this is ~100 distance evaluations per query instead of 20 000.
- * workspace: ehm_nn_grid_workspace_bytes(B, P2) bytes of device scratch.  evals (device, may be NULL): incremented by the number of distance evaluations. */
-int64_t ehm_nn_grid_workspace_bytes(int B, int P2);
-int ehm_nn_dist2_grid(const float* x, const float* y, float* dist2, int32_t* idx, int B, int P1, int P2, void* workspace, int64_t workspace_bytes,
-                      uint64_t* evals, void* stream);
 
 /* ------------------------------------------------------------------ evaluation block ---------- */
 /* test_egohmr.py:399-449: Euclidean error per point of S samples per item against ONE ground truth per item, its mean over the points and its sums over

@@ -55,51 +55,6 @@ def test_nn_dist2_device_vs_oracle(B, P1, P2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["uniform", "room", "far_queries", "flat", "duplicates", "one_point", "nonfinite_refs"])
-def test_nn_dist2_grid_equals_brute_force(case):
-    """ehm_nn_dist2_grid (uniform grid over the reference cloud, shells of cells, exact) against the brute-force kernel: the same distances BIT for bit and the
-    same indices (ties -> smallest index in both), on a filled box, a room-like cloud of surfaces with bodies inside (the contact score's shape), queries far
-    outside the reference box (many shells), a flat cloud (one cell layer), duplicated points (ties), a single reference point and non-finite reference points."""
-    from egohmr_amd import metrics
-    dev = torch.device("cuda:0")
-    g = np.random.Generator(np.random.PCG64(11))
-    B, P1, P2 = 3, 1500, 5000
-    if case == "uniform":
-        x, y = g.uniform(-1, 1, (B, P1, 3)), g.uniform(-1, 1, (B, P2, 3))
-    elif case == "room":
-        P1, P2 = 6890, 20000
-        y = g.uniform(0, 1, (B, P2, 3)) * np.array([5.0, 3.0, 4.0])
-        face = g.integers(0, 3, (B, P2))
-        for a in range(3):
-            y[..., a] = np.where(face == a, np.round(y[..., a] / [5.0, 3.0, 4.0][a]) * [5.0, 3.0, 4.0][a], y[..., a])     # points on the walls / floor / ceiling
-        x = np.array([2.5, 1.0, 2.0]) + 0.4 * g.normal(size=(B, P1, 3))
-    elif case == "far_queries":
-        x, y = 10.0 + 5.0 * g.normal(size=(B, P1, 3)), g.uniform(-1, 1, (B, P2, 3))
-    elif case == "flat":
-        y = g.uniform(-1, 1, (B, P2, 3)); y[..., 1] = 0.25
-        x = g.uniform(-1, 1, (B, P1, 3))
-    elif case == "duplicates":
-        y = np.repeat(g.uniform(-1, 1, (B, P2 // 4, 3)), 4, axis=1)
-        x = g.uniform(-1, 1, (B, P1, 3))
-    elif case == "one_point":
-        P2 = 1
-        x, y = g.uniform(-1, 1, (B, P1, 3)), g.uniform(-1, 1, (B, 1, 3))
-    else:
-        x, y = g.uniform(-1, 1, (B, P1, 3)), g.uniform(-1, 1, (B, P2, 3))
-        y[0, 7, 1], y[1, 100, 0], y[2, 4999, 2] = np.nan, np.inf, -np.inf
-    xd, yd = torch.from_numpy(x.astype(np.float32)).to(dev), torch.from_numpy(y.astype(np.float32)).to(dev)
-    (dg, ig), evals = metrics.nn_dist2(xd, yd, return_idx=True, method="grid", count_evals=True)
-    db, ib = metrics.nn_dist2(xd, yd, return_idx=True, method="brute")
-    assert torch.equal(dg, db)
-    assert torch.equal(ig, ib)
-    print(f"[{case}] {evals / (B * P1):.1f} distance evaluations per query on the grid (brute force: {P2})")
-    if case in ("uniform", "room"):
-        assert evals < 0.05 * B * P1 * P2
-    dauto = metrics.nn_dist2(xd, yd)
-    assert torch.equal(dauto, db)
-
-
-@pytest.mark.gpu
 def test_mpjpe_v2v_formulas():
     from egohmr_amd import metrics
     dev = torch.device("cuda:0")

@@ -45,7 +45,6 @@ class ResNet50Features(nn.Module):
     """models/resnet.py:139-150: ResNet-50 trunk, global average pool -> [B,2048]."""
 
     hi_only = False      # True: the plain-f16 tier of the trunk (ehm_conv_x2_desc.hi_only: hi halves only, one MFMA per product) - NOT parity grade
-    split_batches = True  # a batch just above a multiple of the slot-filling unit (256 = 250 + 6 images) runs as two passes on two streams (folded(): split_for_slots)
 
     def __init__(self):
         super().__init__()
@@ -74,37 +73,33 @@ class ResNet50Features(nn.Module):
 
     # ------------------------------------------------------------------ stream-K hand-off time-outs (csrc/conv.hip): made loud, never waited for
     def _sk_status_async(self, ws):
-        """Behind a trunk pass: a stream-ordered copy of the workspace's time-out count to pinned memory + an event.  Earlier passes' words
-        that have arrived are looked at first (no host wait on the product path)."""
+        """Behind a trunk pass: a stream-ordered copy of the workspace's time-out count to pinned memory + an event.  An earlier pass's word
+        that has arrived is looked at first (no host wait on the product path)."""
         if ws is None:                                     # (no conv of this pass had a stream-K plan)
             return
-        pend = self.__dict__.setdefault("_sk_pending", [])
-        if pend and all(ev.query() for ev, _, _ in pend):
+        ev = getattr(self, "_sk_event", None)
+        if ev is not None and ev.query():
             self.check_status()
-        host = torch.zeros(1, dtype=torch.int32).pin_memory() if not getattr(self, "_sk_free_hosts", None) else self._sk_free_hosts.pop()
-        _lib.check(_lib.lib().ehm_conv_x2_workspace_status(ws.data_ptr(), host.data_ptr(), _lib.stream_ptr()), "ehm_conv_x2_workspace_status")
-        ev = torch.cuda.Event()
-        ev.record()
-        self._sk_pending.append((ev, host, ws))
+        if getattr(self, "_sk_host", None) is None:
+            self._sk_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _lib.check(_lib.lib().ehm_conv_x2_workspace_status(ws.data_ptr(), self._sk_host.data_ptr(), _lib.stream_ptr()), "ehm_conv_x2_workspace_status")
+        self._sk_event = torch.cuda.Event()
+        self._sk_event.record()
+        self._sk_ws_checked = ws
 
     def check_status(self):
         """Raise if a stream-K conv of an earlier trunk pass timed out waiting for a partner block's partial sums (its tiles are NaN and the
-        workspace's counters poisoned); the workspace is zeroed again by the call, so the next pass is clean.  Waits for those passes."""
-        pend, self._sk_pending = self.__dict__.get("_sk_pending", []), []
-        err = None
-        for ev, host, ws in pend:
-            ev.synchronize()
-            bad = int(host[0]) != 0
-            host.zero_()
-            self.__dict__.setdefault("_sk_free_hosts", []).append(host)
-            if bad:
-                try:
-                    with torch.cuda.device(ws.device):
-                        _lib.check(_lib.lib().ehm_conv_x2_workspace_status(ws.data_ptr(), None, _lib.stream_ptr()), "ehm_conv_x2_workspace_status")
-                except _lib.EgoHMRHipError as e:           # (every poisoned workspace is cleaned before the first error is raised)
-                    err = err or e
-        if err is not None:
-            raise err
+        workspace's counters poisoned); the workspace is zeroed again by the call, so the next pass is clean.  Waits for that pass."""
+        ev = getattr(self, "_sk_event", None)
+        if ev is None:
+            return
+        ev.synchronize()
+        self._sk_event = None
+        if int(self._sk_host[0]) != 0:
+            self._sk_host.zero_()
+            ws = self._sk_ws_checked
+            with torch.cuda.device(ws.device):
+                _lib.check(_lib.lib().ehm_conv_x2_workspace_status(ws.data_ptr(), None, _lib.stream_ptr()), "ehm_conv_x2_workspace_status")
 
     # ------------------------------------------------------------------ inference form: BatchNorm folded into the convolutions
     @torch.no_grad()
@@ -132,8 +127,7 @@ class ResNet50Features(nn.Module):
                 blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), fold(blk.conv3, blk.bn3),
                                fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
         packed = {}
-        sk_ws = {}                                         # (device, stream) -> scratch of the stream-K convs (one conv at a time on a stream)
-        side_streams = {}                                  # device -> the side stream of split batches (run_x2)
+        sk_ws = {}                                         # device -> scratch of the stream-K convs (one conv at a time on a stream)
 
         def pack(p):
             """weights [Co,Ci,KH,KW] -> tap-major [Co_pad, KH*KW*Ci] X2 split format, scaled by a power of two"""
@@ -223,18 +217,17 @@ class ResNet50Features(nn.Module):
                 d.x2, d.x2_rows, d.H2, d.W2, d.Ci2, d.stride2 = x_in.data_ptr(), x_in.shape[0], H2, W2, Ci2, stride2
             need = int(_lib.lib().ehm_conv_x2_workspace_bytes(C.byref(d)))      # stream-K scratch (layers 3 / 4: tile counts that straddle the block slots)
             if need:
-                wkey = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)         # one scratch per stream: one conv at a time on a stream
-                ws = sk_ws.get(wkey)
+                ws = sk_ws.get(str(x.device))
                 if ws is None or ws.numel() < need:
-                    ws = sk_ws[wkey] = torch.zeros(need, dtype=torch.uint8, device=x.device)   # zeroed ONCE: the convs leave their counters zeroed
+                    ws = sk_ws[str(x.device)] = torch.zeros(need, dtype=torch.uint8, device=x.device)   # zeroed ONCE: the convs leave their counters zeroed
                 d.workspace, d.workspace_bytes, d.workspace_clean = ws.data_ptr(), ws.numel(), 1
             _lib.check(_lib.lib().ehm_conv_x2(C.byref(d), _lib.stream_ptr()), "ehm_conv_x2")
             if _x2_debug_hook is not None:
                 _x2_debug_hook(y, Co)
             return y, (N, Ho, Wo)
 
-        def trunk_x2(x, out):
-            """the whole trunk with the activations in the X2 split format between the layers (taps gathered by the LDS DMA); out [N, 2048] is written"""
+        def run_x2(x):
+            """the whole trunk with the activations in the X2 split format between the layers (taps gathered by the LDS DMA)"""
             N = x.shape[0]
             shp = (N, x.shape[2] // 4, x.shape[3] // 4)
             x = stem_mc(x, x2=True)
@@ -247,49 +240,10 @@ class ResNet50Features(nn.Module):
                     x, shp = conv_x2(y, s2, c3, shortcut=(x, shp, ds))          # out = conv3(.) + downsample(x) in one launch: no shortcut tensor
                 else:
                     x, shp = conv_x2(y, s2, c3, res=conv_x2(x, shp, ds, relu=False)[0])
-            assert out.shape == (N, x.shape[1]) and out.is_contiguous()
+            out = torch.empty(N, x.shape[1], device=x.device)
             _lib.check(_lib.lib().ehm_x2_group_mean(x.data_ptr(), out.data_ptr(), N, shp[1] * shp[2], x.shape[1], int(bool(self.hi_only)), _lib.stream_ptr()),
                        "ehm_x2_group_mean")
-            self._sk_status_async(sk_ws.get((str(x.device), torch.cuda.current_stream(x.device).cuda_stream)))
-
-        def split_for_slots(N, H, W):
-            """(n_main, n_rest) or None.  Every conv of the trunk runs as persistent 192-row tiles on 2 blocks per CU; an image is (H/32)(W/32) rows at layer 4 and
-            4x / 16x / 64x that at layers 3 / 2 / 1, so the batch size at which layer 4's row tiles fill a quarter of the block slots fills WHOLE rounds of slots in
-            every layer: 250 images of 224 x 224 on 256 CUs.  A batch just above a multiple of that unit (256 = 250 + 6) spills a few per cent of the rows into an
-            extra round - or a stream-K tail - in every layer: measured 8.68 ms for 250 images, 9.82 ms for 256 (profiles/r06g_trunk_tile_quantization.txt).  Such a
-            batch is run as the whole units on this stream and the few remaining images as a second trunk pass on a side stream (its small launches slip into the
-            slots the main pass leaves at its kernel boundaries).  Images are independent: the features do not depend on the split."""
-            p4 = (H // 32) * (W // 32)
-            slots = 2 * int(torch.cuda.get_device_properties(stem_wt.device).multi_processor_count)
-            unit = (slots // 8 * 192) // max(p4, 1)              # layer 4's first conv has 4 column tiles: slots / 4 row tiles of 192 rows... per half round
-            if unit < 32:
-                return None
-            k = N // unit
-            rest = N - k * unit
-            if k < 1 or rest == 0 or rest > unit // 8:
-                return None
-            return k * unit, rest
-
-        def run_x2(x):
-            N = x.shape[0]
-            out = torch.empty(N, 2048, device=x.device)
-            sp = split_for_slots(N, x.shape[2], x.shape[3]) if self.split_batches else None
-            self.last_split = sp
-            if sp is None:
-                trunk_x2(x, out)
-                return out
-            n_main = sp[0]
-            cur = torch.cuda.current_stream(x.device)
-            side = side_streams.get(str(x.device))
-            if side is None:
-                side = side_streams[str(x.device)] = torch.cuda.Stream(device=x.device)
-            side.wait_stream(cur)                                   # x and out exist
-            with torch.cuda.stream(side):
-                trunk_x2(x[n_main:], out[n_main:])
-            trunk_x2(x[:n_main], out[:n_main])
-            cur.wait_stream(side)
-            x.record_stream(side)
-            out.record_stream(side)
+            self._sk_status_async(sk_ws.get(str(x.device)))
             return out
 
         def run(x):

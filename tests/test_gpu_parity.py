@@ -618,35 +618,6 @@ def test_conv_x2_vs_torch_fp64(dev, case):
 
 
 @pytest.mark.gpu
-def test_resnet_trunk_batch_split_for_block_slots(dev):
-    """ResNet50Features at the benchmark batch (256 images = 250 + 6: the slot-filling unit + a remainder run as a second trunk pass on a side stream,
-    encoders.py split_for_slots) against the same batch in one pass: images are independent, so the features agree to float32 re-association of the
-    stream-K hand-offs (a tile cut by a run boundary sums its K ranges in another order) - and both agree with the per-image features of a small batch."""
-    from egohmr_amd.encoders import ResNet50Features
-    torch.manual_seed(5)
-    net = ResNet50Features().to(dev).eval()
-    with torch.no_grad():
-        for m in net.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.running_var.uniform_(0.5, 1.5); m.running_mean.normal_(0, 0.1); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
-    img = torch.randn(256, 3, 224, 224, device=dev)
-    net.split_batches = True
-    a = net(img).clone()
-    assert net.last_split == (250, 6)
-    net.split_batches = False
-    b = net(img).clone()
-    assert net.last_split is None
-    torch.cuda.synchronize()
-    scale = float(b.abs().max())
-    assert float((a - b).abs().max()) <= 2e-6 * scale, (float((a - b).abs().max()), scale)
-    small = net(img[248:253].contiguous())                      # images on both sides of the split, as a batch of their own
-    assert float((small - a[248:253]).abs().max()) <= 2e-6 * scale
-    net.split_batches = True
-    assert net(img[:200].contiguous()).shape == (200, 2048) and net.last_split is None     # below one unit: one pass
-    net.check_status()
-
-
-@pytest.mark.gpu
 def test_conv_x2_stream_k_timeout_is_nan_through_relu_and_reported(dev):
     """A stream-K tile whose partners' partial sums cannot be trusted (arrival counter poisoned by an earlier hand-off time-out) comes out as NaN although
     the conv ends in a ReLU (v_max_f32 would turn NaN into 0), the workspace counts it, ehm_conv_x2_workspace_status reports it once and zeroes the counters,

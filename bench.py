@@ -138,6 +138,10 @@ def compact_line(d):
         subs[name] = e
     if subs:
         out["configs"] = subs
+    ev = d.get("evaluation_block") or {}
+    if ev.get("contact_score"):
+        out["evaluation_block"] = {"contact_ms_1280_bodies": _num(ev["contact_score"]["ms"]), "contact_frac_f32_vector_peak": _num(ev["contact_score"]["frac_of_f32_vector_peak"], 3),
+                                   "pa_mpjpe_ms": _num(ev.get("pa_mpjpe_ms"), 3), "v2v_GBps": _num((ev.get("v2v") or {}).get("GB_per_s"))}
     legs = {}
     for name in ("all_steps_f16x3", "f32_mfma_path", "f16_denoiser_path", "fp16_tier", "schedule_at_contract_tol"):
         if d.get(name):
@@ -715,6 +719,14 @@ def main():
             if sub["config"].get("guidance_weight") is not None:
                 subs[wl]["guidance_weight"] = sub["config"]["guidance_weight"]          # (C5 is timed at 0.5, not the VolSMPL default 30: see w_guid)
         out["configs"] = subs
+        # the evaluation block's kernels at config 3's shape (128 items x 10 samples, 20 000-point scenes as the reference's data): the contact score's
+        # nearest-neighbour search against the f32 vector rate, V2V / MPJPE / PA-MPJPE / diversity (csrc/metrics.hip, csrc/eval.hip; test_egohmr.py:399-505)
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import bench_metrics
+            out["evaluation_block"] = bench_metrics.measure(128, 10, 20000, reps=3, dev=dev)
+        except Exception as e:                                  # (a measurement aid: never lets the bench line fail)
+            out["evaluation_block"] = {"error": repr(e)}
     if rank == 0:
         emit(out)
     edist.barrier()

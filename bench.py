@@ -151,7 +151,7 @@ def compact_line(d):
     out["detail"] = "bench_detail.json"
     line = json.dumps(out, allow_nan=False, separators=(",", ":"))
     # belt and braces: drop optional blocks, longest first, until the line fits
-    for k in ("legs", "roofline_hbm", "configs"):
+    for k in ("evaluation_block", "legs", "roofline_hbm", "configs"):
         if len(line) <= COMPACT_LIMIT:
             break
         out.pop(k, None)

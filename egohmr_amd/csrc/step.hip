@@ -30,7 +30,9 @@ constexpr int kFusedT = kJ * 256;              // floats of one 256-channel grou
 //   NT = 1024 (batches of up to one body per CU): the round-4 shape - with one body per CU its chain of phases IS the launch's duration, and four
 //             groups walk the body's 8 input-conv units in two rounds (LDS 96 KiB: one block per CU);
 //   NT = 512  (bigger batches): 48 KiB of LDS and 128 registers let TWO blocks share a CU, so that one body's global-memory round trips hide behind
-//             another's vector-ALU work (1280 bodies: 297 -> 254 us per launch).
+//             another's vector-ALU work (1280 bodies: 297 -> 254 us per launch);
+//   NT = 256  (more than two bodies per CU): FOUR independent bodies per CU - the same 16 waves, barriers among four waves instead of eight, a body's eight
+//             input-conv units one after the other (1280 bodies: 246 -> 222 us per launch, profiles/r06l_step_fused_nt256_ab.txt).
 // (Two half-blocks per body - each with half of the input-conv units, both recomputing the responses - were built too: 62 -> 70 us at 256 bodies,
 //  and a race: the chain's result and the next input rows share one buffer, which is only safe while ONE block reads a body's rows before it
 //  overwrites them.)  The update runs on three waves (48 elements each) instead of one.
@@ -125,6 +127,7 @@ void launch_fused2(int next_prec, int B, hipStream_t st, const StepFusedArgs& a)
 template <bool HALF_IN>
 void launch_fused(int next_prec, int B, hipStream_t st, const StepFusedArgs& a) {
   if (B <= ehm_num_cus()) launch_fused2<HALF_IN, 1024>(next_prec, B, st, a);     // one body per CU: the wide block
+  else if (B > 2 * ehm_num_cus()) launch_fused2<HALF_IN, 256>(next_prec, B, st, a);   // four blocks per CU (round 6: 1280 bodies 246 -> 222 us, same box)
   else launch_fused2<HALF_IN, 512>(next_prec, B, st, a);                          // two blocks per CU
 }
 

@@ -91,10 +91,12 @@ def test_per_body_step_kernels_do_not_spill(kernels):
         if "step_fused_kernel" in name:
             seen += 1
             nt = k[".max_flat_workgroup_size"]
-            assert nt in (512, 1024), name
+            assert nt in (256, 512, 1024), name
             assert _regs(k) <= 128, f"{name}: {_regs(k)} registers - a CU no longer holds 2048 of these threads"
-            # (the 512-thread form - more bodies than CUs - keeps a dozen spilled dwords at its 128-register cap; the 1024-thread form none)
-            assert k[".private_segment_fixed_size"] <= (64 if nt == 512 else 0), f"{name}: {k['.private_segment_fixed_size']} bytes of scratch per lane"
+            # (the 512- / 256-thread forms - more bodies than CUs - keep a dozen spilled dwords at their 128-register cap; the 1024-thread form none)
+            assert k[".private_segment_fixed_size"] <= (64 if nt <= 512 else 0), f"{name}: {k['.private_segment_fixed_size']} bytes of scratch per lane"
+            if nt == 256:                                   # four of these per CU: LDS must leave room for them
+                assert k[".group_segment_fixed_size"] <= 40 * 1024, f"{name}: {k['.group_segment_fixed_size']} bytes of LDS"
     assert seen >= 4
 
 

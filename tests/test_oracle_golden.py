@@ -261,6 +261,22 @@ def test_g16_end_to_end_sensitive(golden_dir, sensitive_weights, smpl_asset, nam
     _check_out(o, g, atol=1e-4)
 
 
+def test_g18_rows_of_the_full_size_golden(golden_dir, sensitive_weights, smpl_asset):
+    """The oracle against the reference's FULL-SIZE run of BASELINE config 2 (golden G18: 256 items, DDIM-10 of 100, 4096 scene points): items are independent
+    (BatchNorm in eval mode, per-item conditioning), so the oracle on three items of that batch - the first two and the last - must reproduce their rows."""
+    g = _load(golden_dir, "g18_c2_ddim10_b256_sensitive")
+    B, N, n, rs = int(g["B"]), int(g["N"]), int(g["n"]), str(g["respacing"])
+    rows = [0, 1, B - 1]
+    full = syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"]))
+    sub = {k: ({kk: vv[rows] for kk, vv in v.items()} if isinstance(v, dict) else v[rows]) for k, v in full.items()}
+    tab = schedule.make_tables(n, rs)
+    noise = torch.from_numpy(syn.make_noise_stack(tab.num_timesteps, B, seed=int(g["noise_seed"]))[:, rows])
+    m = _model(sensitive_weights, smpl_asset, faithful=False)
+    o = sampler.val_losses(m, _tt(sub), tab, noise, rs)
+    gs = {k: (g[k][rows] if getattr(g[k], "ndim", 0) >= 1 and g[k].shape[0] == B else g[k]) for k in g.files}
+    _check_out(o, gs, atol=1e-4)
+
+
 def test_g17_end_to_end_gain03(golden_dir, smpl_asset):
     """the oracle on the partially sensitive weights (low-noise gain 0.3) vs the reference's own DDPM-100 on them (golden G17: the
     reference gate of a MIXED plain-f16 / split-f16 schedule, tests/test_gpu_schedule.py)."""

@@ -239,7 +239,7 @@ extern "C" int ehm_sample_loop(ehm_gcn* gcn, ehm_smpl* smpl, const ehm_sample_de
   EHM_CHECK_ARG(nh % 2 == 0);
   bool any_guided = false;
   for (int k = 0; k < d->num_steps; ++k) any_guided |= steps[k].grad_scale != 0.f;
-  EHM_CHECK_ARG(!any_guided || (scene && d->num_scene_points > 0 && !d->ddim));
+  EHM_CHECK_ARG(!any_guided || (scene && d->num_scene_points > 0));      // (ddim rows with grad_scale != 0: ddim_sample_with_grad, gaussian_diffusion.py:559-614)
   const ehm_nonlocal_params* nlp = ehm_gcn_nonlocal(gcn);
   EHM_CHECK_ARG(d->nonlocal_ci == nlp->Ci);                                            // the descriptor sized the workspace for the block that is set
   EHM_CHECK_ARG(nlp->Ci == 0 || (ehm_gcn_get_precision(gcn) != 2 && d->lowprec_steps == 0));   // the block reads float32 features

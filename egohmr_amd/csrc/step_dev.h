@@ -203,8 +203,16 @@ __device__ __forceinline__ void step_body_one(int b, int lane, const StepBodyArg
     if (a.trace) a.trace[i] = xv;
     float out;
     if (a.ddim) {
-      const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(a.c.sqrt_recip_ac, xv), x0), a.c.sqrt_recipm1_ac);
-      const float mean = __fadd_rn(__fmul_rn(x0, a.c.sqrt_ac_prev), __fmul_rn(a.c.dir_coef, eps));
+      float x0u = x0;                                         // x0 the UPDATE runs on (a.x0 / the pose keep the model's own x0, as the reference's other_outputs do)
+      if (a.grad) {
+        // ddim_sample_with_grad, gaussian_diffusion.py:580-592 (the last four respaced steps): eps -= sqrt(1 - alpha_bar) * grad * 1.0, x0 re-derived from it;
+        // c.grad_scale carries float32 sqrt(1 - alpha_bar); one rounding per torch op
+        float e1 = __fdiv_rn(__fsub_rn(__fmul_rn(a.c.sqrt_recip_ac, xv), x0), a.c.sqrt_recipm1_ac);       // :582 _predict_eps_from_xstart
+        e1 = __fsub_rn(e1, __fmul_rn(a.c.grad_scale, a.grad[i]));                                          // :585-586
+        x0u = __fsub_rn(__fmul_rn(a.c.sqrt_recip_ac, xv), __fmul_rn(a.c.sqrt_recipm1_ac, e1));             // :587 _predict_xstart_from_eps
+      }
+      const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(a.c.sqrt_recip_ac, xv), x0u), a.c.sqrt_recipm1_ac);
+      const float mean = __fadd_rn(__fmul_rn(x0u, a.c.sqrt_ac_prev), __fmul_rn(a.c.dir_coef, eps));
       out = __fadd_rn(mean, __fmul_rn(__fmul_rn(a.c.nonzero, a.c.sigma), nz));
     } else {
       float mean = __fadd_rn(__fmul_rn(a.c.coef1, x0), __fmul_rn(a.c.coef2, xv));

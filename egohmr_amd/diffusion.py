@@ -124,6 +124,8 @@ class GaussianDiffusion:
         if guided and not ddim and i <= 10:                                           # :378 (respaced index)
             # :381 float32(w) * variance (tensor op)  /  :385 float32(w * 0.01) (python floats first)
             c.grad_scale = _f32(np.float32(grad_weight) * np.float32(c.variance)) if i >= 5 else _f32(float(grad_weight) * 0.01)
+        if guided and ddim and i <= 3:                                                # ddim_sample_with_grad :580-586: eps -= (1 - alpha_bar).sqrt() * grad * 1.0
+            c.grad_scale = float(th.sqrt(1 - ab))                                     # (float32 tensor ops, as the reference's _extract_into_tensor broadcast)
         return c
 
     # ------------------------------------------------------------------ forward process (used for init_data)
@@ -187,7 +189,7 @@ class GaussianDiffusion:
         if noise is None:
             noise = th.randn_like(xc)                                                 # :331 / :547 (drawn even at t == 0)
         noise = _lib.f32(noise, x.device)
-        c = self.step_coefs(i, ddim, eta, cond_grad_weight, guided and not ddim)
+        c = self.step_coefs(i, ddim, eta, cond_grad_weight, guided and not ddim)   # (the generic route spells ddim_sample_with_grad out below)
         grad = None
         if c.grad_scale != 0.0:
             grad = _lib.f32(model.guide_coll(batch, mo, t, compute_grad="x_t"), x.device)   # :379
@@ -223,8 +225,9 @@ class GaussianDiffusion:
         return self._step(model, batch, x, t, True, False, 0.0, eta, noise)
 
     def ddim_sample_with_grad(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, eta=0.0, noise=None):
-        """gaussian_diffusion.py:559-614 (the reference notes at :579 that DDIM "does not work well" with the collision guidance;
-        built for completeness of the call surface, generic route only)."""
+        """gaussian_diffusion.py:559-614 (the reference notes at :579 that DDIM "does not work well" with the collision guidance; built for
+        completeness of the call surface).  This is the single step of the generic route; ddim_sample_loop(cond_fn_with_grad=True) runs the same
+        update inside the one-call loop (step_dev.h: step_body_one, ehm_step_coefs.grad_scale = sqrt(1 - alpha_bar) on the last four steps)."""
         return self._step(model, batch, x, t, True, True, 1.0, eta, noise)
 
     # ------------------------------------------------------------------ loops
@@ -305,10 +308,11 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, batch, shape, noise=None, clip_denoised=True, denoised_fn=None, device=None, progress=False,
                          eta=0.0, skip_timesteps=0, init_data=None, cond_fn_with_grad=False, noise_stack=None):
         """gaussian_diffusion.py:618-658."""
-        if self._fused_ok(model, skip_timesteps, init_data, None, progress, eta) and not cond_fn_with_grad:
+        if self._fused_ok(model, skip_timesteps, init_data, None, progress, eta):
+            # (cond_fn_with_grad: ddim_sample_with_grad inside the one-call loop - the collision gradient enters eps on the last four respaced steps)
             device = self._device_of(model, device)
             stack = noise_stack if noise_stack is not None else self._draw_stack(shape, device, noise)
-            return model.fused_sampler.run(self, batch, stack, ddim=True, guided=False, cond_grad_weight=0.0)
+            return model.fused_sampler.run(self, batch, stack, ddim=True, guided=bool(cond_fn_with_grad), cond_grad_weight=1.0 if cond_fn_with_grad else 0.0)
         final = None
         for sample in self.ddim_sample_loop_progressive(
                 model, batch, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, device=device,

@@ -758,7 +758,9 @@ class FusedSampler:
             else:
                 _lib.check(L.ehm_gcn_stack_status(gcn, _lib.stream_ptr()), "ehm_gcn_stack_status")
                 m.backbone.check_status()                 # (the stream has been waited for: the trunk's stream-K time-out word is there)
-        return {"sample": x_final, "pred_xstart": x0, "other_outputs": out}
+        # ddim_sample_with_grad hands out the GUIDED x0 of its last step as pred_xstart (gaussian_diffusion.py:587-592) while other_outputs keep the model's own;
+        # that step has alpha_bar_prev = 1, so its sample IS the guided x0 (x0g * 1 + 0 * eps)
+        return {"sample": x_final, "pred_xstart": x_final if (ddim and any_guided) else x0, "other_outputs": out}
 
     def check_status(self):
         """Raise if a sampling call issued with defer_status=True flagged its chained launches (see run()), or if a stream-K conv of the ResNet-50

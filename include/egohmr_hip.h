@@ -455,7 +455,8 @@ typedef struct {
   float coef1, coef2, log_variance, variance; /* DDPM */
   float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_prev, dir_coef, sigma; /* DDIM */
   float nonzero;   /* 0 at respaced index 0 */
-  float grad_scale; /* 0 = unguided step; else cond_grad_weight*variance or cond_grad_weight*0.01 */
+  float grad_scale; /* 0 = unguided step; p_sample_with_grad: cond_grad_weight*variance or cond_grad_weight*0.01 (gaussian_diffusion.py:378-385);
+                       ddim_sample_with_grad (ddim = 1): float32 sqrt(1 - alpha_bar) on the last four respaced steps (:580-592, scale 1.0) */
 } ehm_step_coefs;
 
 typedef struct {

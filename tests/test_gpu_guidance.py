@@ -178,12 +178,23 @@ def test_guided_ddim_vs_reference_golden(golden_dir, dev, model):
     for out in d.ddim_sample_loop_progressive(model, b, [B, 144], cond_fn_with_grad=True, noise_stack=noise):
         xs.append(out["sample"].cpu().numpy())
     np.testing.assert_allclose(np.stack(xs[:-1]), g["x_t_trace"], atol=2e-4)
-    o = d.val_losses(model, b, shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False,
-                     cond_fn_with_grad=True, noise_stack=noise)
     c = lambda t: t.detach().cpu().numpy()
-    np.testing.assert_allclose(c(o["pred_x_start"]), g["pred_x_start"], atol=2e-4)
-    np.testing.assert_allclose(c(o["pred_vertices"][:, :64]), g["verts_head"], atol=1e-4)
-    np.testing.assert_allclose(c(o["pred_keypoints_3d"]), g["joints"], atol=1e-4)
+    # both routes of the loop: the one-call native loop (round 6: the guided DDIM update lives in step_body_one) and the python-driven generic one
+    for fused in (True, False):
+        d.allow_fused = fused
+        o = d.val_losses(model, b, shape=[B, 144], clip_denoised=False, timestep_respacing=rs, compute_loss=False,
+                         cond_fn_with_grad=True, noise_stack=noise)
+        np.testing.assert_allclose(c(o["pred_x_start"]), g["pred_x_start"], atol=2e-4)
+        np.testing.assert_allclose(c(o["pred_vertices"][:, :64]), g["verts_head"], atol=1e-4)
+        np.testing.assert_allclose(c(o["pred_keypoints_3d"]), g["joints"], atol=1e-4)
+    d.allow_fused = True
+    fs = model.fused_sampler
+    r = fs.run(d, dict(b), noise, ddim=True, guided=True, cond_grad_weight=1.0, trace=True)
+    np.testing.assert_allclose(fs.last_trace.cpu().numpy(), g["x_t_trace"], atol=2e-4)          # x_t fed to every step, guided tail included
+    np.testing.assert_allclose(c(r["sample"]), xs[-1], atol=2e-5)                               # the final sample of the generic route
+    assert torch.equal(r["pred_xstart"], r["sample"])                                           # the guided x0 of the last step (alpha_bar_prev = 1)
+    ru = fs.run(d, dict(b), noise, ddim=True, guided=False)
+    assert float((ru["sample"] - r["sample"]).abs().max()) > 2e-5                               # the guidance is live in the one-call loop
     # the guidance was live on the last steps only
     xs0 = [out["sample"].cpu().numpy() for out in d.ddim_sample_loop_progressive(model, b, [B, 144], cond_fn_with_grad=False, noise_stack=noise)]
     assert np.abs(xs0[-1] - xs[-1]).max() > 2e-5 and np.abs(xs0[5] - xs[6]).max() == 0.0

@@ -117,7 +117,8 @@ def v2v(pred_vertices: torch.Tensor, pred_pelvis, gt_vertices: torch.Tensor, gt_
     """test_egohmr.py:441-443: pelvis-aligned mean vertex-to-vertex error."""
     p, g, lead = _bs_form(pred_vertices, gt_vertices)
     B, S = p.shape[0], p.shape[1]
-    po = pred_pelvis.expand(*lead, 1, 3).reshape(B, S, 3)
+    po = pred_pelvis.reshape(-1, 3)
+    po = (po if po.shape[0] == B * S else po.reshape(B, -1, 3).expand(B, S, 3)).reshape(B, S, 3)      # [..., 1, 3] per sample, or one pelvis per item
     go = gt_pelvis.reshape(-1, 3)
     go = go if go.shape[0] == B else go.expand(B, 3)
     return point_errors(p, g, pred_origin=po, gt_origin=go)["mean"].reshape(lead)

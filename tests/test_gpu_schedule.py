@@ -126,6 +126,28 @@ def test_full_size_configs_vs_reference_golden(golden_dir, dev, model_sens, name
     _check_out(o, g)
 
 
+def test_contract_bar_schedule_at_full_size_vs_reference_golden(golden_dir, dev, smpl_asset):
+    """The schedule calibrated to the north-star's OWN bar (schedule_tol = 1e-4 m: criterion 5e-5 m on two calibration draws; bench.py's `schedule_at_contract_tol`
+    leg) on the headline workload at full size against the reference itself (G18): a genuinely MIXED schedule (plain-f16 hidden convs on the first steps) whose
+    256 bodies stay inside the 1e-4 m contract - measured 4.2e-5 / 4.5e-5 m (profiles/r06q_schedule_tol_vs_reference_full_size.jsonl).  The default stays 1e-5 m."""
+    from egohmr_amd.diffusion import create_gaussian_diffusion
+    from egohmr_amd.factory import batch_to_device, build_synthetic_model
+    g = _load(golden_dir, "g18_headline_ddpm100_b256_sensitive")
+    B, N, n = int(g["B"]), int(g["N"]), int(g["n"])
+    m = build_synthetic_model(dev, 0, diffuse_fuse=True, smpl_asset=smpl_asset, sensitive=dict(num_diffusion_timesteps=n))
+    m.schedule_tol = 1e-4
+    d = create_gaussian_diffusion(num_diffusion_timesteps=n, timestep_respacing="")
+    b = batch_to_device(syn.make_batch(B, num_scene_points=N, seed=int(g["batch_seed"])), dev)
+    noise = torch.from_numpy(syn.make_noise_stack(d.num_timesteps, B, seed=int(g["noise_seed"]))).to(dev)
+    o = d.val_losses(m, b, shape=[B, 144], clip_denoised=False, timestep_respacing="", compute_loss=False, noise_stack=noise)
+    info = m.fused_sampler.schedule_info
+    dv = np.abs(o["pred_vertices"][:, :64].cpu().numpy() - g["verts_head"]).max()
+    dj = np.abs(o["pred_keypoints_3d"].cpu().numpy() - g["joints"]).max()
+    print(f"[contract-bar schedule, headline at B = 256] k = {info['k']} of {info['T']}; max|dverts| = {dv:.3e} m, max|djoints| = {dj:.3e} m vs the reference")
+    assert info["k"] < info["T"], info                       # plain-f16 steps are really in it
+    assert dv < 1e-4 and dj < 1e-4
+
+
 def test_config3_guided_full_item_count_vs_reference_golden(golden_dir, dev, model_sens):
     """BASELINE config 3 at its full item count against the reference: 128 items, collision-guided 100-step DDPM (weight 2, guidance on the last steps), two of
     its ten samples - the reference's two sequential loops over the batch (g18, encoders memoised) against the product's ONE loop over 2 x 128 bodies

@@ -289,6 +289,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     sens = dict(num_diffusion_timesteps=n) if args.weights == "sensitive" else None
     model = build_synthetic_model(dev, 0, diffuse_fuse=True, sensitive=sens, volsmpl=volsmpl)
     model.lbs_every_step = not args.no_lbs_every_step
+    if args.loop_bodies is not None:
+        model.loop_bodies = int(args.loop_bodies)
     model.gcn_precision = args.precision
     if args.precision_given is None and workload in WORKLOAD_PRECISION:
         model.encoder_precision = "f16"
@@ -481,7 +483,12 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
     if rank == 0:
         passes = 2
         hid = model.diffusion_model.hid_dim
-        vbodies = S * (B + (st.num_masked if model.prune_passes else B))            # body-passes per launch after pass pruning
+        # samples of an item run in groups of loop_bodies // B per fused loop (FusedSampler.run_samples): a LAUNCH works on S_l samples' bodies
+        lb = int(getattr(model, "loop_bodies", 0) or 0)
+        g_s = S if (lb <= 0 or S == 1) else max(1, min(S, lb // B))
+        n_groups = -(-S // g_s)
+        S_l = S / n_groups                                                            # samples per launch (average when S % g_s != 0)
+        vbodies = S_l * (B + (st.num_masked if model.prune_passes else B))          # body-passes per launch after pass pruning
         rows = vbodies * 24
         flops = hidden_layer_flops(vbodies, hid)
         n_hidden = 2 * model.diffusion_model.num_layers
@@ -513,7 +520,7 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_call"])            # the kernel the job spends most time in
         # HBM-bound kernels of the step (per-kernel GB/s against 8 TB/s), algorithmic bytes per launch
         act_b = 2 if prof["chain_f16"]["launches_per_call"] >= prof["chain_f16x3"]["launches_per_call"] else 4   # bytes per activation element of the majority of steps
-        nb = S * B
+        nb = S_l * B
         hbm = {}
 
         def hbm_entry(cls, kernel, bytes_per_launch, what):
@@ -526,8 +533,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
         hbm_entry("out_dot", "gcn_out_dot_kernel (output conv responses [rows,hid] x [hid,12])", rows * hid * act_b + rows * 12 * 4,
                   f"rows*hid*{act_b} B activations read + rows*12*4 B responses written, rows = {rows}")
         n_skin = prof["skin_input"]["launches_per_call"]
-        steps_per_skin = T / n_skin if n_skin else 0
-        if n_skin and n_skin < T:      # deferred skinning: one launch covers steps_per_skin steps
+        steps_per_skin = T * n_groups / n_skin if n_skin else 0
+        if n_skin and n_skin < T * n_groups:      # deferred skinning: one launch covers steps_per_skin steps
             hbm_entry("skin_input", f"skin_mfma_kernel (LBS skinning of {steps_per_skin:g} steps x {nb} bodies in one launch, docs/EXPERIMENTS.md 3.7)",
                       steps_per_skin * nb * (6890 * 3 * 4 + 21 * 3 * 4 + 24 * 12 * 4 + 2 * 224 * 2) + 19.3e6,
                       "per body-step 82,680 B vertices + extra joints + transforms + blend coefficients (SURVEY 8d) + SMPL constants 19.3 MB once per launch")
@@ -545,8 +552,8 @@ def measure(args, workload, steps, warmup, legs_on, cpu_seconds, dev, rank, worl
                       "rows*hid activation rows read (last hidden conv) + rows*hid rows written (next input) + h_img / h_oth slices + x_t / noise / x0 / x_next")
             n_pose = prof["step_body"]["launches_per_call"]
             if n_pose:
-                hbm_entry("step_body", f"pose_steps_kernel (rot6d + 24-joint chain + blend fragments of {T / n_pose:g} steps x {nb} bodies in one launch; one wave per body-step)",
-                          T / n_pose * nb * (576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2), "per body-step: x0 576 B + betas + R + A + joints + blend-coefficient fragments")
+                hbm_entry("step_body", f"pose_steps_kernel (rot6d + 24-joint chain + blend fragments of {T * n_groups / n_pose:g} steps x {nb:g} bodies in one launch; one wave per body-step)",
+                          T * n_groups / n_pose * nb * (576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2), "per body-step: x0 576 B + betas + R + A + joints + blend-coefficient fragments")
         else:
             hbm_entry("step_body", "step_body_kernel (output mix + sampler update + rot6d + 24-joint chain; one wave per body)",
                       nb * (2 * 24 * 12 * 4 + 5 * 576 + 40 + 864 + 1152 + 288 + 2 * 224 * 2),
@@ -676,6 +683,7 @@ def main():
     ap.add_argument("--f16x3-last-steps", type=int, default=None,
                     help="explicit k instead of the calibration (e.g. the k a previous run printed): no calibration launches, so that under rocprofv3 "
                          "every launch of a chain kernel is a full-size one and the kernel-stats average equals roofline.avg_launch_ms * 8")
+    ap.add_argument("--loop-bodies", type=int, default=None, help="EgoHMR.loop_bodies for this run (bodies per fused loop of a multi-sample batch)")
     ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (all-f16x3, f32, f16, other weight set)")
     ap.add_argument("--no-configs", action="store_true", help="default workload only: do not append BASELINE configs 2 and 3 (configs.c2_ddim10 / configs.c3_guided)")
     ap.add_argument("--launch-check", action="store_true", help="only initialise the ranks, report the world size, exit (works without a GPU: gloo)")

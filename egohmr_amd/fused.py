@@ -576,15 +576,38 @@ class FusedSampler:
     @torch.no_grad()
     def run_samples(self, diffusion, batch, noise_stacks, ddim=False, guided=False, cond_grad_weight=1.0, defer_status=False):
         """The reference draws S samples per item with S sequential sampling loops over the same batch (test_egohmr.py:251-266).  The
-        samples are independent given the conditioning, so this runs them as ONE loop over S*B bodies (sample-major: body s*B + b) with
-        the conditioning replicated by index - the same arithmetic per body (the guidance denominator stays B), S times fewer launches
-        and full-size conv tiles for small B.  noise_stacks: S tensors [T+1,B,144].  Returns a list of S result dicts like run()."""
+        samples are independent given the conditioning, so this runs them as loops over g*B bodies (sample-major: body s*B + b) with
+        the conditioning replicated by index - the same arithmetic per body (the guidance denominator stays B), fewer launches and
+        full-size conv tiles for small B.  g = EgoHMR.loop_bodies // B samples share a loop (at least one): about 256 bodies per loop keep the
+        three activation matrices of the chained hidden convs (50 MB each) inside the 256 MB Infinity Cache and give every layer whole rounds
+        of tiles - ONE loop over 1280 bodies ran the chain kernel at 0.173 of peak, loops of 256 at 0.188 (profiles/r06r_loop_bodies_ab.txt).
+        noise_stacks: S tensors [T+1,B,144].  Returns a list of S result dicts like run()."""
         S = len(noise_stacks)
         st = self.prepare(batch)
         if S == 1:
             return [self.run(diffusion, batch, noise_stacks[0], ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=st,
                              defer_status=defer_status)]
         B = st.B
+        width = int(getattr(self.model, "loop_bodies", 0) or 0)
+        g = S if width <= 0 else max(1, min(S, width // max(B, 1)))
+        outs = []
+        for s0 in range(0, S, g):
+            outs += self._run_sample_group(diffusion, batch, st, noise_stacks[s0:s0 + g], ddim, guided, cond_grad_weight, defer_status)
+        # leave the model's per-call attributes as S sequential calls would: un-replicated inputs, the last sample's bodies
+        m = self.model
+        m.scene_pcd_verts, m.input_transl = st.scene, st.transl
+        m.focal_length, m.camera_center_full = m.focal_length[:B], m.camera_center_full[:B]
+        last = outs[-1]["other_outputs"]
+        m.smpl_output = smpl_mod.SMPLOutput(vertices=last["pred_vertices"], joints=last["pred_keypoints_3d"],
+                                            full_pose=torch.cat([last["pred_smpl_params"]["global_orient"], last["pred_smpl_params"]["body_pose"]], dim=1))
+        return outs
+
+    def _run_sample_group(self, diffusion, batch, st, noise_stacks, ddim, guided, cond_grad_weight, defer_status):
+        """S samples of the prepared batch `st` as ONE loop over S*B bodies -> S result dicts."""
+        S, B = len(noise_stacks), st.B
+        if S == 1:
+            return [self.run(diffusion, dict(batch), noise_stacks[0], ddim=ddim, guided=guided, cond_grad_weight=cond_grad_weight, prepared=st, denom_items=B,
+                             defer_status=defer_status)]
         rep = lambda t: t.repeat(S, *([1] * (t.dim() - 1))).contiguous()
         fields = {k: (rep(v) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B and k not in ("mask_items", "mask_slot") else v)
                   for k, v in vars(st).items()}
@@ -609,15 +632,7 @@ class FusedSampler:
                 parts = {k: split(v) for k, v in x.items()}
                 return [{k: parts[k][i] for k in x} for i in range(S)]
             return [x] * S
-        outs = split(res)
-        # leave the model's per-call attributes as S sequential calls would: un-replicated inputs, the last sample's bodies
-        m = self.model
-        m.scene_pcd_verts, m.input_transl = st.scene, st.transl
-        m.focal_length, m.camera_center_full = m.focal_length[:B], m.camera_center_full[:B]
-        last = outs[-1]["other_outputs"]
-        m.smpl_output = smpl_mod.SMPLOutput(vertices=last["pred_vertices"], joints=last["pred_keypoints_3d"],
-                                            full_pose=torch.cat([last["pred_smpl_params"]["global_orient"], last["pred_smpl_params"]["body_pose"]], dim=1))
-        return outs
+        return split(res)
 
     # ------------------------------------------------------------------ whole loop
     @torch.no_grad()

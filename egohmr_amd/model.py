@@ -381,6 +381,11 @@ class EgoHMR(nn.Module):
         # switch this model to gcn_precision 'f32' (float32 activations, no such limit) and run the call again.  Calls issued with defer_status=True
         # always raise (at check_status(): their results have been handed out already)
         self.on_saturation = "raise"
+        # FusedSampler.run_samples: the S samples of an item run as fused loops over about this many bodies each (loop_bodies // B samples per loop, at least
+        # one; 0 = all S x B bodies in one loop).  256 bodies = the three 50 MB activation matrices of the chained hidden convs stay inside the 256 MB Infinity
+        # Cache and every layer is whole rounds of tiles: chain kernel 0.188 of peak against 0.174 for one 1280-body loop (config 4: 4.74 -> 5.06 k bodies/s,
+        # config 3: 2.40 -> 2.50 k; profiles/r06r_loop_bodies_ab.txt).  Results do not depend on the grouping (bodies are independent).
+        self.loop_bodies = 256
         self.per_step_launches = False     # True: the separate per-step launches of rounds 2-3 instead of step_fused_kernel (same bits; A/B runs and tests)
         self.pass_group = 1                # second passes pruned per item (1) or per group of this many consecutive items (FusedSampler.prepare)
         self.prune_passes = True           # exact: items whose 24 joints are all visible skip the image-masked pass (egohmr.py:239-254)
